@@ -1,0 +1,272 @@
+/*
+ * usc3d.h — flat C ABI of libusc3d_hip.so: the MI355X (gfx950) hot path of
+ * UnScene3D's self-training step and pseudo-mask generator.
+ *
+ * Every entry point takes raw DEVICE pointers (caller-owned, contiguous,
+ * row-major), plain sizes and an explicit stream (hipStream_t passed as
+ * void*).  No entry point allocates, frees, synchronises or keeps a pointer
+ * beyond the call; scratch memory is passed in by the caller (sizes via the
+ * *_ws_bytes helpers).  Every function returns 0 on success or a negative
+ * usc_status; usc_last_error() gives the message (the Python wrapper raises
+ * RuntimeError — never exit()/abort(), cf. reference cuda_utils.cpp:4-6 vs
+ * pointnet2 cuda_utils.h:32-41).
+ *
+ * Each declaration cites the reference interface it replaces
+ * (paths relative to RozDavid/UnScene3D @ 2024_10_08).
+ * [ME] = MinkowskiEngine 0.5.4, an un-vendored dependency of the reference
+ * (conf/unscene3d_requirements.txt:50); semantics restated in oracle/.
+ */
+#ifndef USC3D_H
+#define USC3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* usc_stream_t; /* hipStream_t */
+
+enum usc_status {
+  USC_OK = 0,
+  USC_ERR_ARG = -1,     /* bad argument (null pointer, unsupported shape) */
+  USC_ERR_LAUNCH = -2,  /* HIP launch/runtime error */
+  USC_ERR_RANGE = -3    /* coordinate outside the packable range */
+};
+
+/* Message for the last failing call on this thread ("" if none). */
+const char* usc_last_error(void);
+/* Library/ABI version (bumped on any signature change). */
+int usc_abi_version(void);
+/* Number of visible HIP devices, or a negative usc_status. */
+int usc_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * V1/V3/R1  coordinate maps  — replaces [ME] ME.utils.sparse_quantize
+ * (datasets/utils.py:403-408, pseudo_masks/datasets/voxelizer.py:142) and the
+ * coordinate-manager insert behind ME.SparseTensor(...) (trainer/trainer.py:115)
+ * and the stride-2 maps implied by MinkowskiConvolution(k=2,s=2)
+ * (models/res16unet.py:51-116).
+ * ---------------------------------------------------------------------- */
+
+/* coords_out[i,:] = floor(xyz[i,:] / voxel_size) in float64 (== np.floor(x/v),
+ * datasets/utils.py:403), cast to int32.  xyz: f64[n,3]. */
+int usc_voxel_floor_f64(const double* xyz, int64_t n, double voxel_size,
+                        int32_t* coords_out, usc_stream_t s);
+
+/* Hash-table capacity (slots, power of two) required for n coordinates. */
+int64_t usc_coordmap_capacity(int64_t n);
+/* Scratch bytes for usc_coordmap_build on n rows. */
+int64_t usc_coordmap_ws_bytes(int64_t n);
+
+/* Build a coordinate map (open-addressing hash on the packed 64-bit key of
+ * (b, x, y, z)) over coords i32[n,4], optionally quantising x,y,z to
+ * multiples of `quant` first (quant<=1: none; quant = 2*tensor_stride builds
+ * the next-coarser map: c -> floor(c/quant)*quant).
+ * Outputs, all caller-allocated:
+ *   table_keys u64[cap], table_vals i32[cap]  — persistent map: key -> row
+ *   unique_idx i64[n]   first n_out entries valid: the FIRST-OCCURRENCE input
+ *                       row of each distinct coordinate, ascending
+ *                       (== unique_map of sparse_quantize)
+ *   inverse    i64[n]   row of the distinct coordinate each input row maps to
+ *                       (== inverse_map)
+ *   out_coords i32[n,4] first n_out rows valid: the distinct (quantised)
+ *                       coordinates in map-row order (may be NULL)
+ *   n_out      i64[1]   device scalar
+ */
+int usc_coordmap_build(const int32_t* coords, int64_t n, int32_t quant,
+                       uint64_t* table_keys, int32_t* table_vals, int64_t cap,
+                       int64_t* unique_idx, int64_t* inverse,
+                       int32_t* out_coords, int64_t* n_out,
+                       void* ws, int64_t ws_bytes, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * R2  kernel maps ("rulebooks") — replaces [ME] the kernel-map construction
+ * cached by the CoordinateManager for MinkowskiConvolution /
+ * MinkowskiConvolutionTranspose / MinkowskiAvgPooling
+ * (models/modules/common.py:125-188, models/mask3d.py:131).
+ * ---------------------------------------------------------------------- */
+
+/* Dense neighbour table for a stride-1 k^3 HYPER_CUBE kernel on one map:
+ *   nbr[k*n + o] = row i with coord_i == coord_o + off_k*tensor_stride, else -1
+ * offsets: ksize=3 -> {-1,0,1}^3, x fastest (k = dx+1 + 3(dy+1) + 9(dz+1)).
+ * coords i32[n,4] are the map's coordinates; table_* its hash table. */
+int usc_kernel_map_cube(const int32_t* coords, int64_t n, int32_t tensor_stride,
+                        int32_t ksize, const uint64_t* table_keys,
+                        const int32_t* table_vals, int64_t cap, int32_t* nbr,
+                        usc_stream_t s);
+
+/* Child table of a k=2,s=2 kernel between a fine map (n_fine rows, tensor
+ * stride ts) and its coarse parent (n_coarse rows):
+ *   nbr2[k*n_coarse + p] = fine row whose parent is p and whose offset index is
+ *       k = ox + 2*oy + 4*oz, o = (c_fine - c_parent)/ts in {0,1}^3, else -1
+ *   kidx[i] = k of fine row i (u8)
+ * parent i64[n_fine] is the `inverse` returned by usc_coordmap_build(quant=2ts).
+ * nbr2 must be pre-filled with -1 by the caller. */
+int usc_kernel_map_down2(const int32_t* fine_coords, int64_t n_fine,
+                         int32_t tensor_stride, const int64_t* parent,
+                         const int32_t* coarse_coords, int64_t n_coarse,
+                         int32_t* nbr2, uint8_t* kidx, usc_stream_t s);
+
+/* Scratch bytes for usc_rulebook_compact on a [K, n_out] table. */
+int64_t usc_rulebook_ws_bytes(int64_t K, int64_t n_out);
+/* Compact a dense neighbour table into per-offset pair lists, ordered by
+ * (k, out row):  for p in [koff[k], koff[k+1]): (in_idx[p], out_idx[p]).
+ * in_idx/out_idx i32[K*n_out] capacity, koff i64[K+1] (device). */
+int usc_rulebook_compact(const int32_t* nbr, int64_t K, int64_t n_out,
+                         int32_t* in_idx, int32_t* out_idx, int64_t* koff,
+                         void* ws, int64_t ws_bytes, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * C  sparse convolution — replaces [ME] MinkowskiConvolution /
+ * MinkowskiConvolutionTranspose forward + backward
+ * (models/modules/common.py:146,179; instances models/res16unet.py:39-221,
+ * models/modules/resnet_block.py:24-43, models/mask3d.py:60-62).
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+ * ---------------------------------------------------------------------- */
+
+/* out[k][co][ci] = W[mirror ? K-1-k : k][ci][co]  — weights for the dgrad
+ * kernels (mirror=1 for a stride-1 odd kernel whose map is its own transpose). */
+int usc_weight_transpose(const float* W, int32_t K, int32_t cin, int32_t cout,
+                         int32_t mirror, float* out, usc_stream_t s);
+
+/* Output-stationary implicit GEMM over a dense neighbour table:
+ *   out[o,:] = sum_k  in[nbr[k*n_out+o], :] @ W[k]  (+ bias)
+ * in f32[n_in,cin], W f32[K,cin,cout].  nbr==NULL means K==1 identity
+ * (1x1 conv / linear).  bias f32[cout] or NULL.  accumulate=1 adds into out.
+ * Covers: k3/s1 conv fwd and dgrad (W = usc_weight_transpose(mirror=1)),
+ * k2/s2 conv fwd (nbr = child table), conv-transpose dgrad. */
+int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin,
+                           const float* W, int32_t K, int32_t cout,
+                           const int32_t* nbr, int64_t n_out,
+                           const float* bias, float* out, int32_t accumulate,
+                           usc_stream_t s);
+
+/* One-parent form (transposed-conv forward, strided-conv dgrad):
+ *   out[rows_out[p],:] = in[rows_in[p],:] @ W[k]   for p in [koff[k], koff[k+1])
+ * driven by the per-offset pair lists of usc_rulebook_compact on the child
+ * table (every output row appears in exactly one pair).  koff i64[K+1] device,
+ * P_capacity = upper bound of koff[K] known to the host. */
+int usc_spconv_pairs_gemm(const float* in, int32_t cin, const float* W,
+                          int32_t K, int32_t cout, const int32_t* rows_in,
+                          const int32_t* rows_out, const int64_t* koff,
+                          int64_t P_capacity, float* out, usc_stream_t s);
+
+/* Scratch bytes for usc_spconv_wgrad. */
+int64_t usc_spconv_wgrad_ws_bytes(int32_t K, int32_t cin, int32_t cout);
+/* Weight gradient:  dW[k] = sum_{p in list k}  a[a_idx[p],:]^T  b[b_idx[p],:]
+ * a f32[*,cin], b f32[*,cout], dW f32[K,cin,cout]; pair lists as produced by
+ * usc_rulebook_compact (a_idx/b_idx i32, koff i64[K+1] device).
+ * a_idx==NULL && K==1: identity pairs over n_rows (1x1 conv). Deterministic
+ * (fixed split + ordered reduction, no float atomics). */
+int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout,
+                     int32_t K, const int32_t* a_idx, const int32_t* b_idx,
+                     const int64_t* koff, int64_t n_rows, float* dW, void* ws,
+                     int64_t ws_bytes, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * B  row-wise batch norm / ReLU / residual — replaces [ME] MinkowskiBatchNorm
+ * (= BatchNorm1d over feature rows), MinkowskiReLU and `out += residual`
+ * (models/modules/common.py:22, models/modules/resnet_block.py:48-64).
+ * ---------------------------------------------------------------------- */
+
+int64_t usc_colstats_ws_bytes(int64_t n, int32_t c);
+/* Per-channel sums over rows: sum1[c] = sum_i x[i,c], sum2[c] = sum_i x[i,c]*y[i,c]
+ * (y==NULL -> x*x).  Deterministic two-stage reduction.  f32 in, f64 partials. */
+int usc_colstats(const float* x, const float* y, int64_t n, int32_t c,
+                 double* sum1, double* sum2, void* ws, int64_t ws_bytes,
+                 usc_stream_t s);
+/* y = [relu]( x*scale[c] + shift[c] (+ residual) ); mask-free (backward uses y>0). */
+int usc_bn_apply(const float* x, const float* scale, const float* shift,
+                 const float* residual, int32_t relu, float* y, int64_t n,
+                 int32_t c, usc_stream_t s);
+/* BatchNorm backward given saved mean/invstd and channel sums of (dy) and (dy*xhat):
+ *   g = relu_mask ? (y_out>0 ? dy : 0) : dy      (applied on the fly when y_out!=NULL)
+ *   dx = gamma*invstd*( g - mean_g - xhat*mean_gxhat ),  xhat=(x-mean)*invstd
+ * Also writes dres = g when dres != NULL (residual branch gradient). */
+int usc_bn_backward_dx(const float* x, const float* dy, const float* y_out,
+                       const float* mean, const float* invstd,
+                       const float* gamma, const float* mean_g,
+                       const float* mean_gxhat, float* dx, float* dres,
+                       int64_t n, int32_t c, usc_stream_t s);
+/* Channel sums needed by the above: sum_g[c], sum_gxhat[c] (f64). */
+int usc_bn_backward_stats(const float* x, const float* dy, const float* y_out,
+                          const float* mean, const float* invstd, int64_t n,
+                          int32_t c, double* sum_g, double* sum_gxhat, void* ws,
+                          int64_t ws_bytes, usc_stream_t s);
+/* y = max(x,0);  dx = (y>0) ? dy : 0 */
+int usc_relu_fwd(const float* x, float* y, int64_t numel, usc_stream_t s);
+int usc_relu_bwd(const float* y, const float* dy, float* dx, int64_t numel,
+                 usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * P  average pooling — replaces [ME] MinkowskiAvgPooling(kernel_size=2,
+ * stride=2, dimension=3) forward (models/mask3d.py:131,213,432).
+ *   out[p,:] = mean over present children nbr2[k*n_coarse+p]
+ * ---------------------------------------------------------------------- */
+int usc_avgpool_down2(const float* in, int32_t c, const int32_t* nbr2,
+                      int64_t n_coarse, float* out, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * gather / scatter rows (D1 mask-module row gather mask3d.py:418-419, feature
+ * gathers by unique_map datasets/utils.py:412-417)
+ * ---------------------------------------------------------------------- */
+/* out[i,:] = src[idx[i],:]   idx i64[n] */
+int usc_gather_rows(const float* src, int32_t c, const int64_t* idx, int64_t n,
+                    float* out, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Q3  segment mean — replaces torch_scatter.scatter_mean(src, index, dim=0)
+ * (models/mask3d.py:12,223; trainer/trainer.py:449) forward + backward.
+ * CSR built once per scene: order i64[n] rows sorted by segment (stable),
+ * seg_off i64[S+1].
+ * ---------------------------------------------------------------------- */
+int64_t usc_segment_csr_ws_bytes(int64_t n, int64_t S);
+int usc_segment_csr(const int64_t* seg, int64_t n, int64_t S, int64_t* order,
+                    int64_t* seg_off, void* ws, int64_t ws_bytes,
+                    usc_stream_t s);
+int usc_segment_mean_fwd(const float* src, int32_t c, const int64_t* order,
+                         const int64_t* seg_off, int64_t S, float* out,
+                         usc_stream_t s);
+/* dsrc[i,:] = dout[seg[i],:] / count[seg[i]] */
+int usc_segment_mean_bwd(const float* dout, int32_t c, const int64_t* seg,
+                         const int64_t* seg_off, int64_t n, float* dsrc,
+                         usc_stream_t s);
+
+/* Per-segment mean over the NON-ZERO feature rows of each segment (N1:
+ * aggregate_features mode 'mean', pseudo_masks/unscene3d_pseudo_main.py:350-402):
+ * out f32[S,d], nonzero_cnt i64[S] (may be NULL).  Uses the segment CSR. */
+int usc_segment_mean_nonzero(const float* feats, int32_t d,
+                             const int64_t* order, const int64_t* seg_off,
+                             int64_t S, float* out, int64_t* nonzero_cnt,
+                             usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Q1  furthest point sampling — replaces pointnet2._ext.furthest_point_sampling
+ * (third_party/pointnet2/_ext_src/src/sampling.cpp:67-88,
+ *  sampling_gpu.cu:73-232; called from models/mask3d.py:228).
+ * xyz f32[b,n,3], tmp f32[b,n] pre-filled with 1e10, idx i32[b,m].
+ * Bit-exact with the reference kernel's result incl. its tie-break
+ * (winner = tied k with smallest (k mod 512), then smallest k, for n>=512)
+ * and its |p|^2 <= 1e-3 skip.
+ * ---------------------------------------------------------------------- */
+int usc_furthest_point_sampling(const float* xyz, int32_t b, int32_t n,
+                                int32_t m, float* tmp, int32_t* idx,
+                                usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Q2  Fourier positional encoding — replaces
+ * PositionEmbeddingCoordsSine.get_fourier_embeddings
+ * (models/position_embedding.py:128-157) with normalize=True
+ * (shift_scale_points :12-40, dst_range [0,1]):
+ *   out[i, :] = [sin(2*pi*xn@B) | cos(2*pi*xn@B)],  xn=(x-lo)/(hi-lo)
+ * xyz f32[n,3], lo/hi f32[3], gauss_B f32[3,d/2], out f32[n,d] (row-major).
+ * ---------------------------------------------------------------------- */
+int usc_fourier_posenc(const float* xyz, int64_t n, const float* lo,
+                       const float* hi, const float* gauss_B, int32_t d,
+                       float* out, usc_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USC3D_H */

@@ -1,0 +1,366 @@
+"""GPU parity: every HIP kernel (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Integer outputs bit-exact; fp32 features within 1e-3 relative
+(BASELINE.json north_star) — in practice ~1e-6 because the MFMA path is exact fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ref as R
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-3   # north_star tolerance for fp32 features / losses
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+def _scene_coords(seed, n, extent, batch=2):
+    rng = np.random.default_rng(seed)
+    c = rng.integers(-extent, extent, size=(n, 3))
+    c[:, 2] = rng.integers(-2, 3, size=n)              # surface-like slab so neighbours exist
+    b = np.sort(rng.integers(0, batch, size=(n, 1)), axis=0)
+    return np.concatenate([b, c], 1).astype(np.int32)
+
+
+def _dev(x, device, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x)) if not isinstance(x, torch.Tensor) else x
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(device).contiguous()
+
+
+@pytest.mark.parametrize("n,extent,quant", [(0, 4, 1), (1, 4, 1), (5000, 12, 1), (40000, 30, 1), (5000, 12, 2),
+                                            (40000, 30, 4)])
+def test_coordmap_bit_exact(device, n, extent, quant):
+    from unscene3d_amd import ops
+
+    c = _scene_coords(n + quant, n, extent)
+    cmap, u, inv = ops.coordmap_build(_dev(c, device), quant=quant, tensor_stride=quant)
+    eu, einv, ec = R.coordmap_build(c, quant)
+    assert np.array_equal(u.cpu().numpy(), eu)
+    assert np.array_equal(inv.cpu().numpy(), einv)
+    assert np.array_equal(cmap.coords.cpu().numpy(), ec)
+
+
+def test_coordmap_range_error(device):
+    from unscene3d_amd import ops
+
+    c = np.array([[0, 0, 0, 0], [0, 1 << 20, 0, 0]], np.int32)
+    with pytest.raises(RuntimeError):
+        ops.coordmap_build(_dev(c, device))
+
+
+def test_voxel_floor_matches_numpy(device):
+    from unscene3d_amd import ops
+
+    rng = np.random.default_rng(0)
+    xyz = rng.uniform(-3, 3, (20000, 3))
+    xyz[:100] = np.round(xyz[:100] / 0.02) * 0.02      # values on voxel boundaries
+    got = ops.voxel_floor(_dev(xyz, device), 0.02).cpu().numpy()
+    assert np.array_equal(got, R.voxel_floor(xyz, 0.02))
+
+
+def _maps(device, seed=1, n=6000, extent=14):
+    from unscene3d_amd import ops
+
+    c = R.coordmap_build(_scene_coords(seed, n, extent))[2]
+    cmap, _, _ = ops.coordmap_build(_dev(c, device))
+    return c, cmap
+
+
+def test_kernel_maps_bit_exact(device):
+    from unscene3d_amd import ops
+
+    c, cmap = _maps(device)
+    nbr = ops.kernel_map_cube(cmap, 3)
+    enbr = R.kernel_map_cube(c, 1)
+    assert np.array_equal(nbr.cpu().numpy(), enbr)
+    rb = ops.rulebook_compact(nbr)
+    ei, eo, ek = R.rulebook_compact(enbr)
+    assert np.array_equal(rb.koff.cpu().numpy(), ek)
+    assert np.array_equal(rb.in_idx.cpu().numpy(), ei) and np.array_equal(rb.out_idx.cpu().numpy(), eo)
+    # strided level
+    coarse, _, parent = ops.coordmap_build(cmap.coords, quant=2, tensor_stride=2)
+    _, eparent, ecc = R.coordmap_build(c, 2)
+    assert np.array_equal(parent.cpu().numpy(), eparent)
+    nbr2, kidx = ops.kernel_map_down2(cmap, parent, coarse)
+    enbr2, ekidx = R.kernel_map_down2(c, 1, eparent, ecc)
+    assert np.array_equal(nbr2.cpu().numpy(), enbr2) and np.array_equal(kidx.cpu().numpy(), ekidx)
+    # cube map on the coarse level (tensor stride 2)
+    assert np.array_equal(ops.kernel_map_cube(coarse, 3).cpu().numpy(), R.kernel_map_cube(ecc, 2))
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 32), (32, 32), (64, 96), (96, 96), (128, 256), (384, 256), (96, 20)])
+def test_conv3_forward_backward(device, cin, cout):
+    from unscene3d_amd import ops
+
+    c, cmap = _maps(device, seed=cin + cout, n=3000, extent=10)
+    n = len(c)
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, generator=g)
+    W = torch.randn(27, cin, cout, generator=g) / np.sqrt(27 * cin)
+    dy = torch.randn(n, cout, generator=g)
+    enbr = R.kernel_map_cube(c, 1)
+    xr, Wr = x.clone().requires_grad_(), W.clone().requires_grad_()
+    yr = R.conv_gather(xr, Wr, enbr, n)
+    yr.backward(dy)
+
+    nbr = ops.kernel_map_cube(cmap, 3)
+    xd, Wd = _dev(x, device).requires_grad_(), _dev(W, device).requires_grad_()
+    y = ops.conv_same(xd, Wd, None, nbr, lambda: ops.rulebook_compact(nbr))
+    y.backward(_dev(dy, device))
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5
+    assert rel_err(Wd.grad, Wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (128, 128), (256, 128), (96, 96)])
+def test_strided_and_transposed_conv(device, cin, cout):
+    from unscene3d_amd import ops
+
+    c, cmap = _maps(device, seed=3, n=4000, extent=12)
+    coarse, _, parent = ops.coordmap_build(cmap.coords, quant=2, tensor_stride=2)
+    nbr2, kidx = ops.kernel_map_down2(cmap, parent, coarse)
+    _, eparent, ecc = R.coordmap_build(c, 2)
+    enbr2, ekidx = R.kernel_map_down2(c, 1, eparent, ecc)
+    n, nc = len(c), len(ecc)
+    g = torch.Generator().manual_seed(11)
+    rb = ops.rulebook_compact(nbr2)
+
+    # down conv
+    x = torch.randn(n, cin, generator=g)
+    W = torch.randn(8, cin, cout, generator=g) / np.sqrt(8 * cin)
+    dy = torch.randn(nc, cout, generator=g)
+    xr, Wr = x.clone().requires_grad_(), W.clone().requires_grad_()
+    yr = R.conv_gather(xr, Wr, enbr2, nc)
+    yr.backward(dy)
+    xd, Wd = _dev(x, device).requires_grad_(), _dev(W, device).requires_grad_()
+    y = ops.conv_down2(xd, Wd, nbr2, lambda: rb)
+    y.backward(_dev(dy, device))
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5
+
+    # transposed conv back to the fine map
+    xc = torch.randn(nc, cin, generator=g)
+    Wt = torch.randn(8, cin, cout, generator=g) / np.sqrt(8 * cin)
+    dyf = torch.randn(n, cout, generator=g)
+    xcr, Wtr = xc.clone().requires_grad_(), Wt.clone().requires_grad_()
+    import oracle.res16unet_ref as M
+    yr = M._tr_conv(xcr, Wtr, eparent, ekidx, n)
+    yr.backward(dyf)
+    xcd, Wtd = _dev(xc, device).requires_grad_(), _dev(Wt, device).requires_grad_()
+    y = ops.conv_tr_up2(xcd, Wtd, nbr2, lambda: rb, n)
+    y.backward(_dev(dyf, device))
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(xcd.grad, xcr.grad) < 1e-5 and rel_err(Wtd.grad, Wtr.grad) < 1e-5
+
+
+def test_conv1x1_with_bias(device):
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x, W, b = torch.randn(5000, 96, generator=g), torch.randn(96, 128, generator=g) / 10, torch.randn(1, 128, generator=g)
+    dy = torch.randn(5000, 128, generator=g)
+    xr, Wr, br = x.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
+    (xr @ Wr + br).backward(dy)
+    xd, Wd, bd = (_dev(t, device).requires_grad_() for t in (x, W, b))
+    y = ops.conv_same(xd, Wd, bd, None, None)
+    y.backward(_dev(dy, device))
+    assert rel_err(y.detach(), (x @ W + b)) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("c,relu,res", [(32, True, False), (96, True, True), (256, False, False), (100, False, True)])
+def test_batch_norm_act(device, c, relu, res):
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(c)
+    n = 7777
+    x = torch.randn(n, c, generator=g) * 3 + 1
+    r = torch.randn(n, c, generator=g) if res else None
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    dy = torch.randn(n, c, generator=g)
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rr = r.clone().requires_grad_() if res else None
+    rm, rv = torch.zeros(c), torch.ones(c)
+    yr = torch.nn.functional.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.02, eps=1e-5)
+    if res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy)
+    xd, gd, bd = (_dev(t, device).requires_grad_() for t in (x, gamma, beta))
+    rd = _dev(r, device).requires_grad_() if res else None
+    rmd, rvd = torch.zeros(c, device=device), torch.ones(c, device=device)
+    y = ops.batch_norm_act(xd, gd, bd, rd, relu, 1e-5, rmd, rvd, 0.02, True)
+    y.backward(_dev(dy, device))
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-4
+    assert rel_err(gd.grad, gr.grad) < 1e-4 and rel_err(bd.grad, br.grad) < 1e-4
+    if res:
+        assert rel_err(rd.grad, rr.grad) < 1e-6
+    assert rel_err(rmd, rm) < 1e-5 and rel_err(rvd, rv) < 1e-5
+
+
+def test_avgpool_gather_segment_mean(device):
+    from unscene3d_amd import ops
+
+    c, cmap = _maps(device, seed=9, n=5000, extent=12)
+    coarse, _, parent = ops.coordmap_build(cmap.coords, quant=2, tensor_stride=2)
+    nbr2, _ = ops.kernel_map_down2(cmap, parent, coarse)
+    g = torch.Generator().manual_seed(2)
+    for ch in (3, 100):
+        f = torch.randn(len(c), ch, generator=g)
+        got = ops.avgpool_down2(_dev(f, device), nbr2)
+        exp = R.avgpool_down2(f, nbr2.cpu().numpy())
+        assert rel_err(got, exp) < 1e-6
+    # gather rows fwd/bwd
+    src = torch.randn(300, 128, generator=g)
+    idx = torch.randint(0, 300, (5000,), generator=g)
+    dy = torch.randn(5000, 128, generator=g)
+    sr = src.clone().requires_grad_()
+    sr[idx].backward(dy)
+    sd = _dev(src, device).requires_grad_()
+    out = ops.gather_rows(sd, _dev(idx, device))
+    out.backward(_dev(dy, device))
+    assert torch.equal(out.detach().cpu(), src[idx])
+    assert rel_err(sd.grad, sr.grad) < 1e-5
+    # segment mean fwd/bwd == torch_scatter.scatter_mean
+    S = 321
+    seg = torch.randint(0, S, (len(c),), generator=g)
+    seg[:S] = torch.arange(S)   # every segment non-empty
+    f = torch.randn(len(c), 128, generator=g)
+    fr = f.clone().requires_grad_()
+    mr = R.scatter_mean(fr, seg, S)
+    dm = torch.randn(S, 128, generator=g)
+    mr.backward(dm)
+    csr = ops.segment_csr(_dev(seg, device), S)
+    order = csr.order.cpu()
+    assert torch.equal(order, torch.sort(seg, stable=True)[1])          # stable counting sort
+    assert torch.equal(csr.seg_off.cpu()[1:] - csr.seg_off.cpu()[:-1], torch.bincount(seg, minlength=S))
+    fd = _dev(f, device).requires_grad_()
+    m = ops.segment_mean(fd, csr)
+    m.backward(_dev(dm, device))
+    assert rel_err(m.detach(), mr.detach()) < 1e-5 and rel_err(fd.grad, fr.grad) < 1e-6
+
+
+def _fps_ref(xyz, m):
+    """numpy restatement of sampling_gpu.cu:73-176 incl. the tie-break (block size 512)."""
+    n = xyz.shape[0]
+    bs = 1
+    while bs * 2 <= n and bs < 512:
+        bs *= 2
+    tmp = np.full(n, 1e10, np.float32)
+    idx = np.zeros(m, np.int32)
+    mag = (xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1] + xyz[:, 2] * xyz[:, 2]).astype(np.float32)
+    ok = ~(mag <= np.float32(1e-3))
+    ks = np.arange(n)
+    old = 0
+    for j in range(1, m):
+        d = ((xyz - xyz[old]) ** 2).astype(np.float32)
+        d = (d[:, 0] + d[:, 1] + d[:, 2]).astype(np.float32)
+        d2 = np.minimum(d, tmp)
+        tmp = np.where(ok, d2, tmp)
+        cand = np.where(ok, d2, -np.inf)
+        best = cand.max()
+        if not np.isfinite(best):
+            old = 0
+        else:
+            tied = ks[cand == best]
+            old = int(tied[np.lexsort((tied, tied % bs))][0])
+        idx[j] = old
+    return idx
+
+
+@pytest.mark.parametrize("n,m", [(700, 20), (20000, 100), (300, 50)])
+def test_fps_bit_exact_with_ties(device, n, m):
+    from unscene3d_amd import ops
+
+    rng = np.random.default_rng(n)
+    xyz = rng.integers(-40, 40, size=(2, n, 3)).astype(np.float32)   # integer voxel coords -> many exact ties
+    xyz[0, 5] = 0.0                                                   # |p|^2 <= 1e-3 is skipped
+    got = ops.furthest_point_sample(_dev(xyz, device), m).cpu().numpy()
+    for b in range(2):
+        assert np.array_equal(got[b], _fps_ref(xyz[b], m))
+
+
+def test_fourier_posenc(device):
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(9000, 3, generator=g) * 5 - 1
+    B = torch.randn(3, 64, generator=g)
+    lo, hi = xyz.min(0)[0], xyz.max(0)[0]
+    xn = ((xyz - lo) * 1.0) / (hi - lo) + 0.0
+    proj = (xn * (2 * np.pi)) @ B
+    exp = torch.cat([proj.sin(), proj.cos()], 1)
+    got = ops.fourier_posenc(_dev(xyz, device), _dev(lo, device), _dev(hi, device), _dev(B, device), 128)
+    assert float((got.cpu() - exp).abs().max()) < 2e-5
+
+
+def _backbone_case(device, cls_name, layers, seed, n_points, grad):
+    """config 1 / config 2 at oracle-friendly size: voxelise a synthetic scene, run the device
+    backbone and the CPU restatement from the SAME state_dict."""
+    from types import SimpleNamespace
+
+    import oracle.res16unet_ref as M
+    from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd.models import res16unet
+    from unscene3d_amd.synthetic import make_scene
+
+    sc = make_scene(seed, target_voxels=n_points, tol=0.05)
+    xyz, colors = sc["xyz"], sc["colors"]
+    # device voxelisation (V1) vs oracle
+    coords_dev = ME.utils.sparse_quantize(xyz, quantization_size=0.02, return_index=True, return_inverse=True,
+                                          device=str(device))
+    c3, umap, inv = coords_dev
+    ec = R.voxel_floor(xyz, 0.02)
+    eu, einv = R.sparse_quantize(ec)
+    assert np.array_equal(umap.cpu().numpy(), eu) and np.array_equal(inv.cpu().numpy(), einv)
+    feats = torch.from_numpy(colors[eu])
+    coords4, _ = R.sparse_collate([ec[eu]], [colors[eu]])
+
+    torch.manual_seed(seed)
+    cfg = SimpleNamespace(bn_momentum=0.02, conv1_kernel_size=3, dilations=[1, 1, 1, 1])
+    model = getattr(res16unet, cls_name)(3, 20, cfg, out_fpn=True).to(device)
+    model.train()
+    x = ME.SparseTensor(features=feats.to(device), coordinates=torch.from_numpy(coords4).to(device), device=device)
+    out, fmaps = model(x)
+
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    pyr = M.Pyramid(coords4)
+    # per-level coordinates and rulebooks are bit-exact
+    cm = x.coordinate_manager
+    for lvl in range(5):
+        ts = 1 << lvl
+        assert np.array_equal(cm.coord_map(ts).coords.cpu().numpy(), pyr.coords[lvl])
+        assert np.array_equal(cm.cube_map(ts)["nbr"].cpu().numpy(), pyr.cube_map(lvl))
+        if lvl < 4:
+            assert np.array_equal(cm.stride_map(ts)["nbr2"].cpu().numpy(), pyr.nbr2[lvl])
+    ref_out, ref_levels = M.res16unet_forward(sd, pyr, feats, layers)
+    assert rel_err(out.F.detach(), ref_out.detach()) < REL_TOL
+    for a, b in zip(fmaps, ref_levels):
+        assert a.F.shape == b.shape and rel_err(a.F.detach(), b.detach()) < REL_TOL
+    if grad:
+        g = torch.Generator().manual_seed(1)
+        dy = torch.randn(ref_out.shape, generator=g)
+        (out.F * dy.to(device)).sum().backward()
+        (ref_out * dy).sum().backward()
+        worst = 0.0
+        for name, p in model.named_parameters():
+            if name.startswith("final."):
+                assert p.grad is None          # built but unused in forward (reference res16unet.py:219 vs :294)
+                continue
+            worst = max(worst, rel_err(p.grad, sd[name].grad))
+        assert worst < REL_TOL, worst
+
+
+def test_config1_res16unet14_forward(device):
+    _backbone_case(device, "Res16UNet14", (1,) * 8, seed=1000, n_points=8000, grad=False)
+
+
+def test_config2_res16unet34c_forward_backward_small(device):
+    _backbone_case(device, "Res16UNet34C", (2, 3, 4, 6, 2, 2, 2, 2), seed=2000, n_points=6000, grad=True)

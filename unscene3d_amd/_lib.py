@@ -1,0 +1,94 @@
+"""ctypes binding of libusc3d_hip.so — the flat C ABI declared in include/usc3d.h.
+
+The library is the ONLY compute backend of this package: there is no CPU or
+PyTorch fallback.  Loading fails loudly (ImportError) when the shared object has
+not been built (`python -c "import __graft_entry__ as g; g.build()"` or
+`make -C unscene3d_amd/csrc`), and every op raises RuntimeError when no HIP
+device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libusc3d_hip.so")
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f64 = C.c_double
+_f32 = C.c_float
+
+# name -> (restype, [argtypes])   — mirrors include/usc3d.h one to one
+SIGNATURES = {
+    "usc_last_error": (C.c_char_p, []),
+    "usc_abi_version": (C.c_int, []),
+    "usc_device_count": (C.c_int, []),
+    "usc_voxel_floor_f64": (C.c_int, [_p, _i64, _f64, _p, _p]),
+    "usc_coordmap_capacity": (_i64, [_i64]),
+    "usc_coordmap_ws_bytes": (_i64, [_i64]),
+    "usc_coordmap_build": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
+    "usc_kernel_map_cube": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p]),
+    "usc_kernel_map_down2": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p]),
+    "usc_rulebook_ws_bytes": (_i64, [_i64, _i64]),
+    "usc_rulebook_compact": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
+    "usc_weight_transpose": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
+    "usc_spconv_gather_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p, _p, _i32, _p]),
+    "usc_spconv_pairs_gemm": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p]),
+    "usc_spconv_wgrad_ws_bytes": (_i64, [_i32, _i32, _i32]),
+    "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i64, _p]),
+    "usc_colstats_ws_bytes": (_i64, [_i64, _i32]),
+    "usc_colstats": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "usc_bn_apply": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i64, _i32, _p]),
+    "usc_bn_backward_dx": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "usc_bn_backward_stats": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "usc_relu_fwd": (C.c_int, [_p, _p, _i64, _p]),
+    "usc_relu_bwd": (C.c_int, [_p, _p, _p, _i64, _p]),
+    "usc_avgpool_down2": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
+    "usc_gather_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
+    "usc_segment_csr_ws_bytes": (_i64, [_i64, _i64]),
+    "usc_segment_csr": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _p]),
+    "usc_segment_mean_fwd": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _p]),
+    "usc_segment_mean_bwd": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _p]),
+    "usc_segment_mean_nonzero": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _p, _p]),
+    "usc_furthest_point_sampling": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
+    "usc_fourier_posenc": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p, _p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(`python -c 'import __graft_entry__ as g; g.build()'`). "
+            "unscene3d_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.usc_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    """Turn a usc_status into a Python RuntimeError (reference: TORCH_CHECK ->
+    RuntimeError, utils/cuda_utils/cuda_utils.cpp:4-6)."""
+    if rc != 0:
+        raise RuntimeError(f"{what or 'libusc3d_hip'} failed (status {rc}): {last_error()}")
+
+
+def require_device() -> None:
+    n = lib.usc_device_count()
+    if n <= 0:
+        raise RuntimeError(
+            "unscene3d_amd: no HIP device visible — the MI355X kernels cannot run and there is no CPU fallback"
+        )

@@ -1,0 +1,603 @@
+// rows.hip — HBM-bound row kernels around the sparse convs (SURVEY.md §8a rows
+// B, P, Q3, D1): per-channel statistics for MinkowskiBatchNorm, fused
+// BN-apply(+residual)(+ReLU), BN backward, ReLU, 2x2x2 average pooling over a
+// child table, row gather and segment mean (torch_scatter.scatter_mean) with a
+// stable counting-sort CSR so that every floating-point sum has a fixed order.
+// All kernels move 16 B per lane where the channel count allows it.
+#include "common.h"
+#include "scan.h"
+
+namespace usc {
+
+// ---------------------------------------------------------------------------
+// column statistics: two sums per channel over N rows, f64 accumulation,
+// block partials -> ordered final reduction (no float atomics).
+enum StatMode { STAT_XY = 0, STAT_BN_BWD = 1 };
+
+struct StatArgs {
+  const float* x;       // [n,c]
+  const float* y;       // STAT_XY: second factor or NULL (x*x); STAT_BN_BWD: dy
+  const float* y_out;   // STAT_BN_BWD: forward output for the ReLU mask, or NULL
+  const float* mean;    // STAT_BN_BWD
+  const float* invstd;  // STAT_BN_BWD
+  int64_t n;
+  int c;
+};
+
+constexpr int kStatMaxBlocks = 1024;
+
+template <int VEC, int MODE>
+__global__ __launch_bounds__(256) void colstats_kernel(StatArgs a, double* __restrict__ partial) {
+  extern __shared__ double sh[];  // [RP][c][2]
+  const int c = a.c;
+  const int CT = c / VEC;        // threads per row
+  const int RP = 256 / CT;       // rows per pass
+  const int rl = threadIdx.x / CT, cg = threadIdx.x - rl * CT;
+  const bool active = rl < RP;
+  double s1[VEC], s2[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s1[v] = s2[v] = 0.0;
+  float mu[VEC], is[VEC];
+  if (MODE == STAT_BN_BWD && active) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      mu[v] = a.mean[cg * VEC + v];
+      is[v] = a.invstd[cg * VEC + v];
+    }
+  }
+  if (active) {
+    for (int64_t r = (int64_t)blockIdx.x * RP + rl; r < a.n; r += (int64_t)gridDim.x * RP) {
+      const int64_t off = r * c + cg * VEC;
+      float xv[VEC], yv[VEC], ov[VEC];
+      if (VEC == 4) {
+        float4 t = *reinterpret_cast<const float4*>(a.x + off);
+        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+        if (a.y) {
+          float4 u = *reinterpret_cast<const float4*>(a.y + off);
+          yv[0] = u.x; yv[1] = u.y; yv[2] = u.z; yv[3] = u.w;
+        }
+        if (MODE == STAT_BN_BWD && a.y_out) {
+          float4 u = *reinterpret_cast<const float4*>(a.y_out + off);
+          ov[0] = u.x; ov[1] = u.y; ov[2] = u.z; ov[3] = u.w;
+        }
+      } else {
+        xv[0] = a.x[off];
+        if (a.y) yv[0] = a.y[off];
+        if (MODE == STAT_BN_BWD && a.y_out) ov[0] = a.y_out[off];
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        if (MODE == STAT_XY) {
+          s1[v] += (double)xv[v];
+          s2[v] += (double)xv[v] * (double)(a.y ? yv[v] : xv[v]);
+        } else {
+          float g = yv[v];
+          if (a.y_out && !(ov[v] > 0.f)) g = 0.f;
+          const float xhat = (xv[v] - mu[v]) * is[v];
+          s1[v] += (double)g;
+          s2[v] += (double)g * (double)xhat;
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      sh[((int64_t)rl * c + cg * VEC + v) * 2 + 0] = s1[v];
+      sh[((int64_t)rl * c + cg * VEC + v) * 2 + 1] = s2[v];
+    }
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    double t1 = 0.0, t2 = 0.0;
+    for (int r = 0; r < RP; ++r) {
+      t1 += sh[((int64_t)r * c + ch) * 2 + 0];
+      t2 += sh[((int64_t)r * c + ch) * 2 + 1];
+    }
+    partial[((int64_t)blockIdx.x * 2 + 0) * c + ch] = t1;
+    partial[((int64_t)blockIdx.x * 2 + 1) * c + ch] = t2;
+  }
+}
+
+__global__ void colstats_final_kernel(const double* __restrict__ partial, int nblocks, int c, double* __restrict__ sum1,
+                                      double* __restrict__ sum2) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double t1 = 0.0, t2 = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    t1 += partial[((int64_t)b * 2 + 0) * c + ch];
+    t2 += partial[((int64_t)b * 2 + 1) * c + ch];
+  }
+  sum1[ch] = t1;
+  sum2[ch] = t2;
+}
+
+static int colstats_blocks(int64_t n, int c, int vec) {
+  const int CT = c / vec, RP = 256 / CT;
+  int64_t b = ceil_div(n, (int64_t)RP * 16);
+  if (b > kStatMaxBlocks) b = kStatMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+template <int MODE>
+static int launch_colstats(const StatArgs& a, double* sum1, double* sum2, void* ws, int64_t ws_bytes, hipStream_t st,
+                           const char* name) {
+  const int c = a.c;
+  USC_REQUIRE(c >= 1 && c <= 1024, "%s: unsupported channel count %d", name, c);
+  const int vec = (c % 4 == 0 && c / 4 <= 256) ? 4 : 1;
+  USC_REQUIRE(c / vec <= 256, "%s: unsupported channel count %d", name, c);
+  const int nb = colstats_blocks(a.n, c, vec);
+  USC_REQUIRE(ws_bytes >= (int64_t)nb * 2 * c * 8, "%s: workspace too small", name);
+  const int RP = 256 / (c / vec);
+  const size_t lds = (size_t)RP * c * 2 * sizeof(double);
+  double* partial = (double*)ws;
+  if (vec == 4)
+    hipLaunchKernelGGL((colstats_kernel<4, MODE>), dim3(nb), dim3(256), lds, st, a, partial);
+  else
+    hipLaunchKernelGGL((colstats_kernel<1, MODE>), dim3(nb), dim3(256), lds, st, a, partial);
+  hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)ceil_div(c, 128)), dim3(128), 0, st, partial, nb, c, sum1,
+                     sum2);
+  return USC_OK;
+}
+
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift,
+                                                      const float* __restrict__ res, int relu, float* __restrict__ y,
+                                                      int64_t nvec, int c) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nvec; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = j * VEC;
+    const int ch = (int)(e % c);
+    if (VEC == 4) {
+      float4 v = *reinterpret_cast<const float4*>(x + e);
+      const float4 sc = *reinterpret_cast<const float4*>(scale + ch);
+      const float4 sf = *reinterpret_cast<const float4*>(shift + ch);
+      v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+      if (res) {
+        const float4 r = *reinterpret_cast<const float4*>(res + e);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(y + e) = v;
+    } else {
+      float v = x[e] * scale[ch] + shift[ch];
+      if (res) v += res[e];
+      if (relu) v = fmaxf(v, 0.f);
+      y[e] = v;
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ y_out,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean_g,
+                                                       const float* __restrict__ mean_gx, float* __restrict__ dx,
+                                                       float* __restrict__ dres, int64_t nvec, int c) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nvec; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = j * VEC;
+    const int ch0 = (int)(e % c);
+    float xv[VEC], gv[VEC], ov[VEC], ox[VEC];
+    if (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4*>(x + e);
+      xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
+      t = *reinterpret_cast<const float4*>(dy + e);
+      gv[0] = t.x; gv[1] = t.y; gv[2] = t.z; gv[3] = t.w;
+      if (y_out) {
+        t = *reinterpret_cast<const float4*>(y_out + e);
+        ov[0] = t.x; ov[1] = t.y; ov[2] = t.z; ov[3] = t.w;
+      }
+    } else {
+      xv[0] = x[e];
+      gv[0] = dy[e];
+      if (y_out) ov[0] = y_out[e];
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int ch = ch0 + v;
+      float g = gv[v];
+      if (y_out && !(ov[v] > 0.f)) g = 0.f;
+      gv[v] = g;
+      const float xhat = (xv[v] - mean[ch]) * invstd[ch];
+      ox[v] = gamma[ch] * invstd[ch] * (g - mean_g[ch] - xhat * mean_gx[ch]);
+    }
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(dx + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
+      if (dres) *reinterpret_cast<float4*>(dres + e) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+    } else {
+      dx[e] = ox[0];
+      if (dres) dres[e] = gv[0];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(x)[j];
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    reinterpret_cast<float4*>(y)[j] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    y[e] = fmaxf(x[e], 0.f);
+  }
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                      float* __restrict__ dx, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += (int64_t)gridDim.x * blockDim.x) {
+    const float4 o = reinterpret_cast<const float4*>(y)[j];
+    float4 g = reinterpret_cast<const float4*>(dy)[j];
+    g.x = o.x > 0.f ? g.x : 0.f; g.y = o.y > 0.f ? g.y : 0.f; g.z = o.z > 0.f ? g.z : 0.f; g.w = o.w > 0.f ? g.w : 0.f;
+    reinterpret_cast<float4*>(dx)[j] = g;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t e = (n4 << 2) + threadIdx.x;
+    dx[e] = y[e] > 0.f ? dy[e] : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void avgpool_down2_kernel(const float* __restrict__ in, int c,
+                                                           const int32_t* __restrict__ nbr2, int64_t n_coarse,
+                                                           float* __restrict__ out) {
+  const int CT = c / VEC;
+  const int64_t total = n_coarse * CT;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = j / CT;
+    const int cg = (int)(j - p * CT);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ch = nbr2[(int64_t)k * n_coarse + p];
+      if (ch >= 0) {
+        ++cnt;
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(in + (int64_t)ch * c + cg * 4);
+          acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
+        } else {
+          acc[0] += in[(int64_t)ch * c + cg];
+        }
+      }
+    }
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(out + p * c + cg * 4) =
+          make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    } else {
+      out[p * c + cg] = acc[0] * inv;
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int c,
+                                                         const int64_t* __restrict__ idx, int64_t n,
+                                                         float* __restrict__ out) {
+  const int CT = c / VEC;
+  const int64_t total = n * CT;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = j / CT;
+    const int cg = (int)(j - r * CT);
+    const int64_t sr = idx[r];
+    if (VEC == 4)
+      *reinterpret_cast<float4*>(out + r * c + cg * 4) = *reinterpret_cast<const float4*>(src + sr * c + cg * 4);
+    else
+      out[r * c + cg] = src[sr * c + cg];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Stable counting sort of rows by segment id -> CSR (order, seg_off).
+constexpr int kSegTile = 2048;
+
+__global__ __launch_bounds__(256) void seg_hist_kernel(const int64_t* __restrict__ seg, int64_t n, int64_t S,
+                                                      int32_t* __restrict__ hist /*[T][S]*/) {
+  const int64_t t = blockIdx.x;
+  const int64_t b = t * kSegTile;
+  for (int j = threadIdx.x; j < kSegTile; j += 256) {
+    const int64_t i = b + j;
+    if (i < n) atomicAdd(&hist[t * S + seg[i]], 1);
+  }
+}
+// per segment: exclusive scan over tiles (in place), total -> counts[s]
+__global__ __launch_bounds__(256) void seg_tilescan_kernel(int32_t* __restrict__ hist, int64_t T, int64_t S,
+                                                          int32_t* __restrict__ counts) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  int run = 0;
+  for (int64_t t = 0; t < T; ++t) {
+    const int v = hist[t * S + s];
+    hist[t * S + s] = run;
+    run += v;
+  }
+  counts[s] = run;
+}
+struct CountVal {
+  const int32_t* counts;
+  __device__ int operator()(int64_t i) const { return counts[i]; }
+};
+struct SegOffEmit {
+  int64_t* seg_off;
+  __device__ void operator()(int64_t i, int64_t pos, int) const { seg_off[i] = pos; }
+};
+// one wave per tile walks its rows in order; equal ids inside a 64-row chunk are
+// ranked by lane order, so the placement is stable.
+__global__ __launch_bounds__(64) void seg_place_kernel(const int64_t* __restrict__ seg, int64_t n, int64_t S,
+                                                      int32_t* __restrict__ base /*[T][S] tile offsets*/,
+                                                      const int64_t* __restrict__ seg_off,
+                                                      int64_t* __restrict__ order) {
+  const int64_t t = blockIdx.x;
+  const int lane = threadIdx.x;
+  int32_t* mybase = base + t * S;
+  for (int ch = 0; ch < kSegTile / 64; ++ch) {
+    const int64_t i = t * kSegTile + ch * 64 + lane;
+    const bool act = i < n;
+    const int64_t sid = act ? seg[i] : -1;
+    unsigned long long todo = __ballot(act);
+    int64_t dst = -1;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int64_t lsid = __shfl(sid, leader, 64);
+      const unsigned long long m = __ballot(act && sid == lsid);
+      const int cnt = __popcll(m);
+      int old = 0;
+      if (lane == leader) {
+        old = mybase[lsid];
+        mybase[lsid] = old + cnt;
+      }
+      old = __shfl(old, leader, 64);
+      if (act && sid == lsid) {
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        dst = seg_off[lsid] + old + rank;
+      }
+      todo &= ~m;
+    }
+    if (act) order[dst] = i;
+  }
+}
+
+__global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* __restrict__ src, int c,
+                                                              const int64_t* __restrict__ order,
+                                                              const int64_t* __restrict__ seg_off, int64_t S,
+                                                              int only_nonzero, float* __restrict__ out,
+                                                              int64_t* __restrict__ nz_cnt) {
+  // one wave per segment; lanes stride the channels; rows summed in CSR order
+  const int lane = threadIdx.x & 63;
+  const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= S) return;
+  const int64_t b = seg_off[s], e = seg_off[s + 1];
+  for (int c0 = 0; c0 < c; c0 += 64) {
+    const int ch = c0 + lane;
+    float acc = 0.f;
+    int64_t cnt = 0;
+    for (int64_t q = b; q < e; ++q) {
+      const int64_t r = order[q];
+      bool use = true;
+      if (only_nonzero) {
+        // row counts when any channel is non-zero (reference: feats.sum(1) != 0 is
+        // approximated by the reference itself as "non-zero row"; see oracle)
+        float rs = 0.f;
+        for (int cc = lane; cc < c; cc += 64) rs += src[r * c + cc];
+        rs = wave_reduce_addf(rs);
+        use = rs != 0.f;
+      }
+      if (use) {
+        ++cnt;
+        if (ch < c) acc += src[r * c + ch];
+      }
+    }
+    if (ch < c) out[s * c + ch] = cnt > 0 ? acc / (float)cnt : 0.f;
+    if (c0 == 0 && lane == 0 && nz_cnt) nz_cnt[s] = cnt;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __restrict__ dout, int c,
+                                                              const int64_t* __restrict__ seg,
+                                                              const int64_t* __restrict__ seg_off, int64_t n,
+                                                              float* __restrict__ dsrc) {
+  const int CT = c / VEC;
+  const int64_t total = n * CT;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = j / CT;
+    const int cg = (int)(j - r * CT);
+    const int64_t s = seg[r];
+    const float inv = 1.f / (float)(seg_off[s + 1] - seg_off[s]);
+    if (VEC == 4) {
+      float4 v = *reinterpret_cast<const float4*>(dout + s * c + cg * 4);
+      v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+      *reinterpret_cast<float4*>(dsrc + r * c + cg * 4) = v;
+    } else {
+      dsrc[r * c + cg] = dout[s * c + cg] * inv;
+    }
+  }
+}
+
+}  // namespace usc
+
+using namespace usc;
+
+extern "C" {
+
+int64_t usc_colstats_ws_bytes(int64_t n, int32_t c) { (void)n; return (int64_t)kStatMaxBlocks * 2 * c * 8; }
+
+int usc_colstats(const float* x, const float* y, int64_t n, int32_t c, double* sum1, double* sum2, void* ws,
+                 int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(x && sum1 && sum2 && ws && n >= 0, "usc_colstats: bad argument");
+  StatArgs a{x, y, nullptr, nullptr, nullptr, n, (int)c};
+  int rc = launch_colstats<STAT_XY>(a, sum1, sum2, ws, ws_bytes, as_stream(s), "usc_colstats");
+  if (rc) return rc;
+  USC_CHECK_LAUNCH("usc_colstats");
+  return USC_OK;
+}
+
+int usc_bn_backward_stats(const float* x, const float* dy, const float* y_out, const float* mean, const float* invstd,
+                          int64_t n, int32_t c, double* sum_g, double* sum_gxhat, void* ws, int64_t ws_bytes,
+                          usc_stream_t s) {
+  USC_REQUIRE(x && dy && mean && invstd && sum_g && sum_gxhat && ws && n >= 0, "usc_bn_backward_stats: bad argument");
+  StatArgs a{x, dy, y_out, mean, invstd, n, (int)c};
+  int rc = launch_colstats<STAT_BN_BWD>(a, sum_g, sum_gxhat, ws, ws_bytes, as_stream(s), "usc_bn_backward_stats");
+  if (rc) return rc;
+  USC_CHECK_LAUNCH("usc_bn_backward_stats");
+  return USC_OK;
+}
+
+int usc_bn_apply(const float* x, const float* scale, const float* shift, const float* residual, int32_t relu, float* y,
+                 int64_t n, int32_t c, usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && c >= 1, "usc_bn_apply: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(x && scale && shift && y, "usc_bn_apply: null pointer");
+  const int64_t numel = n * c;
+  if (c % 4 == 0)
+    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(stream_grid(numel / 4, 256)), dim3(256), 0, as_stream(s), x, scale,
+                       shift, residual, (int)relu, y, numel / 4, (int)c);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(stream_grid(numel, 256)), dim3(256), 0, as_stream(s), x, scale,
+                       shift, residual, (int)relu, y, numel, (int)c);
+  USC_CHECK_LAUNCH("usc_bn_apply");
+  return USC_OK;
+}
+
+int usc_bn_backward_dx(const float* x, const float* dy, const float* y_out, const float* mean, const float* invstd,
+                       const float* gamma, const float* mean_g, const float* mean_gxhat, float* dx, float* dres,
+                       int64_t n, int32_t c, usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && c >= 1, "usc_bn_backward_dx: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(x && dy && mean && invstd && gamma && mean_g && mean_gxhat && dx, "usc_bn_backward_dx: null pointer");
+  const int64_t numel = n * c;
+  if (c % 4 == 0)
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<4>), dim3(stream_grid(numel / 4, 256)), dim3(256), 0, as_stream(s), x, dy,
+                       y_out, mean, invstd, gamma, mean_g, mean_gxhat, dx, dres, numel / 4, (int)c);
+  else
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(stream_grid(numel, 256)), dim3(256), 0, as_stream(s), x, dy, y_out,
+                       mean, invstd, gamma, mean_g, mean_gxhat, dx, dres, numel, (int)c);
+  USC_CHECK_LAUNCH("usc_bn_backward_dx");
+  return USC_OK;
+}
+
+int usc_relu_fwd(const float* x, float* y, int64_t numel, usc_stream_t s) {
+  USC_REQUIRE(numel >= 0, "usc_relu_fwd: bad size");
+  if (numel == 0) return USC_OK;
+  USC_REQUIRE(x && y, "usc_relu_fwd: null pointer");
+  hipLaunchKernelGGL(relu_fwd_kernel, dim3(stream_grid(numel / 4 + 1, 256)), dim3(256), 0, as_stream(s), x, y, numel);
+  USC_CHECK_LAUNCH("usc_relu_fwd");
+  return USC_OK;
+}
+int usc_relu_bwd(const float* y, const float* dy, float* dx, int64_t numel, usc_stream_t s) {
+  USC_REQUIRE(numel >= 0, "usc_relu_bwd: bad size");
+  if (numel == 0) return USC_OK;
+  USC_REQUIRE(y && dy && dx, "usc_relu_bwd: null pointer");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(stream_grid(numel / 4 + 1, 256)), dim3(256), 0, as_stream(s), y, dy, dx,
+                     numel);
+  USC_CHECK_LAUNCH("usc_relu_bwd");
+  return USC_OK;
+}
+
+int usc_avgpool_down2(const float* in, int32_t c, const int32_t* nbr2, int64_t n_coarse, float* out, usc_stream_t s) {
+  USC_REQUIRE(c >= 1 && n_coarse >= 0, "usc_avgpool_down2: bad sizes");
+  if (n_coarse == 0) return USC_OK;
+  USC_REQUIRE(in && nbr2 && out, "usc_avgpool_down2: null pointer");
+  if (c % 4 == 0)
+    hipLaunchKernelGGL((avgpool_down2_kernel<4>), dim3(stream_grid(n_coarse * (c / 4), 256)), dim3(256), 0,
+                       as_stream(s), in, (int)c, nbr2, n_coarse, out);
+  else
+    hipLaunchKernelGGL((avgpool_down2_kernel<1>), dim3(stream_grid(n_coarse * c, 256)), dim3(256), 0, as_stream(s), in,
+                       (int)c, nbr2, n_coarse, out);
+  USC_CHECK_LAUNCH("usc_avgpool_down2");
+  return USC_OK;
+}
+
+int usc_gather_rows(const float* src, int32_t c, const int64_t* idx, int64_t n, float* out, usc_stream_t s) {
+  USC_REQUIRE(c >= 1 && n >= 0, "usc_gather_rows: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(src && idx && out, "usc_gather_rows: null pointer");
+  if (c % 4 == 0)
+    hipLaunchKernelGGL((gather_rows_kernel<4>), dim3(stream_grid(n * (c / 4), 256)), dim3(256), 0, as_stream(s), src,
+                       (int)c, idx, n, out);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(stream_grid(n * c, 256)), dim3(256), 0, as_stream(s), src, (int)c,
+                       idx, n, out);
+  USC_CHECK_LAUNCH("usc_gather_rows");
+  return USC_OK;
+}
+
+static int64_t seg_tiles(int64_t n) { return n > 0 ? ceil_div(n, kSegTile) : 1; }
+int64_t usc_segment_csr_ws_bytes(int64_t n, int64_t S) {
+  // hist i32[T][S] | counts i32[S] | scan ws
+  return align_up(seg_tiles(n) * S * 4, 16) + align_up(S * 4, 16) + scan_ws_bytes(S + 1);
+}
+
+int usc_segment_csr(const int64_t* seg, int64_t n, int64_t S, int64_t* order, int64_t* seg_off, void* ws,
+                    int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && S >= 1, "usc_segment_csr: bad sizes");
+  USC_REQUIRE(seg_off && ws && (n == 0 || (seg && order)), "usc_segment_csr: null pointer");
+  USC_REQUIRE(ws_bytes >= usc_segment_csr_ws_bytes(n, S), "usc_segment_csr: workspace too small");
+  hipStream_t st = as_stream(s);
+  const int64_t T = seg_tiles(n);
+  char* w = (char*)ws;
+  int32_t* hist = (int32_t*)w;
+  int32_t* counts = (int32_t*)(w + align_up(T * S * 4, 16));
+  void* scan_ws = w + align_up(T * S * 4, 16) + align_up(S * 4, 16);
+  (void)hipMemsetAsync(hist, 0, (size_t)(T * S * 4), st);
+  if (n > 0) hipLaunchKernelGGL(seg_hist_kernel, dim3((unsigned)T), dim3(256), 0, st, seg, n, S, hist);
+  hipLaunchKernelGGL(seg_tilescan_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, st, hist, T, S, counts);
+  // seg_off[0..S] = exclusive scan of counts (entry S = total): scan S+1 values with counts[S] := 0
+  struct CountValPad {
+    const int32_t* counts; int64_t S;
+    __device__ int operator()(int64_t i) const { return i < S ? counts[i] : 0; }
+  };
+  CountValPad f{counts, S};
+  SegOffEmit e{seg_off};
+  device_exclusive_scan(f, e, S + 1, scan_ws, st);
+  if (n > 0) hipLaunchKernelGGL(seg_place_kernel, dim3((unsigned)T), dim3(64), 0, st, seg, n, S, hist, seg_off, order);
+  USC_CHECK_LAUNCH("usc_segment_csr");
+  return USC_OK;
+}
+
+int usc_segment_mean_fwd(const float* src, int32_t c, const int64_t* order, const int64_t* seg_off, int64_t S,
+                         float* out, usc_stream_t s) {
+  USC_REQUIRE(c >= 1 && S >= 0, "usc_segment_mean_fwd: bad sizes");
+  if (S == 0) return USC_OK;
+  USC_REQUIRE(src && order && seg_off && out, "usc_segment_mean_fwd: null pointer");
+  hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, as_stream(s), src, (int)c,
+                     order, seg_off, S, 0, out, (int64_t*)nullptr);
+  USC_CHECK_LAUNCH("usc_segment_mean_fwd");
+  return USC_OK;
+}
+
+int usc_segment_mean_nonzero(const float* feats, int32_t d, const int64_t* order, const int64_t* seg_off, int64_t S,
+                             float* out, int64_t* nonzero_cnt, usc_stream_t s) {
+  USC_REQUIRE(d >= 1 && S >= 0, "usc_segment_mean_nonzero: bad sizes");
+  if (S == 0) return USC_OK;
+  USC_REQUIRE(feats && order && seg_off && out, "usc_segment_mean_nonzero: null pointer");
+  hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, as_stream(s), feats, (int)d,
+                     order, seg_off, S, 1, out, nonzero_cnt);
+  USC_CHECK_LAUNCH("usc_segment_mean_nonzero");
+  return USC_OK;
+}
+
+int usc_segment_mean_bwd(const float* dout, int32_t c, const int64_t* seg, const int64_t* seg_off, int64_t n,
+                         float* dsrc, usc_stream_t s) {
+  USC_REQUIRE(c >= 1 && n >= 0, "usc_segment_mean_bwd: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(dout && seg && seg_off && dsrc, "usc_segment_mean_bwd: null pointer");
+  if (c % 4 == 0)
+    hipLaunchKernelGGL((segment_mean_bwd_kernel<4>), dim3(stream_grid(n * (c / 4), 256)), dim3(256), 0, as_stream(s),
+                       dout, (int)c, seg, seg_off, n, dsrc);
+  else
+    hipLaunchKernelGGL((segment_mean_bwd_kernel<1>), dim3(stream_grid(n * c, 256)), dim3(256), 0, as_stream(s), dout,
+                       (int)c, seg, seg_off, n, dsrc);
+  USC_CHECK_LAUNCH("usc_segment_mean_bwd");
+  return USC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,403 @@
+// spconv.hip — sparse convolution as rulebook-driven implicit GEMM on the
+// gfx950 matrix cores.
+//
+// Three kernels cover every conv in Res16UNet34C + Mask3D, forward and backward:
+//   gather_gemm  (output-stationary over a dense neighbour table nbr[K][N_out]):
+//                k3/s1 conv fwd + dgrad, k2/s2 conv fwd, k2/s2 conv-transpose dgrad,
+//                1x1 conv / linear (nbr == NULL)
+//   pairs_gemm   (one-parent form driven by per-offset pair lists):
+//                k2/s2 conv-transpose fwd, k2/s2 conv dgrad
+//   wgrad        dW[k] = sum_pairs a^T b, split over pair chunks, ordered reduction
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32 (bitwise an fmaf chain), so the
+// result is within fp32 round-off of the reference's cuBLAS/CPU GEMMs.
+// Each 64-lane wave owns a 32-row x (NB*32)-column output tile with NB 32x32
+// accumulators in registers; A rows are gathered straight from HBM/L2 with 16-B
+// loads (the reduction index is permuted so that a lane's float4 feeds four
+// consecutive MFMA steps), B (the weight slice W[k]) is read as 128-B coalesced
+// row segments that stay L1/L2 resident across the waves of a CU.  Offsets with
+// no neighbour in the wave's 32 rows are skipped with a wave-uniform ballot.
+#include "common.h"
+
+namespace usc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+struct GemmParams {
+  const float* in;      // [n_in, cin]
+  const float* W;       // [K, cin, cout]
+  const int32_t* nbr;   // [K, n_out] or NULL (identity)
+  const float* bias;    // [cout] or NULL
+  float* out;           // [n_out, cout]
+  int64_t n_out;
+  int cin, cout, K;
+  int accumulate;
+  // pairs form
+  const int32_t* rows_in;
+  const int32_t* rows_out;
+  const int64_t* koff;
+};
+
+// MFMA C/D layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ inline int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+template <int NB, bool LIST>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * (NB * 32);
+  const int cin = p.cin, cout = p.cout;
+  const bool vec_ok = (cin & 7) == 0;
+
+  int64_t tile_row0 = 0;  // table form: first output row of this wave
+  int k_begin = 0, k_end = p.K;
+  int64_t pair0 = 0, pair_end = 0;  // list form
+  if (LIST) {
+    // locate (k, tile-in-k) of this wave from the per-offset pair counts
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    int k = 0;
+    bool found = false;
+    for (; k < p.K; ++k) {
+      const int64_t b = p.koff[k], e = p.koff[k + 1];
+      const int64_t nt = (e - b + 31) >> 5;
+      if (t < nt) {
+        pair0 = b + t * 32;
+        pair_end = e;
+        found = true;
+        break;
+      }
+      t -= nt;
+    }
+    if (!found) return;  // wave-uniform
+    k_begin = k;
+    k_end = k + 1;
+  } else {
+    tile_row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if (tile_row0 >= p.n_out) return;
+  }
+
+  int64_t my_out_row = -1;  // output row handled by lane (i) of this wave
+  int64_t my_in_row_list = -1;
+  if (LIST) {
+    const int64_t pp = pair0 + i;
+    if (pp < pair_end) {
+      my_out_row = p.rows_out[pp];
+      my_in_row_list = p.rows_in[pp];
+    }
+  } else {
+    const int64_t r = tile_row0 + i;
+    my_out_row = (r < p.n_out) ? r : -1;
+  }
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  for (int k = k_begin; k < k_end; ++k) {
+    int64_t in_row;
+    if (LIST) {
+      in_row = my_in_row_list;
+    } else if (p.nbr) {
+      in_row = (my_out_row >= 0) ? (int64_t)p.nbr[(int64_t)k * p.n_out + my_out_row] : -1;
+    } else {
+      in_row = my_out_row;
+    }
+    const bool valid = in_row >= 0;
+    if (!__any(valid)) continue;  // no neighbour at this offset in the wave's 32 rows
+    const float* arow = p.in + (valid ? in_row : 0) * (int64_t)cin;
+    const float* wk = p.W + (int64_t)k * cin * cout;
+
+    for (int c0 = 0; c0 < cin; c0 += 32) {
+      float a[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int c = c0 + 8 * t + 4 * h;
+        if (vec_ok) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (valid && c < cin) v = *reinterpret_cast<const float4*>(arow + c);
+          a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[t][j] = (valid && c + j < cin) ? arow[c + j] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (c0 + 8 * t >= cin) break;  // wave-uniform tail (cin < 32)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = c0 + 8 * t + 4 * h + j;
+          const float* wrow = wk + (int64_t)c * cout + n0 + i;
+          float b[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) b[nb] = (c < cin && n0 + nb * 32 + i < cout) ? wrow[nb * 32] : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA32(a[t][j], b[nb], acc[nb]);
+        }
+      }
+    }
+  }
+
+  // epilogue: lanes 0-31 hold 32 consecutive columns of row acc_row(r,0), lanes 32-63 of acc_row(r,1)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ro = acc_row(r, h);
+    const int64_t orow = __shfl(my_out_row, ro, 64);
+    if (orow < 0) continue;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + nb * 32 + i;
+      if (n < cout) {
+        float v = acc[nb][r];
+        if (p.bias) v += p.bias[n];
+        float* dst = p.out + orow * (int64_t)cout + n;
+        if (p.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// wgrad: dW[k][ci][co] = sum_p a[a_idx[p]][ci] * b[b_idx[p]][co]
+struct WgradParams {
+  const float* a;
+  const float* b;
+  const int32_t* a_idx;
+  const int32_t* b_idx;
+  const int64_t* koff;
+  int64_t n_rows;  // identity form
+  float* partial;  // [S, K, cin, cout]
+  int cin, cout, K, S;
+};
+
+template <int NB>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+  extern __shared__ float red[];  // [3 waves][NB*16 regs][64 lanes]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int k = blockIdx.x / p.S, s = blockIdx.x % p.S;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * (NB * 32);
+  const int cin = p.cin, cout = p.cout;
+
+  int64_t pb, pe;
+  if (p.a_idx) {
+    pb = p.koff[k];
+    pe = p.koff[k + 1];
+  } else {
+    pb = 0;
+    pe = p.n_rows;
+  }
+  // contiguous, even-length chunk of pairs for (split s, wave)
+  const int64_t nchunks = (int64_t)p.S * 4;
+  int64_t L = (pe - pb + nchunks - 1) / nchunks;
+  L = (L + 1) & ~1ll;
+  const int64_t cb = pb + ((int64_t)s * 4 + wave) * L;
+  int64_t ce = cb + L;
+  if (ce > pe) ce = pe;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  const bool ci_ok = ci0 + i < cin;
+  for (int64_t q = cb; q < ce; q += 16) {
+    // 16 pairs per iteration: lanes 0-15 fetch a-rows, 16-31 b-rows
+    int64_t idxreg = -1;
+    {
+      const int l16 = lane & 15;
+      const int64_t pp = q + l16;
+      if (lane < 32 && pp < ce) {
+        if (p.a_idx)
+          idxreg = (lane < 16) ? p.a_idx[pp] : p.b_idx[pp];
+        else
+          idxreg = pp;
+      }
+    }
+    float av[8];
+    float bv[8][NB];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t ia = __shfl(idxreg, 2 * u + h, 64);
+      const int64_t ib = __shfl(idxreg, 16 + 2 * u + h, 64);
+      av[u] = (ia >= 0 && ci_ok) ? p.a[ia * cin + ci0 + i] : 0.f;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        bv[u][nb] = (ib >= 0 && co0 + nb * 32 + i < cout) ? p.b[ib * cout + co0 + nb * 32 + i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA32(av[u], bv[u][nb], acc[nb]);
+  }
+
+  // ordered cross-wave reduction in LDS: wave 0 adds waves 1,2,3 in order
+  if (wave > 0) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave - 1) * NB * 16 + nb * 16 + r) * 64 + lane] = acc[nb][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] += red[(w * NB * 16 + nb * 16 + r) * 64 + lane];
+    float* dst = p.partial + ((int64_t)s * p.K + k) * cin * cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + acc_row(r, h);
+      if (ci >= cin) continue;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int co = co0 + nb * 32 + i;
+        if (co < cout) dst[(int64_t)ci * cout + co] = acc[nb][r];
+      }
+    }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t numel, float* __restrict__ dW) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < numel; j += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += partial[(int64_t)s * numel + j];
+    dW[j] = v;
+  }
+}
+
+// out[k][co][ci] = W[mirror ? K-1-k : k][ci][co]
+__global__ void weight_transpose_kernel(const float* __restrict__ W, int K, int cin, int cout, int mirror,
+                                        float* __restrict__ out) {
+  const int64_t per = (int64_t)cin * cout;
+  const int64_t total = per * K;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(j / per);
+    const int64_t rem = j - (int64_t)k * per;
+    const int co = (int)(rem / cin), ci = (int)(rem - (int64_t)co * cin);
+    const int ks = mirror ? (K - 1 - k) : k;
+    out[j] = W[(int64_t)ks * per + (int64_t)ci * cout + co];
+  }
+}
+
+static int wgrad_splits(int K, int cin, int cout, int NB, int64_t n_rows) {
+  const int64_t tiles = (int64_t)K * ceil_div(cin, 32) * ceil_div(cout, NB * 32);
+  int64_t S = ceil_div(2048, tiles);
+  const int64_t by_rows = n_rows / 2048 + 1;
+  if (S > by_rows) S = by_rows;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+static int pick_nb(int cout) {
+  if (cout <= 32) return 1;
+  if (cout <= 64) return 2;
+  if (cout % 128 == 0) return 4;
+  if (cout % 96 == 0) return 3;
+  return 4;
+}
+
+}  // namespace usc
+
+using namespace usc;
+
+extern "C" {
+
+int usc_weight_transpose(const float* W, int32_t K, int32_t cin, int32_t cout, int32_t mirror, float* out,
+                         usc_stream_t s) {
+  USC_REQUIRE(W && out && K >= 1 && cin >= 1 && cout >= 1, "usc_weight_transpose: bad argument");
+  const int64_t total = (int64_t)K * cin * cout;
+  hipLaunchKernelGGL(weight_transpose_kernel, dim3(stream_grid(total, 256)), dim3(256), 0, as_stream(s), W, (int)K,
+                     (int)cin, (int)cout, (int)mirror, out);
+  USC_CHECK_LAUNCH("usc_weight_transpose");
+  return USC_OK;
+}
+
+int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
+                           const int32_t* nbr, int64_t n_out, const float* bias, float* out, int32_t accumulate,
+                           usc_stream_t s) {
+  USC_REQUIRE(cin >= 1 && cout >= 1 && K >= 1 && n_out >= 0 && n_in >= 0, "usc_spconv_gather_gemm: bad sizes");
+  USC_REQUIRE(nbr || K == 1, "usc_spconv_gather_gemm: K>1 needs a neighbour table");
+  USC_REQUIRE(nbr || n_in == n_out, "usc_spconv_gather_gemm: identity map needs n_in == n_out");
+  if (n_out == 0) return USC_OK;
+  USC_REQUIRE(in && W && out, "usc_spconv_gather_gemm: null pointer");
+  GemmParams p{};
+  p.in = in; p.W = W; p.nbr = nbr; p.bias = bias; p.out = out;
+  p.n_out = n_out; p.cin = cin; p.cout = cout; p.K = K; p.accumulate = accumulate;
+  const int NB = pick_nb(cout);
+  dim3 grid((unsigned)ceil_div(n_out, 128), (unsigned)ceil_div(cout, NB * 32));
+  hipStream_t st = as_stream(s);
+  switch (NB) {
+    case 1: hipLaunchKernelGGL((gather_gemm_kernel<1, false>), grid, dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((gather_gemm_kernel<2, false>), grid, dim3(256), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((gather_gemm_kernel<3, false>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((gather_gemm_kernel<4, false>), grid, dim3(256), 0, st, p); break;
+  }
+  USC_CHECK_LAUNCH("usc_spconv_gather_gemm");
+  return USC_OK;
+}
+
+int usc_spconv_pairs_gemm(const float* in, int32_t cin, const float* W, int32_t K, int32_t cout,
+                          const int32_t* rows_in, const int32_t* rows_out, const int64_t* koff, int64_t P_capacity,
+                          float* out, usc_stream_t s) {
+  USC_REQUIRE(cin >= 1 && cout >= 1 && K >= 1 && P_capacity >= 0, "usc_spconv_pairs_gemm: bad sizes");
+  if (P_capacity == 0) return USC_OK;
+  USC_REQUIRE(in && W && rows_in && rows_out && koff && out, "usc_spconv_pairs_gemm: null pointer");
+  GemmParams p{};
+  p.in = in; p.W = W; p.out = out; p.cin = cin; p.cout = cout; p.K = K;
+  p.rows_in = rows_in; p.rows_out = rows_out; p.koff = koff;
+  const int NB = pick_nb(cout);
+  const int64_t max_tiles = ceil_div(P_capacity, 32) + K;  // each offset pads to a multiple of 32 pairs
+  dim3 grid((unsigned)ceil_div(max_tiles, 4), (unsigned)ceil_div(cout, NB * 32));
+  hipStream_t st = as_stream(s);
+  switch (NB) {
+    case 1: hipLaunchKernelGGL((gather_gemm_kernel<1, true>), grid, dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((gather_gemm_kernel<2, true>), grid, dim3(256), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((gather_gemm_kernel<3, true>), grid, dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((gather_gemm_kernel<4, true>), grid, dim3(256), 0, st, p); break;
+  }
+  USC_CHECK_LAUNCH("usc_spconv_pairs_gemm");
+  return USC_OK;
+}
+
+int64_t usc_spconv_wgrad_ws_bytes(int32_t K, int32_t cin, int32_t cout) {
+  return (int64_t)64 * K * cin * cout * (int64_t)sizeof(float);
+}
+
+int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, int32_t K, const int32_t* a_idx,
+                     const int32_t* b_idx, const int64_t* koff, int64_t n_rows, float* dW, void* ws, int64_t ws_bytes,
+                     usc_stream_t s) {
+  USC_REQUIRE(cin >= 1 && cout >= 1 && K >= 1 && n_rows >= 0, "usc_spconv_wgrad: bad sizes");
+  USC_REQUIRE(a && b && dW && ws, "usc_spconv_wgrad: null pointer");
+  USC_REQUIRE((a_idx && b_idx && koff) || (!a_idx && K == 1), "usc_spconv_wgrad: pair lists required for K>1");
+  const int NB = pick_nb(cout);
+  const int S = wgrad_splits(K, cin, cout, NB, n_rows);
+  const int64_t numel = (int64_t)K * cin * cout;
+  USC_REQUIRE(ws_bytes >= (int64_t)S * numel * 4, "usc_spconv_wgrad: workspace too small");
+  WgradParams p{};
+  p.a = a; p.b = b; p.a_idx = a_idx; p.b_idx = b_idx; p.koff = koff; p.n_rows = n_rows;
+  p.partial = (float*)ws; p.cin = cin; p.cout = cout; p.K = K; p.S = S;
+  dim3 grid((unsigned)(K * S), (unsigned)ceil_div(cin, 32), (unsigned)ceil_div(cout, NB * 32));
+  const size_t lds = (size_t)3 * NB * 16 * 64 * sizeof(float);
+  hipStream_t st = as_stream(s);
+  switch (NB) {
+    case 1: hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), lds, st, p); break;
+    case 2: hipLaunchKernelGGL((wgrad_kernel<2>), grid, dim3(256), lds, st, p); break;
+    case 3: hipLaunchKernelGGL((wgrad_kernel<3>), grid, dim3(256), lds, st, p); break;
+    default: hipLaunchKernelGGL((wgrad_kernel<4>), grid, dim3(256), lds, st, p); break;
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, S, numel,
+                     dW);
+  USC_CHECK_LAUNCH("usc_spconv_wgrad");
+  return USC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,531 @@
+"""Tensor-level wrappers over the C ABI (include/usc3d.h) + autograd Functions.
+
+PyTorch is used only as plumbing here: device memory (torch.empty), the current
+HIP stream, and autograd bookkeeping.  All arithmetic happens inside
+libusc3d_hip.so.  Inputs must be contiguous tensors on a HIP device; anything
+else raises RuntimeError (reference: CHECK_CONTIGUOUS / CHECK_CUDA,
+utils/cuda_utils/cuda_utils.cpp:4-6, third_party/pointnet2/_ext_src/src/sampling.cpp:68).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from . import profiler as _prof
+from ._lib import check, lib, require_device
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a HIP (cuda) tensor — unscene3d_amd has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes: int, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------ coordinates
+def voxel_floor(xyz: torch.Tensor, voxel_size: float) -> torch.Tensor:
+    """floor(xyz / voxel_size) in f64 -> i32[n,3] (reference datasets/utils.py:403)."""
+    require_device()
+    _chk(xyz, torch.float64, "xyz")
+    out = torch.empty(xyz.shape, dtype=torch.int32, device=xyz.device)
+    check(lib.usc_voxel_floor_f64(_ptr(xyz), xyz.shape[0], float(voxel_size), _ptr(out), _stream()),
+          "usc_voxel_floor_f64")
+    return out
+
+
+@dataclass
+class CoordMap:
+    """One coordinate map: coordinates in row order + its HBM-resident hash table."""
+    coords: torch.Tensor        # i32[n,4]  (b,x,y,z)
+    table_keys: torch.Tensor    # i64[cap] (u64 bit pattern)
+    table_vals: torch.Tensor    # i32[cap]
+    tensor_stride: int
+
+    @property
+    def n(self) -> int:
+        return self.coords.shape[0]
+
+    @property
+    def cap(self) -> int:
+        return self.table_keys.shape[0]
+
+
+def coordmap_build(coords: torch.Tensor, quant: int = 1, tensor_stride: int = 1):
+    """-> (CoordMap of distinct coords, unique_idx i64[n_out], inverse i64[n]).
+
+    First-occurrence unique == ME.utils.sparse_quantize(return_index, return_inverse)
+    (reference datasets/utils.py:403-408)."""
+    require_device()
+    _chk(coords, torch.int32, "coords")
+    if coords.dim() != 2 or coords.shape[1] != 4:
+        raise RuntimeError("coords must be int32 [n,4] (b,x,y,z)")
+    n = coords.shape[0]
+    dev = coords.device
+    cap = lib.usc_coordmap_capacity(n)
+    keys = torch.empty(cap, dtype=torch.int64, device=dev)
+    vals = torch.empty(cap, dtype=torch.int32, device=dev)
+    unique_idx = torch.empty(n, dtype=torch.int64, device=dev)
+    inverse = torch.empty(n, dtype=torch.int64, device=dev)
+    out_coords = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int64, device=dev)
+    wsb = lib.usc_coordmap_ws_bytes(n)
+    ws = _ws(wsb, dev)
+    check(lib.usc_coordmap_build(_ptr(coords), n, int(quant), _ptr(keys), _ptr(vals), cap, _ptr(unique_idx),
+                                 _ptr(inverse), _ptr(out_coords), _ptr(n_out), _ptr(ws), ws.numel(), _stream()),
+          "usc_coordmap_build")
+    m = int(n_out.item())
+    if m < 0:
+        raise RuntimeError("usc_coordmap_build: coordinate outside the packable range (|c| < 2^17, batch < 1024)")
+    cmap = CoordMap(out_coords[:m].contiguous() if m != n else out_coords, keys, vals, tensor_stride)
+    return cmap, unique_idx[:m], inverse
+
+
+def kernel_map_cube(cmap: CoordMap, ksize: int = 3) -> torch.Tensor:
+    """Dense neighbour table i32[K, n] of a stride-1 HYPER_CUBE kernel on `cmap`."""
+    K = ksize ** 3
+    nbr = torch.empty((K, cmap.n), dtype=torch.int32, device=cmap.coords.device)
+    check(lib.usc_kernel_map_cube(_ptr(cmap.coords), cmap.n, cmap.tensor_stride, ksize, _ptr(cmap.table_keys),
+                                  _ptr(cmap.table_vals), cmap.cap, _ptr(nbr), _stream()), "usc_kernel_map_cube")
+    return nbr
+
+
+def kernel_map_down2(fine: CoordMap, parent: torch.Tensor, coarse: CoordMap):
+    """Child table i32[8, n_coarse] and kidx u8[n_fine] of a k=2,s=2 kernel."""
+    dev = fine.coords.device
+    nbr2 = torch.full((8, coarse.n), -1, dtype=torch.int32, device=dev)
+    kidx = torch.empty(fine.n, dtype=torch.uint8, device=dev)
+    check(lib.usc_kernel_map_down2(_ptr(fine.coords), fine.n, fine.tensor_stride, _ptr(parent), _ptr(coarse.coords),
+                                   coarse.n, _ptr(nbr2), _ptr(kidx), _stream()), "usc_kernel_map_down2")
+    return nbr2, kidx
+
+
+@dataclass
+class Rulebook:
+    in_idx: torch.Tensor   # i32[P]
+    out_idx: torch.Tensor  # i32[P]
+    koff: torch.Tensor     # i64[K+1] (device)
+    P: int                 # host copy of koff[K]
+
+
+def rulebook_compact(nbr: torch.Tensor) -> Rulebook:
+    _chk(nbr, torch.int32, "nbr")
+    K, n_out = nbr.shape
+    dev = nbr.device
+    in_idx = torch.empty(K * n_out, dtype=torch.int32, device=dev)
+    out_idx = torch.empty(K * n_out, dtype=torch.int32, device=dev)
+    koff = torch.empty(K + 1, dtype=torch.int64, device=dev)
+    ws = _ws(lib.usc_rulebook_ws_bytes(K, n_out), dev)
+    check(lib.usc_rulebook_compact(_ptr(nbr), K, n_out, _ptr(in_idx), _ptr(out_idx), _ptr(koff), _ptr(ws),
+                                   ws.numel(), _stream()), "usc_rulebook_compact")
+    P = int(koff[K].item())
+    return Rulebook(in_idx[:P], out_idx[:P], koff, P)
+
+
+# ------------------------------------------------------------------ convolution
+def _conv_cost(P, n_in, n_out, K, cin, cout):
+    """Algorithmic work of one sparse-conv launch: flops = 2*P*cin*cout,
+    bytes = 4*(n_in*cin + n_out*cout + K*cin*cout) + 8*P."""
+    return 2.0 * P * cin * cout, 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + 8.0 * P
+
+
+def weight_transpose(W: torch.Tensor, mirror: bool) -> torch.Tensor:
+    _chk(W, torch.float32, "W")
+    K, cin, cout = W.shape
+    out = torch.empty((K, cout, cin), dtype=torch.float32, device=W.device)
+    check(lib.usc_weight_transpose(_ptr(W), K, cin, cout, int(mirror), _ptr(out), _stream()), "usc_weight_transpose")
+    return out
+
+
+def gather_gemm(feats, W, nbr, n_out, bias=None, out=None, accumulate=False):
+    """out[o] = sum_k feats[nbr[k,o]] @ W[k] (+bias).  W f32[K,cin,cout]; nbr None -> identity."""
+    _chk(feats, torch.float32, "feats")
+    _chk(W, torch.float32, "W")
+    K, cin, cout = W.shape
+    if feats.shape[1] != cin:
+        raise RuntimeError(f"gather_gemm: feats have {feats.shape[1]} channels, kernel expects {cin}")
+    if nbr is not None:
+        _chk(nbr, torch.int32, "nbr")
+        if nbr.shape[0] != K or nbr.shape[1] != n_out:
+            raise RuntimeError("gather_gemm: neighbour table shape mismatch")
+    if out is None:
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if bias is not None:
+        _chk(bias, torch.float32, "bias")
+    with _prof.maybe(lambda: f"usc::gather_gemm_kernel<{_prof.pick_nb(cout)}, false>",
+                     lambda: _conv_cost(_prof.table_pairs(nbr) if nbr is not None else n_out, feats.shape[0], n_out,
+                                        K, cin, cout)):
+        check(lib.usc_spconv_gather_gemm(_ptr(feats), feats.shape[0], cin, _ptr(W), K, cout, _ptr(nbr), n_out,
+                                         _ptr(bias), _ptr(out), int(accumulate), _stream()), "usc_spconv_gather_gemm")
+    return out
+
+
+def pairs_gemm(feats, W, rows_in, rows_out, koff, P, n_out):
+    """out[rows_out[p]] = feats[rows_in[p]] @ W[k(p)] — every out row written exactly once."""
+    _chk(feats, torch.float32, "feats")
+    _chk(W, torch.float32, "W")
+    K, cin, cout = W.shape
+    if feats.shape[1] != cin:
+        raise RuntimeError("pairs_gemm: channel mismatch")
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    with _prof.maybe(lambda: f"usc::gather_gemm_kernel<{_prof.pick_nb(cout)}, true>",
+                     lambda: _conv_cost(int(P), feats.shape[0], n_out, K, cin, cout)):
+        check(lib.usc_spconv_pairs_gemm(_ptr(feats), cin, _ptr(W), K, cout, _ptr(rows_in), _ptr(rows_out),
+                                        _ptr(koff), int(P), _ptr(out), _stream()), "usc_spconv_pairs_gemm")
+    return out
+
+
+def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None):
+    """dW[k] = sum_{p in list k} a[a_idx[p]]^T b[b_idx[p]] -> f32[K,cin,cout]."""
+    _chk(a, torch.float32, "a")
+    _chk(b, torch.float32, "b")
+    cin, cout = a.shape[1], b.shape[1]
+    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=a.device)
+    ws = _ws(lib.usc_spconv_wgrad_ws_bytes(K, cin, cout), a.device)
+    n_rows = a.shape[0] if a_idx is None else int(a_idx.shape[0])
+    with _prof.maybe(lambda: f"usc::wgrad_kernel<{_prof.pick_nb(cout)}>",
+                     lambda: _conv_cost(n_rows, a.shape[0], b.shape[0], K, cin, cout)):
+        check(lib.usc_spconv_wgrad(_ptr(a), cin, _ptr(b), cout, K, _ptr(a_idx), _ptr(b_idx), _ptr(koff), n_rows,
+                                   _ptr(dW), _ptr(ws), ws.numel(), _stream()), "usc_spconv_wgrad")
+    return dW
+
+
+class _ConvSame(torch.autograd.Function):
+    """k^3 stride-1 conv on one map (in map == out map) or 1x1 conv (nbr None)."""
+
+    @staticmethod
+    def forward(ctx, feats, W, bias, nbr, get_rulebook):
+        feats = feats.contiguous()
+        W3 = W if W.dim() == 3 else W[None]
+        out = gather_gemm(feats, W3.contiguous(), nbr, feats.shape[0], bias=None if bias is None else bias.reshape(-1))
+        ctx.save_for_backward(feats, W3)
+        ctx.nbr, ctx.get_rulebook = nbr, get_rulebook
+        ctx.w_dim, ctx.has_bias = W.dim(), bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, W3 = ctx.saved_tensors
+        dout = dout.contiguous()
+        K = W3.shape[0]
+        dfeats = dW = dbias = None
+        if ctx.needs_input_grad[0]:
+            Wt = weight_transpose(W3.contiguous(), mirror=K > 1)
+            dfeats = gather_gemm(dout, Wt, ctx.nbr, feats.shape[0])
+        if ctx.needs_input_grad[1]:
+            if ctx.nbr is None:
+                dW = wgrad(feats, dout, 1)
+            else:
+                rb = ctx.get_rulebook()
+                dW = wgrad(feats, dout, K, rb.in_idx, rb.out_idx, rb.koff)
+            if ctx.w_dim == 2:
+                dW = dW[0]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = colsum(dout).reshape(1, -1)
+        return dfeats, dW, dbias, None, None
+
+
+class _ConvDown2(torch.autograd.Function):
+    """k=2, s=2 conv: fine map -> coarse map via the child table nbr2[8, n_coarse]."""
+
+    @staticmethod
+    def forward(ctx, feats, W, nbr2, get_rulebook):
+        feats = feats.contiguous()
+        out = gather_gemm(feats, W.contiguous(), nbr2, nbr2.shape[1])
+        ctx.save_for_backward(feats, W)
+        ctx.nbr2, ctx.get_rulebook = nbr2, get_rulebook
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, W = ctx.saved_tensors
+        dout = dout.contiguous()
+        rb = ctx.get_rulebook()  # in_idx = fine row, out_idx = coarse row
+        dfeats = dW = None
+        if ctx.needs_input_grad[0]:
+            Wt = weight_transpose(W.contiguous(), mirror=False)
+            dfeats = pairs_gemm(dout, Wt, rb.out_idx, rb.in_idx, rb.koff, rb.P, feats.shape[0])
+        if ctx.needs_input_grad[1]:
+            dW = wgrad(feats, dout, W.shape[0], rb.in_idx, rb.out_idx, rb.koff)
+        return dfeats, dW, None, None
+
+
+class _ConvTrUp2(torch.autograd.Function):
+    """k=2, s=2 transposed conv: coarse map -> cached fine map (same child table)."""
+
+    @staticmethod
+    def forward(ctx, feats, W, nbr2, get_rulebook, n_fine):
+        feats = feats.contiguous()
+        rb = get_rulebook()
+        out = pairs_gemm(feats, W.contiguous(), rb.out_idx, rb.in_idx, rb.koff, rb.P, n_fine)
+        ctx.save_for_backward(feats, W)
+        ctx.nbr2, ctx.rb = nbr2, rb
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feats, W = ctx.saved_tensors
+        dout = dout.contiguous()
+        rb = ctx.rb
+        dfeats = dW = None
+        if ctx.needs_input_grad[0]:
+            Wt = weight_transpose(W.contiguous(), mirror=False)
+            dfeats = gather_gemm(dout, Wt, ctx.nbr2, feats.shape[0])
+        if ctx.needs_input_grad[1]:
+            dW = wgrad(feats, dout, W.shape[0], rb.out_idx, rb.in_idx, rb.koff)
+        return dfeats, dW, None, None, None
+
+
+def conv_same(feats, W, bias, nbr, get_rulebook):
+    return _ConvSame.apply(feats, W, bias, nbr, get_rulebook)
+
+
+def conv_down2(feats, W, nbr2, get_rulebook):
+    return _ConvDown2.apply(feats, W, nbr2, get_rulebook)
+
+
+def conv_tr_up2(feats, W, nbr2, get_rulebook, n_fine):
+    return _ConvTrUp2.apply(feats, W, nbr2, get_rulebook, n_fine)
+
+
+# ------------------------------------------------------------------ batch norm / relu
+def colstats(x, y=None):
+    """-> (sum_i x[i,c], sum_i x[i,c]*y[i,c]) as f64[c] (y None -> x*x)."""
+    _chk(x, torch.float32, "x")
+    n, c = x.shape
+    s1 = torch.empty(c, dtype=torch.float64, device=x.device)
+    s2 = torch.empty(c, dtype=torch.float64, device=x.device)
+    ws = _ws(lib.usc_colstats_ws_bytes(n, c), x.device)
+    check(lib.usc_colstats(_ptr(x), _ptr(y), n, c, _ptr(s1), _ptr(s2), _ptr(ws), ws.numel(), _stream()),
+          "usc_colstats")
+    return s1, s2
+
+
+def colsum(x):
+    return colstats(x)[0].to(torch.float32)
+
+
+def bn_apply(x, scale, shift, residual=None, relu=False):
+    _chk(x, torch.float32, "x")
+    n, c = x.shape
+    y = torch.empty_like(x)
+    check(lib.usc_bn_apply(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), int(relu), _ptr(y), n, c, _stream()),
+          "usc_bn_apply")
+    return y
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """y = [relu](BN_train(x) [+ residual]) — MinkowskiBatchNorm (+MinkowskiReLU) (+`out += residual`)
+    fused into one stats pass and one apply pass (reference models/modules/resnet_block.py:48-64)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, relu, eps, running_mean, running_var, momentum, training):
+        x = x.contiguous()
+        n, c = x.shape
+        if training:
+            s1, s2 = colstats(x)
+            mean64 = s1 / n
+            var64 = (s2 / n - mean64 * mean64).clamp_(min=0.0)
+            mean = mean64.to(torch.float32)
+            invstd = torch.rsqrt(var64 + eps).to(torch.float32)
+            if running_mean is not None:
+                with torch.no_grad():
+                    unbiased = var64 * (n / max(n - 1, 1))
+                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(unbiased.to(torch.float32), alpha=momentum)
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+        scale = gamma * invstd
+        shift = beta - mean * scale
+        res = None if residual is None else residual.contiguous()
+        y = bn_apply(x, scale.contiguous(), shift.contiguous(), res, relu)
+        ctx.save_for_backward(x, gamma, mean, invstd, y if relu else None)
+        ctx.relu, ctx.has_res, ctx.training = relu, residual is not None, training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, c = x.shape
+        dev = x.device
+        sg = torch.empty(c, dtype=torch.float64, device=dev)
+        sgx = torch.empty(c, dtype=torch.float64, device=dev)
+        ws = _ws(lib.usc_colstats_ws_bytes(n, c), dev)
+        check(lib.usc_bn_backward_stats(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), n, c, _ptr(sg),
+                                        _ptr(sgx), _ptr(ws), ws.numel(), _stream()), "usc_bn_backward_stats")
+        dgamma = sgx.to(torch.float32)
+        dbeta = sg.to(torch.float32)
+        if ctx.training:
+            mean_g = (sg / n).to(torch.float32)
+            mean_gx = (sgx / n).to(torch.float32)
+        else:  # eval mode: statistics are constants
+            mean_g = torch.zeros(c, dtype=torch.float32, device=dev)
+            mean_gx = torch.zeros(c, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        check(lib.usc_bn_backward_dx(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(mean_g),
+                                     _ptr(mean_gx), _ptr(dx), _ptr(dres), n, c, _stream()), "usc_bn_backward_dx")
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, residual=None, relu=False, eps=1e-5, running_mean=None, running_var=None,
+                   momentum=0.1, training=True):
+    return _BatchNormAct.apply(x, gamma, beta, residual, relu, eps, running_mean, running_var, momentum, training)
+
+
+class _ReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(lib.usc_relu_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), "usc_relu_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        check(lib.usc_relu_bwd(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), _stream()), "usc_relu_bwd")
+        return dx
+
+
+def relu(x):
+    _chk(x, torch.float32, "x")
+    return _ReLU.apply(x)
+
+
+# ------------------------------------------------------------------ pooling / gather / segments
+def avgpool_down2(feats, nbr2):
+    """MinkowskiAvgPooling(kernel_size=2, stride=2) forward: mean over present children."""
+    _chk(feats, torch.float32, "feats")
+    nc = nbr2.shape[1]
+    out = torch.empty((nc, feats.shape[1]), dtype=torch.float32, device=feats.device)
+    check(lib.usc_avgpool_down2(_ptr(feats), feats.shape[1], _ptr(nbr2), nc, _ptr(out), _stream()),
+          "usc_avgpool_down2")
+    return out
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, idx):
+        src = src.contiguous()
+        idx = idx.contiguous()
+        out = torch.empty((idx.shape[0], src.shape[1]), dtype=torch.float32, device=src.device)
+        check(lib.usc_gather_rows(_ptr(src), src.shape[1], _ptr(idx), idx.shape[0], _ptr(out), _stream()),
+              "usc_gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.n_src = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        # scatter-add of rows: deterministic segment sum over the CSR of idx
+        csr = segment_csr(idx, ctx.n_src)
+        return segment_sum_from_csr(dout.contiguous(), csr), None
+
+
+def gather_rows(src, idx):
+    _chk(src, torch.float32, "src")
+    _chk(idx, torch.int64, "idx")
+    return _GatherRows.apply(src, idx)
+
+
+@dataclass
+class SegmentCSR:
+    seg: torch.Tensor      # i64[n]
+    order: torch.Tensor    # i64[n] rows sorted by segment (stable)
+    seg_off: torch.Tensor  # i64[S+1]
+    S: int
+
+
+def segment_csr(seg: torch.Tensor, S: int) -> SegmentCSR:
+    _chk(seg, torch.int64, "seg")
+    n = seg.shape[0]
+    dev = seg.device
+    order = torch.empty(n, dtype=torch.int64, device=dev)
+    seg_off = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    ws = _ws(lib.usc_segment_csr_ws_bytes(n, S), dev)
+    check(lib.usc_segment_csr(_ptr(seg), n, S, _ptr(order), _ptr(seg_off), _ptr(ws), ws.numel(), _stream()),
+          "usc_segment_csr")
+    return SegmentCSR(seg, order, seg_off, S)
+
+
+def segment_sum_from_csr(src, csr: SegmentCSR):
+    mean = torch.empty((csr.S, src.shape[1]), dtype=torch.float32, device=src.device)
+    check(lib.usc_segment_mean_fwd(_ptr(src), src.shape[1], _ptr(csr.order), _ptr(csr.seg_off), csr.S, _ptr(mean),
+                                   _stream()), "usc_segment_mean_fwd")
+    cnt = (csr.seg_off[1:] - csr.seg_off[:-1]).to(torch.float32)
+    return mean * cnt[:, None]
+
+
+class _SegmentMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, csr):
+        src = src.contiguous()
+        out = torch.empty((csr.S, src.shape[1]), dtype=torch.float32, device=src.device)
+        check(lib.usc_segment_mean_fwd(_ptr(src), src.shape[1], _ptr(csr.order), _ptr(csr.seg_off), csr.S, _ptr(out),
+                                       _stream()), "usc_segment_mean_fwd")
+        ctx.csr, ctx.n = csr, src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        csr = ctx.csr
+        dsrc = torch.empty((ctx.n, dout.shape[1]), dtype=torch.float32, device=dout.device)
+        check(lib.usc_segment_mean_bwd(_ptr(dout), dout.shape[1], _ptr(csr.seg), _ptr(csr.seg_off), ctx.n,
+                                       _ptr(dsrc), _stream()), "usc_segment_mean_bwd")
+        return dsrc, None
+
+
+def segment_mean(src, csr: SegmentCSR):
+    """torch_scatter.scatter_mean(src, seg, dim=0) with a prebuilt CSR (reference models/mask3d.py:223)."""
+    _chk(src, torch.float32, "src")
+    return _SegmentMean.apply(src, csr)
+
+
+# ------------------------------------------------------------------ points
+def furthest_point_sample(xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+    """pointnet2_utils.furthest_point_sample(xyz f32[B,N,3], npoint) -> i32[B,npoint]
+    (reference third_party/pointnet2/pointnet2_utils.py:50-79)."""
+    require_device()
+    _chk(xyz, torch.float32, "xyz")
+    if xyz.dim() != 3 or xyz.shape[2] != 3:
+        raise RuntimeError("xyz must be f32 [B,N,3]")
+    B, N, _ = xyz.shape
+    tmp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+    idx = torch.zeros((B, npoint), dtype=torch.int32, device=xyz.device)
+    check(lib.usc_furthest_point_sampling(_ptr(xyz), B, N, npoint, _ptr(tmp), _ptr(idx), _stream()),
+          "usc_furthest_point_sampling")
+    return idx
+
+
+def fourier_posenc(xyz, lo, hi, gauss_B, d):
+    """PositionEmbeddingCoordsSine('fourier', normalize=True): f32[n,3] -> f32[n,d]."""
+    _chk(xyz, torch.float32, "xyz")
+    out = torch.empty((xyz.shape[0], d), dtype=torch.float32, device=xyz.device)
+    check(lib.usc_fourier_posenc(_ptr(xyz), xyz.shape[0], _ptr(lo.contiguous()), _ptr(hi.contiguous()),
+                                 _ptr(gauss_B.contiguous()), d, _ptr(out), _stream()), "usc_fourier_posenc")
+    return out
