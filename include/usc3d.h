@@ -134,13 +134,24 @@ int usc_weight_transpose(const float* W, int32_t K, int32_t cin, int32_t cout,
  *   out[o,:] = sum_k  in[nbr[k*n_out+o], :] @ W[k]  (+ bias)
  * in f32[n_in,cin], W f32[K,cin,cout].  nbr==NULL means K==1 identity
  * (1x1 conv / linear).  bias f32[cout] or NULL.  accumulate=1 adds into out.
+ * Small maps (coarse U-Net levels) split the K offsets over extra workgroups and
+ * reduce the partial sums in a fixed order through `ws`
+ * (usc_spconv_gather_gemm_ws_bytes; 0 bytes when no split is planned).
  * Covers: k3/s1 conv fwd and dgrad (W = usc_weight_transpose(mirror=1)),
  * k2/s2 conv fwd (nbr = child table), conv-transpose dgrad. */
+/* Launch plan chosen for a shape (for profiling labels): returns
+ * NB | aligned<<8 | G<<16 where NB = 32-column blocks per wave, aligned = fast
+ * path, G = offset groups.  kind 0: gather_gemm (n = n_out), 1: pairs_gemm
+ * (n = P_capacity), 2: wgrad. */
+int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout,
+                    int32_t K);
+int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin,
+                                        int32_t cout, int32_t K);
 int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin,
                            const float* W, int32_t K, int32_t cout,
                            const int32_t* nbr, int64_t n_out,
                            const float* bias, float* out, int32_t accumulate,
-                           usc_stream_t s);
+                           void* ws, int64_t ws_bytes, usc_stream_t s);
 
 /* One-parent form (transposed-conv forward, strided-conv dgrad):
  *   out[rows_out[p],:] = in[rows_in[p],:] @ W[k]   for p in [koff[k], koff[k+1])

@@ -30,10 +30,11 @@ struct GemmParams {
   const float* W;       // [K, cin, cout]
   const int32_t* nbr;   // [K, n_out] or NULL (identity)
   const float* bias;    // [cout] or NULL
-  float* out;           // [n_out, cout]
+  float* out;           // [n_out, cout]  (G == 1)  or partial [G, n_out, cout]
   int64_t n_out;
   int cin, cout, K;
   int accumulate;
+  int G;                // offset groups (blockIdx.z); >1 -> partial sums, reduced afterwards
   // pairs form
   const int32_t* rows_in;
   const int32_t* rows_out;
@@ -43,53 +44,79 @@ struct GemmParams {
 // MFMA C/D layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ inline int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+template <int NB> struct BVec;
+template <> struct BVec<1> { float v[1]; };
+template <> struct BVec<2> { float v[2]; };
+template <> struct BVec<3> { float v[3]; };
+template <> struct BVec<4> { float v[4]; };
+
+// Column mapping of the aligned kernels: MFMA column j of accumulator nb is the
+// actual output column n0 + NB*j + nb, so that a lane's NB B-operands (and its NB
+// results per row) are CONTIGUOUS in memory: one NB-dword load per reduction step,
+// one NB-dword store per output row.
+template <int NB>
+__device__ inline void load_b(const float* __restrict__ p, float (&b)[NB]) {
+  if (NB == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3 % NB] = t.w;
+  } else if (NB == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    b[0] = t.x; b[1 % NB] = t.y;
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) b[nb] = p[nb];
+  }
+}
+
+// Locate this wave's work item.  Table form: 32 consecutive output rows.  List
+// form: 32 consecutive pairs of one offset k (every offset padded to 32 pairs).
+template <bool LIST>
+__device__ inline bool locate_tile(const GemmParams& p, int wave, int i, int& k_begin, int& k_end,
+                                   int64_t& my_out_row, int64_t& my_in_row_list) {
+  my_out_row = -1;
+  my_in_row_list = -1;
+  if (LIST) {
+    int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    for (int k = 0; k < p.K; ++k) {
+      const int64_t b = p.koff[k], e = p.koff[k + 1];
+      const int64_t nt = (e - b + 31) >> 5;
+      if (t < nt) {
+        const int64_t pp = b + t * 32 + i;
+        if (pp < e) {
+          my_out_row = p.rows_out[pp];
+          my_in_row_list = p.rows_in[pp];
+        }
+        k_begin = k;
+        k_end = k + 1;
+        return true;
+      }
+      t -= nt;
+    }
+    return false;
+  } else {
+    const int64_t tile_row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+    if (tile_row0 >= p.n_out) return false;
+    const int64_t r = tile_row0 + i;
+    my_out_row = (r < p.n_out) ? r : -1;
+    // offset group of this block
+    const int Kg = (p.K + p.G - 1) / p.G;
+    k_begin = blockIdx.z * Kg;
+    k_end = k_begin + Kg < p.K ? k_begin + Kg : p.K;
+    return true;
+  }
+}
+
+// Fast path: cin % 32 == 0 and cout % (32*NB) == 0 — no bounds checks inside the loop,
+// every load unconditional (invalid rows read row 0 and are zeroed with a select).
 template <int NB, bool LIST>
-__global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256) void gather_gemm_aligned_kernel(GemmParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.y * (NB * 32);
   const int cin = p.cin, cout = p.cout;
-  const bool vec_ok = (cin & 7) == 0;
-
-  int64_t tile_row0 = 0;  // table form: first output row of this wave
-  int k_begin = 0, k_end = p.K;
-  int64_t pair0 = 0, pair_end = 0;  // list form
-  if (LIST) {
-    // locate (k, tile-in-k) of this wave from the per-offset pair counts
-    int64_t t = (int64_t)blockIdx.x * 4 + wave;
-    int k = 0;
-    bool found = false;
-    for (; k < p.K; ++k) {
-      const int64_t b = p.koff[k], e = p.koff[k + 1];
-      const int64_t nt = (e - b + 31) >> 5;
-      if (t < nt) {
-        pair0 = b + t * 32;
-        pair_end = e;
-        found = true;
-        break;
-      }
-      t -= nt;
-    }
-    if (!found) return;  // wave-uniform
-    k_begin = k;
-    k_end = k + 1;
-  } else {
-    tile_row0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-    if (tile_row0 >= p.n_out) return;
-  }
-
-  int64_t my_out_row = -1;  // output row handled by lane (i) of this wave
-  int64_t my_in_row_list = -1;
-  if (LIST) {
-    const int64_t pp = pair0 + i;
-    if (pp < pair_end) {
-      my_out_row = p.rows_out[pp];
-      my_in_row_list = p.rows_in[pp];
-    }
-  } else {
-    const int64_t r = tile_row0 + i;
-    my_out_row = (r < p.n_out) ? r : -1;
-  }
+  int k_begin, k_end;
+  int64_t my_out_row, my_in_row_list;
+  if (!locate_tile<LIST>(p, wave, i, k_begin, k_end, my_out_row, my_in_row_list)) return;
 
   f32x16 acc[NB];
 #pragma unroll
@@ -99,15 +126,112 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
 
   for (int k = k_begin; k < k_end; ++k) {
     int64_t in_row;
-    if (LIST) {
-      in_row = my_in_row_list;
-    } else if (p.nbr) {
-      in_row = (my_out_row >= 0) ? (int64_t)p.nbr[(int64_t)k * p.n_out + my_out_row] : -1;
-    } else {
-      in_row = my_out_row;
-    }
+    if (LIST) in_row = my_in_row_list;
+    else if (p.nbr) in_row = (my_out_row >= 0) ? (int64_t)p.nbr[(int64_t)k * p.n_out + my_out_row] : -1;
+    else in_row = my_out_row;
     const bool valid = in_row >= 0;
-    if (!__any(valid)) continue;  // no neighbour at this offset in the wave's 32 rows
+    if (!__any(valid)) continue;  // wave-uniform: no neighbour at this offset in these 32 rows
+    const float* arow = p.in + (valid ? in_row : 0) * (int64_t)cin + 4 * h;
+    const float* wk = p.W + (int64_t)k * cin * cout + (int64_t)(4 * h) * cout + n0 + NB * i;
+
+    for (int c0 = 0; c0 < cin; c0 += 32) {
+      float4 a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(arow + c0 + 8 * t);
+      float b[16][NB];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) load_b<NB>(wk + (int64_t)(c0 + 8 * t + j) * cout, b[4 * t + j]);
+      if (!valid) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float av[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA32(av[j], b[4 * t + j][nb], acc[nb]);
+      }
+    }
+  }
+
+  float* outp = p.out;
+  if (!LIST && p.G > 1) outp += (int64_t)blockIdx.z * p.n_out * cout;
+  const bool direct = LIST || p.G == 1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t orow = __shfl(my_out_row, acc_row(r, h), 64);
+    if (orow < 0) continue;
+    float v[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) v[nb] = acc[nb][r];
+    float* dst = outp + orow * (int64_t)cout + n0 + NB * i;
+    if (direct) {
+      if (p.bias) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) v[nb] += p.bias[n0 + NB * i + nb];
+      }
+      if (p.accumulate) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) v[nb] += dst[nb];
+      }
+    }
+    if (NB == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1 % NB], v[2 % NB], v[3 % NB]);
+    else if (NB == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1 % NB]);
+    else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) dst[nb] = v[nb];
+    }
+  }
+}
+
+// out = (accumulate ? out : 0) + bias + sum_g partial[g]   (fixed order)
+__global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restrict__ partial, int G, int64_t numel4,
+                                                          int cout, const float* __restrict__ bias, int accumulate,
+                                                          float* __restrict__ out) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < numel4; j += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (accumulate) v = reinterpret_cast<const float4*>(out)[j];
+    if (bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(bias + (j * 4) % cout);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    for (int g = 0; g < G; ++g) {
+      const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)g * numel4 + j];
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    reinterpret_cast<float4*>(out)[j] = v;
+  }
+}
+
+// Generic path (any cin / cout, e.g. the 3-channel stem and 20-class head): bounds-checked.
+template <int NB, bool LIST>
+__global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * (NB * 32);
+  const int cin = p.cin, cout = p.cout;
+  const bool vec_ok = (cin & 7) == 0;
+  int k_begin, k_end;
+  int64_t my_out_row, my_in_row_list;
+  if (!locate_tile<LIST>(p, wave, i, k_begin, k_end, my_out_row, my_in_row_list)) return;
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+
+  for (int k = k_begin; k < k_end; ++k) {
+    int64_t in_row;
+    if (LIST) in_row = my_in_row_list;
+    else if (p.nbr) in_row = (my_out_row >= 0) ? (int64_t)p.nbr[(int64_t)k * p.n_out + my_out_row] : -1;
+    else in_row = my_out_row;
+    const bool valid = in_row >= 0;
+    if (!__any(valid)) continue;
     const float* arow = p.in + (valid ? in_row : 0) * (int64_t)cin;
     const float* wk = p.W + (int64_t)k * cin * cout;
 
@@ -142,20 +266,23 @@ __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {
     }
   }
 
-  // epilogue: lanes 0-31 hold 32 consecutive columns of row acc_row(r,0), lanes 32-63 of acc_row(r,1)
+  float* outp = p.out;
+  if (!LIST && p.G > 1) outp += (int64_t)blockIdx.z * p.n_out * cout;
+  const bool direct = LIST || p.G == 1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int ro = acc_row(r, h);
-    const int64_t orow = __shfl(my_out_row, ro, 64);
+    const int64_t orow = __shfl(my_out_row, acc_row(r, h), 64);
     if (orow < 0) continue;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       const int n = n0 + nb * 32 + i;
       if (n < cout) {
         float v = acc[nb][r];
-        if (p.bias) v += p.bias[n];
-        float* dst = p.out + orow * (int64_t)cout + n;
-        if (p.accumulate) v += *dst;
+        float* dst = outp + orow * (int64_t)cout + n;
+        if (direct) {
+          if (p.bias) v += p.bias[n];
+          if (p.accumulate) v += *dst;
+        }
         *dst = v;
       }
     }
@@ -175,7 +302,9 @@ struct WgradParams {
   int cin, cout, K, S;
 };
 
-template <int NB>
+// ALIGNED: cin % 32 == 0 and cout % (32*NB) == 0 -> unconditional vector loads; the lane's NB
+// columns are contiguous (column of accumulator nb, MFMA column j = co0 + NB*j + nb).
+template <int NB, bool ALIGNED>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   extern __shared__ float red[];  // [3 waves][NB*16 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -207,8 +336,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 
   const bool ci_ok = ci0 + i < cin;
+  const int acol = ci0 + i;
+  const int bcol = ALIGNED ? co0 + NB * i : co0 + i;
   for (int64_t q = cb; q < ce; q += 16) {
-    // 16 pairs per iteration: lanes 0-15 fetch a-rows, 16-31 b-rows
+    // 16 pairs per iteration: lanes 0-15 fetch a-row ids, 16-31 b-row ids
     int64_t idxreg = -1;
     {
       const int l16 = lane & 15;
@@ -226,10 +357,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
     for (int u = 0; u < 8; ++u) {
       const int64_t ia = __shfl(idxreg, 2 * u + h, 64);
       const int64_t ib = __shfl(idxreg, 16 + 2 * u + h, 64);
-      av[u] = (ia >= 0 && ci_ok) ? p.a[ia * cin + ci0 + i] : 0.f;
+      if (ALIGNED) {
+        // out-of-range pairs read row 0; their A value is zeroed, which zeroes the product
+        const float t = p.a[(ia >= 0 ? ia : 0) * cin + acol];
+        av[u] = ia >= 0 ? t : 0.f;
+        load_b<NB>(p.b + (ib >= 0 ? ib : 0) * cout + bcol, bv[u]);
+      } else {
+        av[u] = (ia >= 0 && ci_ok) ? p.a[ia * cin + acol] : 0.f;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-        bv[u][nb] = (ib >= 0 && co0 + nb * 32 + i < cout) ? p.b[ib * cout + co0 + nb * 32 + i] : 0.f;
+        for (int nb = 0; nb < NB; ++nb)
+          bv[u][nb] = (ib >= 0 && bcol + nb * 32 < cout) ? p.b[ib * cout + bcol + nb * 32] : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
@@ -259,7 +397,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
       if (ci >= cin) continue;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
-        const int co = co0 + nb * 32 + i;
+        const int co = ALIGNED ? bcol + nb : bcol + nb * 32;
         if (co < cout) dst[(int64_t)ci * cout + co] = acc[nb][r];
       }
     }
@@ -305,6 +443,69 @@ static int pick_nb(int cout) {
   return 4;
 }
 
+// Launch plan of the table-form gather GEMM: column blocks per wave (NB) and offset
+// groups (G).  Large maps keep the widest tile (least re-gathering of A rows); small maps
+// (coarse U-Net levels: hundreds to a few thousand rows, 128-256 channels) shrink the tile
+// and split the K offsets over blockIdx.z so that >= ~3 waves per SIMD are in flight.
+struct GemmPlan { int NB; int G; bool aligned; };
+constexpr int64_t kTargetWaves = 3072;
+
+static GemmPlan plan_table(int64_t n_out, int cin, int cout, int K) {
+  GemmPlan pl{pick_nb(cout), 1, false};
+  const bool al = (cin % 32 == 0) && (cout % 32 == 0);
+  if (!al) return pl;
+  pl.aligned = true;
+  const int64_t row_tiles = ceil_div(n_out, 32);
+  const int cb = cout / 32;
+  const int cands[4] = {4, 3, 2, 1};
+  int chosen = 1;
+  for (int c = 0; c < 4; ++c) {
+    const int nb = cands[c];
+    if (cb % nb) continue;
+    if (row_tiles * (cb / nb) >= kTargetWaves) { chosen = nb; break; }
+  }
+  pl.NB = chosen;
+  const int64_t waves = row_tiles * (cb / chosen);
+  if (waves < kTargetWaves && K > 1) {
+    int64_t G = ceil_div(kTargetWaves, waves);
+    if (G > K) G = K;
+    pl.G = (int)G;
+  }
+  return pl;
+}
+static GemmPlan plan_list(int64_t max_tiles, int cin, int cout) {
+  GemmPlan pl{pick_nb(cout), 1, false};
+  const bool al = (cin % 32 == 0) && (cout % 32 == 0);
+  if (!al) return pl;
+  pl.aligned = true;
+  const int cb = cout / 32;
+  const int cands[4] = {4, 3, 2, 1};
+  int chosen = 1;
+  for (int c = 0; c < 4; ++c) {
+    const int nb = cands[c];
+    if (cb % nb) continue;
+    if (max_tiles * (cb / nb) >= kTargetWaves) { chosen = nb; break; }
+  }
+  pl.NB = chosen;
+  return pl;
+}
+
+template <bool LIST>
+static void launch_gemm(const GemmPlan& pl, dim3 grid, hipStream_t st, const GemmParams& p) {
+#define USC_GG(NBv)                                                                                      \
+  if (pl.aligned)                                                                                        \
+    hipLaunchKernelGGL((gather_gemm_aligned_kernel<NBv, LIST>), grid, dim3(256), 0, st, p);             \
+  else                                                                                                   \
+    hipLaunchKernelGGL((gather_gemm_kernel<NBv, LIST>), grid, dim3(256), 0, st, p);
+  switch (pl.NB) {
+    case 1: USC_GG(1) break;
+    case 2: USC_GG(2) break;
+    case 3: USC_GG(3) break;
+    default: USC_GG(4) break;
+  }
+#undef USC_GG
+}
+
 }  // namespace usc
 
 using namespace usc;
@@ -321,25 +522,43 @@ int usc_weight_transpose(const float* W, int32_t K, int32_t cin, int32_t cout, i
   return USC_OK;
 }
 
+int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout, int32_t K) {
+  // kind 0: gather_gemm on n output rows; 1: pairs_gemm with P_capacity n; 2: wgrad
+  GemmPlan pl;
+  if (kind == 0) pl = plan_table(n, cin, cout, K);
+  else if (kind == 1) pl = plan_list(ceil_div(n, 32) + K, cin, cout);
+  else { const int NB = pick_nb(cout); pl = GemmPlan{NB, 1, (cin % 32 == 0) && (cout % (NB * 32) == 0)}; }
+  return pl.NB | ((pl.aligned ? 1 : 0) << 8) | (pl.G << 16);
+}
+
+int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin, int32_t cout, int32_t K) {
+  const GemmPlan pl = plan_table(n_out, cin, cout, K);
+  return pl.G > 1 ? (int64_t)pl.G * n_out * cout * 4 : 0;
+}
+
 int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
                            const int32_t* nbr, int64_t n_out, const float* bias, float* out, int32_t accumulate,
-                           usc_stream_t s) {
+                           void* ws, int64_t ws_bytes, usc_stream_t s) {
   USC_REQUIRE(cin >= 1 && cout >= 1 && K >= 1 && n_out >= 0 && n_in >= 0, "usc_spconv_gather_gemm: bad sizes");
   USC_REQUIRE(nbr || K == 1, "usc_spconv_gather_gemm: K>1 needs a neighbour table");
   USC_REQUIRE(nbr || n_in == n_out, "usc_spconv_gather_gemm: identity map needs n_in == n_out");
   if (n_out == 0) return USC_OK;
   USC_REQUIRE(in && W && out, "usc_spconv_gather_gemm: null pointer");
+  const GemmPlan pl = plan_table(n_out, cin, cout, K);
   GemmParams p{};
   p.in = in; p.W = W; p.nbr = nbr; p.bias = bias; p.out = out;
-  p.n_out = n_out; p.cin = cin; p.cout = cout; p.K = K; p.accumulate = accumulate;
-  const int NB = pick_nb(cout);
-  dim3 grid((unsigned)ceil_div(n_out, 128), (unsigned)ceil_div(cout, NB * 32));
+  p.n_out = n_out; p.cin = cin; p.cout = cout; p.K = K; p.accumulate = accumulate; p.G = pl.G;
+  if (pl.G > 1) {
+    USC_REQUIRE(ws && ws_bytes >= (int64_t)pl.G * n_out * cout * 4, "usc_spconv_gather_gemm: workspace too small");
+    p.out = (float*)ws;
+  }
+  dim3 grid((unsigned)ceil_div(n_out, 128), (unsigned)ceil_div(cout, pl.NB * 32), (unsigned)pl.G);
   hipStream_t st = as_stream(s);
-  switch (NB) {
-    case 1: hipLaunchKernelGGL((gather_gemm_kernel<1, false>), grid, dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((gather_gemm_kernel<2, false>), grid, dim3(256), 0, st, p); break;
-    case 3: hipLaunchKernelGGL((gather_gemm_kernel<3, false>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((gather_gemm_kernel<4, false>), grid, dim3(256), 0, st, p); break;
+  launch_gemm<false>(pl, grid, st, p);
+  if (pl.G > 1) {
+    const int64_t numel4 = n_out * cout / 4;
+    hipLaunchKernelGGL(group_reduce_kernel, dim3(stream_grid(numel4, 256)), dim3(256), 0, st, (const float*)ws, pl.G,
+                       numel4, (int)cout, bias, (int)accumulate, out);
   }
   USC_CHECK_LAUNCH("usc_spconv_gather_gemm");
   return USC_OK;
@@ -352,18 +571,12 @@ int usc_spconv_pairs_gemm(const float* in, int32_t cin, const float* W, int32_t 
   if (P_capacity == 0) return USC_OK;
   USC_REQUIRE(in && W && rows_in && rows_out && koff && out, "usc_spconv_pairs_gemm: null pointer");
   GemmParams p{};
-  p.in = in; p.W = W; p.out = out; p.cin = cin; p.cout = cout; p.K = K;
+  p.in = in; p.W = W; p.out = out; p.cin = cin; p.cout = cout; p.K = K; p.G = 1;
   p.rows_in = rows_in; p.rows_out = rows_out; p.koff = koff;
-  const int NB = pick_nb(cout);
   const int64_t max_tiles = ceil_div(P_capacity, 32) + K;  // each offset pads to a multiple of 32 pairs
-  dim3 grid((unsigned)ceil_div(max_tiles, 4), (unsigned)ceil_div(cout, NB * 32));
-  hipStream_t st = as_stream(s);
-  switch (NB) {
-    case 1: hipLaunchKernelGGL((gather_gemm_kernel<1, true>), grid, dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((gather_gemm_kernel<2, true>), grid, dim3(256), 0, st, p); break;
-    case 3: hipLaunchKernelGGL((gather_gemm_kernel<3, true>), grid, dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((gather_gemm_kernel<4, true>), grid, dim3(256), 0, st, p); break;
-  }
+  const GemmPlan pl = plan_list(max_tiles, cin, cout);
+  dim3 grid((unsigned)ceil_div(max_tiles, 4), (unsigned)ceil_div(cout, pl.NB * 32));
+  launch_gemm<true>(pl, grid, as_stream(s), p);
   USC_CHECK_LAUNCH("usc_spconv_pairs_gemm");
   return USC_OK;
 }
@@ -379,6 +592,7 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
   USC_REQUIRE(a && b && dW && ws, "usc_spconv_wgrad: null pointer");
   USC_REQUIRE((a_idx && b_idx && koff) || (!a_idx && K == 1), "usc_spconv_wgrad: pair lists required for K>1");
   const int NB = pick_nb(cout);
+  const bool aligned = (cin % 32 == 0) && (cout % (NB * 32) == 0);
   const int S = wgrad_splits(K, cin, cout, NB, n_rows);
   const int64_t numel = (int64_t)K * cin * cout;
   USC_REQUIRE(ws_bytes >= (int64_t)S * numel * 4, "usc_spconv_wgrad: workspace too small");
@@ -388,12 +602,16 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
   dim3 grid((unsigned)(K * S), (unsigned)ceil_div(cin, 32), (unsigned)ceil_div(cout, NB * 32));
   const size_t lds = (size_t)3 * NB * 16 * 64 * sizeof(float);
   hipStream_t st = as_stream(s);
+#define USC_WG(NBv)                                                                          \
+  if (aligned) hipLaunchKernelGGL((wgrad_kernel<NBv, true>), grid, dim3(256), lds, st, p);  \
+  else hipLaunchKernelGGL((wgrad_kernel<NBv, false>), grid, dim3(256), lds, st, p);
   switch (NB) {
-    case 1: hipLaunchKernelGGL((wgrad_kernel<1>), grid, dim3(256), lds, st, p); break;
-    case 2: hipLaunchKernelGGL((wgrad_kernel<2>), grid, dim3(256), lds, st, p); break;
-    case 3: hipLaunchKernelGGL((wgrad_kernel<3>), grid, dim3(256), lds, st, p); break;
-    default: hipLaunchKernelGGL((wgrad_kernel<4>), grid, dim3(256), lds, st, p); break;
+    case 1: USC_WG(1) break;
+    case 2: USC_WG(2) break;
+    case 3: USC_WG(3) break;
+    default: USC_WG(4) break;
   }
+#undef USC_WG
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, S, numel,
                      dW);
   USC_CHECK_LAUNCH("usc_spconv_wgrad");

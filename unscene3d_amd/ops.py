@@ -146,6 +146,16 @@ def _conv_cost(P, n_in, n_out, K, cin, cout):
     return 2.0 * P * cin * cout, 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + 8.0 * P
 
 
+def _kernel_symbol(kind, n, cin, cout, K):
+    """rocprof-style symbol of the kernel a launch will use (usc_spconv_plan)."""
+    code = lib.usc_spconv_plan(kind, int(n), cin, cout, K)
+    nb, aligned = code & 0xFF, (code >> 8) & 1
+    if kind == 2:
+        return f"usc::wgrad_kernel<{nb}, {'true' if aligned else 'false'}>"
+    base = "usc::gather_gemm_aligned_kernel" if aligned else "usc::gather_gemm_kernel"
+    return f"{base}<{nb}, {'true' if kind == 1 else 'false'}>"
+
+
 def weight_transpose(W: torch.Tensor, mirror: bool) -> torch.Tensor:
     _chk(W, torch.float32, "W")
     K, cin, cout = W.shape
@@ -169,11 +179,14 @@ def gather_gemm(feats, W, nbr, n_out, bias=None, out=None, accumulate=False):
         out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
     if bias is not None:
         _chk(bias, torch.float32, "bias")
-    with _prof.maybe(lambda: f"usc::gather_gemm_kernel<{_prof.pick_nb(cout)}, false>",
+    wsb = lib.usc_spconv_gather_gemm_ws_bytes(n_out, cin, cout, K)
+    ws = _ws(wsb, feats.device) if wsb > 0 else None
+    with _prof.maybe(lambda: _kernel_symbol(0, n_out, cin, cout, K),
                      lambda: _conv_cost(_prof.table_pairs(nbr) if nbr is not None else n_out, feats.shape[0], n_out,
                                         K, cin, cout)):
         check(lib.usc_spconv_gather_gemm(_ptr(feats), feats.shape[0], cin, _ptr(W), K, cout, _ptr(nbr), n_out,
-                                         _ptr(bias), _ptr(out), int(accumulate), _stream()), "usc_spconv_gather_gemm")
+                                         _ptr(bias), _ptr(out), int(accumulate), _ptr(ws), wsb, _stream()),
+              "usc_spconv_gather_gemm")
     return out
 
 
@@ -185,7 +198,7 @@ def pairs_gemm(feats, W, rows_in, rows_out, koff, P, n_out):
     if feats.shape[1] != cin:
         raise RuntimeError("pairs_gemm: channel mismatch")
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
-    with _prof.maybe(lambda: f"usc::gather_gemm_kernel<{_prof.pick_nb(cout)}, true>",
+    with _prof.maybe(lambda: _kernel_symbol(1, int(P), cin, cout, K),
                      lambda: _conv_cost(int(P), feats.shape[0], n_out, K, cin, cout)):
         check(lib.usc_spconv_pairs_gemm(_ptr(feats), cin, _ptr(W), K, cout, _ptr(rows_in), _ptr(rows_out),
                                         _ptr(koff), int(P), _ptr(out), _stream()), "usc_spconv_pairs_gemm")
@@ -200,7 +213,7 @@ def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None):
     dW = torch.empty((K, cin, cout), dtype=torch.float32, device=a.device)
     ws = _ws(lib.usc_spconv_wgrad_ws_bytes(K, cin, cout), a.device)
     n_rows = a.shape[0] if a_idx is None else int(a_idx.shape[0])
-    with _prof.maybe(lambda: f"usc::wgrad_kernel<{_prof.pick_nb(cout)}>",
+    with _prof.maybe(lambda: _kernel_symbol(2, n_rows, cin, cout, K),
                      lambda: _conv_cost(n_rows, a.shape[0], b.shape[0], K, cin, cout)):
         check(lib.usc_spconv_wgrad(_ptr(a), cin, _ptr(b), cout, K, _ptr(a_idx), _ptr(b_idx), _ptr(koff), n_rows,
                                    _ptr(dW), _ptr(ws), ws.numel(), _stream()), "usc_spconv_wgrad")

@@ -113,6 +113,21 @@ def make_scene(seed: int, target_voxels: int = 150_000, points_per_cell: float =
         else:
             lo = s
     pts, objs, faces, tiles, n_obj, nv = best
+    if nv > (1 + tol) * target_voxels:
+        # tiny targets (unit tests): the smallest room is still too big -> crop along x
+        xs = np.sort(pts[:, 0])
+        lo_i, hi_i = 0, pts.shape[0] - 1
+        for _ in range(24):
+            mid = (lo_i + hi_i) // 2
+            keep = pts[:, 0] <= xs[mid]
+            nv = _count_voxels(pts[keep])
+            if abs(nv - target_voxels) <= tol * target_voxels:
+                break
+            if nv > target_voxels:
+                hi_i = mid
+            else:
+                lo_i = mid
+        pts, objs, faces, tiles = pts[keep], objs[keep], faces[keep], tiles[keep]
     rng = np.random.default_rng(seed + 7919)
     perm = rng.permutation(pts.shape[0])
     pts, objs, faces, tiles = pts[perm], objs[perm], faces[perm], tiles[perm]
