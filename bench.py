@@ -49,12 +49,16 @@ def build_model(device):
 
 def train_step(model, opt, xyz, colors, flat, world):
     from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd import ops
 
     # V1: voxelise on the device (reference: ME.utils.sparse_quantize in the collate, datasets/utils.py:403-408)
     c3, umap, _ = ME.utils.sparse_quantize(xyz, quantization_size=0.02, return_index=True, return_inverse=True,
                                            device=str(xyz.device))
     coords = torch.cat([torch.zeros((c3.shape[0], 1), dtype=torch.int32, device=xyz.device), c3], 1).contiguous()
-    feats = colors[umap]
+    # collate-side row order: z-order cells keep neighbouring voxels' rows close in HBM/L2
+    order = ops.spatial_order(coords)
+    coords = ops.gather_rows_i32(coords, order)
+    feats = ops.gather_rows(colors, umap[order])
     x = ME.SparseTensor(features=feats, coordinates=coords, device=xyz.device)   # V3
     out, fmaps = model(x)
     loss = out.F.square().mean()

@@ -80,6 +80,17 @@ int usc_coordmap_build(const int32_t* coords, int64_t n, int32_t quant,
                        int32_t* out_coords, int64_t* n_out,
                        void* ws, int64_t ws_bytes, usc_stream_t s);
 
+/* Spatial (z-order) cell id of every row: Morton code of ((c - lo) >> shift) with
+ * bits_per_axis bits per axis, batch index above it.  Feeding these ids to
+ * usc_segment_csr gives a stable, cache-friendly row permutation (rows of one
+ * 2^shift-voxel cell become contiguous) — an MI355X-side optimisation of the
+ * collate step (datasets/utils.py:412-417 gathers by unique_map; any consistent
+ * row order is valid downstream); it keeps gathers of neighbouring rows inside
+ * one XCD's L2. */
+int usc_morton_cell_ids(const int32_t* coords, int64_t n, int32_t shift,
+                        int32_t lo_x, int32_t lo_y, int32_t lo_z,
+                        int32_t bits_per_axis, int64_t* ids, usc_stream_t s);
+
 /* ------------------------------------------------------------------------
  * R2  kernel maps ("rulebooks") — replaces [ME] the kernel-map construction
  * cached by the CoordinateManager for MinkowskiConvolution /
@@ -187,6 +198,15 @@ int64_t usc_colstats_ws_bytes(int64_t n, int32_t c);
 int usc_colstats(const float* x, const float* y, int64_t n, int32_t c,
                  double* sum1, double* sum2, void* ws, int64_t ws_bytes,
                  usc_stream_t s);
+/* BatchNorm1d training statistics in one pass (f64 accumulation) + finalisation:
+ * mean, invstd = 1/sqrt(var_biased+eps), scale = gamma*invstd, shift = beta-mean*scale,
+ * and the running-stat update running = (1-m)*running + m*{mean, var_unbiased}
+ * (running_* may both be NULL).  ws: usc_colstats_ws_bytes(n, c). */
+int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamma,
+                         const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, float* mean,
+                         float* invstd, float* scale, float* shift, void* ws,
+                         int64_t ws_bytes, usc_stream_t s);
 /* y = [relu]( x*scale[c] + shift[c] (+ residual) ); mask-free (backward uses y>0). */
 int usc_bn_apply(const float* x, const float* scale, const float* shift,
                  const float* residual, int32_t relu, float* y, int64_t n,
@@ -200,11 +220,14 @@ int usc_bn_backward_dx(const float* x, const float* dy, const float* y_out,
                        const float* gamma, const float* mean_g,
                        const float* mean_gxhat, float* dx, float* dres,
                        int64_t n, int32_t c, usc_stream_t s);
-/* Channel sums needed by the above: sum_g[c], sum_gxhat[c] (f64). */
-int usc_bn_backward_stats(const float* x, const float* dy, const float* y_out,
-                          const float* mean, const float* invstd, int64_t n,
-                          int32_t c, double* sum_g, double* sum_gxhat, void* ws,
-                          int64_t ws_bytes, usc_stream_t s);
+/* Reductions needed by the above in one pass: dbeta[c] = sum g, dgamma[c] = sum g*xhat,
+ * mean_g = dbeta/n, mean_gxhat = dgamma/n (both 0 when training==0: eval-mode BN
+ * treats the statistics as constants).  g applies the ReLU mask of y_out when given. */
+int usc_bn_backward_reduce(const float* x, const float* dy, const float* y_out,
+                           const float* mean, const float* invstd, int64_t n,
+                           int32_t c, int32_t training, float* dgamma,
+                           float* dbeta, float* mean_g, float* mean_gxhat,
+                           void* ws, int64_t ws_bytes, usc_stream_t s);
 /* y = max(x,0);  dx = (y>0) ? dy : 0 */
 int usc_relu_fwd(const float* x, float* y, int64_t numel, usc_stream_t s);
 int usc_relu_bwd(const float* y, const float* dy, float* dx, int64_t numel,

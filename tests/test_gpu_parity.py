@@ -379,3 +379,20 @@ def test_config1_res16unet14_forward(device):
 
 def test_config2_res16unet34c_forward_backward_small(device):
     _backbone_case(device, "Res16UNet34C", (2, 3, 4, 6, 2, 2, 2, 2), seed=2000, n_points=5000, grad=True)
+
+
+def test_spatial_order_is_a_stable_cell_permutation(device):
+    from unscene3d_amd import ops
+
+    c = R.coordmap_build(_scene_coords(77, 20000, 40, batch=3))[2]
+    order = ops.spatial_order(_dev(c, device), shift=3).cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(len(c)))          # a permutation
+    cs = c[order]
+    assert np.all(np.diff(cs[:, 0]) >= 0)                             # batches stay grouped, in order
+    cell = np.concatenate([cs[:, :1], (cs[:, 1:] - c[:, 1:].min(0)) >> 3], 1)
+    change = np.any(np.diff(cell, axis=0) != 0, axis=1)
+    _, first = np.unique(cell, axis=0, return_index=True)
+    assert change.sum() + 1 == len(first)                             # every cell is one contiguous run
+    # stable inside a cell: original row order preserved
+    runs = np.split(order, np.nonzero(change)[0] + 1)
+    assert all(np.all(np.diff(r) > 0) for r in runs)

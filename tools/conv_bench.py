@@ -30,12 +30,15 @@ def main():
     ap.add_argument("--voxels", type=int, default=150000)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", type=str, default="")
+    ap.add_argument("--sorted", action="store_true", help="apply ops.spatial_order to the voxel rows first")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     sc = make_scene(2000, target_voxels=a.voxels)
     c3, umap, _ = ME.utils.sparse_quantize(sc["xyz"], quantization_size=0.02, return_index=True, return_inverse=True,
                                            device="cuda:0")
     coords = torch.cat([torch.zeros((c3.shape[0], 1), dtype=torch.int32, device=dev), c3], 1).contiguous()
+    if a.sorted:
+        coords = ops.gather_rows_i32(coords, ops.spatial_order(coords))
     x = ME.SparseTensor(features=torch.zeros(coords.shape[0], 3, device=dev), coordinates=coords, device=dev)
     cm = x.coordinate_manager
     for ts in (1, 2, 4, 8):

@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libusc3d_hip.so")
+LIB_PATH = os.environ.get("USC3D_LIB", os.path.join(_HERE, "libusc3d_hip.so"))   # override: developer ablation builds
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -29,6 +29,7 @@ SIGNATURES = {
     "usc_coordmap_capacity": (_i64, [_i64]),
     "usc_coordmap_ws_bytes": (_i64, [_i64]),
     "usc_coordmap_build": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p]),
+    "usc_morton_cell_ids": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "usc_kernel_map_cube": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _i64, _p, _p]),
     "usc_kernel_map_down2": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p]),
     "usc_rulebook_ws_bytes": (_i64, [_i64, _i64]),
@@ -44,7 +45,8 @@ SIGNATURES = {
     "usc_colstats": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "usc_bn_apply": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i64, _i32, _p]),
     "usc_bn_backward_dx": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
-    "usc_bn_backward_stats": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
+    "usc_bn_backward_reduce": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p]),
+    "usc_bn_forward_stats": (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "usc_relu_fwd": (C.c_int, [_p, _p, _i64, _p]),
     "usc_relu_bwd": (C.c_int, [_p, _p, _p, _i64, _p]),
     "usc_avgpool_down2": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),

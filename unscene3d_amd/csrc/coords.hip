@@ -173,6 +173,26 @@ __global__ __launch_bounds__(256) void kernel_map_down2_kernel(const int32_t* __
   kidx[i] = (uint8_t)k;
 }
 
+// Morton (z-order) code of the coarse cell (coord - lo) >> shift, batch index in the top bits.
+__device__ inline uint32_t spread3(uint32_t v) {  // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+__global__ __launch_bounds__(256) void morton_cells_kernel(const int32_t* __restrict__ coords, int64_t n, int shift,
+                                                          int lox, int loy, int loz, int bits, int64_t* __restrict__ ids) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int4 c = *reinterpret_cast<const int4*>(coords + 4 * i);
+  const uint32_t x = (uint32_t)((c.y - lox) >> shift), y = (uint32_t)((c.z - loy) >> shift),
+                 z = (uint32_t)((c.w - loz) >> shift);
+  const uint32_t m = spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+  ids[i] = ((int64_t)c.x << (3 * bits)) | (int64_t)(m & ((1u << (3 * bits)) - 1u));
+}
+
 struct NbrFlag {
   const int32_t* nbr;
   __device__ int operator()(int64_t j) const { return nbr[j] >= 0 ? 1 : 0; }
@@ -299,6 +319,17 @@ int usc_kernel_map_down2(const int32_t* fine_coords, int64_t n_fine, int32_t ten
   hipLaunchKernelGGL(kernel_map_down2_kernel, dim3((unsigned)ceil_div(n_fine, 256)), dim3(256), 0, as_stream(s),
                      fine_coords, n_fine, (int)tensor_stride, parent, coarse_coords, n_coarse, nbr2, kidx);
   USC_CHECK_LAUNCH("usc_kernel_map_down2");
+  return USC_OK;
+}
+
+int usc_morton_cell_ids(const int32_t* coords, int64_t n, int32_t shift, int32_t lo_x, int32_t lo_y, int32_t lo_z,
+                        int32_t bits_per_axis, int64_t* ids, usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && shift >= 0 && bits_per_axis >= 1 && bits_per_axis <= 10, "usc_morton_cell_ids: bad argument");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(coords && ids, "usc_morton_cell_ids: null pointer");
+  hipLaunchKernelGGL(morton_cells_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), coords, n,
+                     (int)shift, (int)lo_x, (int)lo_y, (int)lo_z, (int)bits_per_axis, ids);
+  USC_CHECK_LAUNCH("usc_morton_cell_ids");
   return USC_OK;
 }
 

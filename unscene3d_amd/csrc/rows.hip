@@ -97,17 +97,76 @@ __global__ __launch_bounds__(256) void colstats_kernel(StatArgs a, double* __res
   }
 }
 
-__global__ void colstats_final_kernel(const double* __restrict__ partial, int nblocks, int c, double* __restrict__ sum1,
-                                      double* __restrict__ sum2) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double t1 = 0.0, t2 = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    t1 += partial[((int64_t)b * 2 + 0) * c + ch];
-    t2 += partial[((int64_t)b * 2 + 1) * c + ch];
+// one wave per channel: lanes stride the block partials, fixed shuffle tree -> deterministic
+__device__ inline void reduce_partials(const double* __restrict__ partial, int nblocks, int c, int ch, double& t1,
+                                       double& t2) {
+  const int lane = threadIdx.x & 63;
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = lane; b < nblocks; b += 64) {
+    a1 += partial[((int64_t)b * 2 + 0) * c + ch];
+    a2 += partial[((int64_t)b * 2 + 1) * c + ch];
   }
-  sum1[ch] = t1;
-  sum2[ch] = t2;
+  t1 = wave_reduce_addd(a1);
+  t2 = wave_reduce_addd(a2);
+}
+
+__global__ __launch_bounds__(64) void colstats_final_kernel(const double* __restrict__ partial, int nblocks, int c,
+                                                           double* __restrict__ sum1, double* __restrict__ sum2) {
+  const int ch = blockIdx.x;
+  double t1, t2;
+  reduce_partials(partial, nblocks, c, ch, t1, t2);
+  if ((threadIdx.x & 63) == 0) {
+    sum1[ch] = t1;
+    sum2[ch] = t2;
+  }
+}
+
+// BatchNorm1d training statistics -> everything the apply/backward kernels need, plus the
+// running-stat update (momentum rule of torch.nn.BatchNorm1d: unbiased variance).
+struct BnFwdOut {
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;
+  float* mean; float* invstd; float* scale; float* shift;
+  float eps, momentum;
+  int64_t n;
+};
+__global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int c,
+                                                            BnFwdOut o) {
+  const int ch = blockIdx.x;
+  double s1, s2;
+  reduce_partials(partial, nblocks, c, ch, s1, s2);
+  if ((threadIdx.x & 63) == 0) {
+    const double n = (double)o.n;
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m;
+    const float invstd = (float)(1.0 / sqrt(var + (double)o.eps));
+    const float sc = o.gamma[ch] * invstd;
+    o.mean[ch] = mean;
+    o.invstd[ch] = invstd;
+    o.scale[ch] = sc;
+    o.shift[ch] = o.beta[ch] - mean * sc;
+    if (o.running_mean) {
+      const double unbiased = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+      o.running_mean[ch] = (1.f - o.momentum) * o.running_mean[ch] + o.momentum * mean;
+      o.running_var[ch] = (1.f - o.momentum) * o.running_var[ch] + o.momentum * (float)unbiased;
+    }
+  }
+}
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int c,
+                                                            int64_t n, int training, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ mean_g,
+                                                            float* __restrict__ mean_gx) {
+  const int ch = blockIdx.x;
+  double sg, sgx;
+  reduce_partials(partial, nblocks, c, ch, sg, sgx);
+  if ((threadIdx.x & 63) == 0) {
+    dbeta[ch] = (float)sg;
+    dgamma[ch] = (float)sgx;
+    mean_g[ch] = training ? (float)(sg / (double)n) : 0.f;
+    mean_gx[ch] = training ? (float)(sgx / (double)n) : 0.f;
+  }
 }
 
 static int colstats_blocks(int64_t n, int c, int vec) {
@@ -119,8 +178,8 @@ static int colstats_blocks(int64_t n, int c, int vec) {
 }
 
 template <int MODE>
-static int launch_colstats(const StatArgs& a, double* sum1, double* sum2, void* ws, int64_t ws_bytes, hipStream_t st,
-                           const char* name) {
+static int launch_colstats_partials(const StatArgs& a, void* ws, int64_t ws_bytes, hipStream_t st, const char* name,
+                                    int* nblocks_out) {
   const int c = a.c;
   USC_REQUIRE(c >= 1 && c <= 1024, "%s: unsupported channel count %d", name, c);
   const int vec = (c % 4 == 0 && c / 4 <= 256) ? 4 : 1;
@@ -134,8 +193,7 @@ static int launch_colstats(const StatArgs& a, double* sum1, double* sum2, void* 
     hipLaunchKernelGGL((colstats_kernel<4, MODE>), dim3(nb), dim3(256), lds, st, a, partial);
   else
     hipLaunchKernelGGL((colstats_kernel<1, MODE>), dim3(nb), dim3(256), lds, st, a, partial);
-  hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)ceil_div(c, 128)), dim3(128), 0, st, partial, nb, c, sum1,
-                     sum2);
+  *nblocks_out = nb;
   return USC_OK;
 }
 
@@ -434,20 +492,42 @@ int usc_colstats(const float* x, const float* y, int64_t n, int32_t c, double* s
                  int64_t ws_bytes, usc_stream_t s) {
   USC_REQUIRE(x && sum1 && sum2 && ws && n >= 0, "usc_colstats: bad argument");
   StatArgs a{x, y, nullptr, nullptr, nullptr, n, (int)c};
-  int rc = launch_colstats<STAT_XY>(a, sum1, sum2, ws, ws_bytes, as_stream(s), "usc_colstats");
+  int nb = 0;
+  int rc = launch_colstats_partials<STAT_XY>(a, ws, ws_bytes, as_stream(s), "usc_colstats", &nb);
   if (rc) return rc;
+  hipLaunchKernelGGL(colstats_final_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c,
+                     sum1, sum2);
   USC_CHECK_LAUNCH("usc_colstats");
   return USC_OK;
 }
 
-int usc_bn_backward_stats(const float* x, const float* dy, const float* y_out, const float* mean, const float* invstd,
-                          int64_t n, int32_t c, double* sum_g, double* sum_gxhat, void* ws, int64_t ws_bytes,
-                          usc_stream_t s) {
-  USC_REQUIRE(x && dy && mean && invstd && sum_g && sum_gxhat && ws && n >= 0, "usc_bn_backward_stats: bad argument");
-  StatArgs a{x, dy, y_out, mean, invstd, n, (int)c};
-  int rc = launch_colstats<STAT_BN_BWD>(a, sum_g, sum_gxhat, ws, ws_bytes, as_stream(s), "usc_bn_backward_stats");
+int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
+                         float* scale, float* shift, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(x && gamma && beta && mean && invstd && scale && shift && ws && n >= 1, "usc_bn_forward_stats: bad argument");
+  USC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "usc_bn_forward_stats: running stats mismatch");
+  StatArgs a{x, nullptr, nullptr, nullptr, nullptr, n, (int)c};
+  int nb = 0;
+  int rc = launch_colstats_partials<STAT_XY>(a, ws, ws_bytes, as_stream(s), "usc_bn_forward_stats", &nb);
   if (rc) return rc;
-  USC_CHECK_LAUNCH("usc_bn_backward_stats");
+  BnFwdOut o{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n};
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c, o);
+  USC_CHECK_LAUNCH("usc_bn_forward_stats");
+  return USC_OK;
+}
+
+int usc_bn_backward_reduce(const float* x, const float* dy, const float* y_out, const float* mean, const float* invstd,
+                           int64_t n, int32_t c, int32_t training, float* dgamma, float* dbeta, float* mean_g,
+                           float* mean_gxhat, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(x && dy && mean && invstd && dgamma && dbeta && mean_g && mean_gxhat && ws && n >= 1,
+              "usc_bn_backward_reduce: bad argument");
+  StatArgs a{x, dy, y_out, mean, invstd, n, (int)c};
+  int nb = 0;
+  int rc = launch_colstats_partials<STAT_BN_BWD>(a, ws, ws_bytes, as_stream(s), "usc_bn_backward_reduce", &nb);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c,
+                     n, (int)training, dgamma, dbeta, mean_g, mean_gxhat);
+  USC_CHECK_LAUNCH("usc_bn_backward_reduce");
   return USC_OK;
 }
 

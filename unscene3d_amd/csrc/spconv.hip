@@ -35,6 +35,7 @@ struct GemmParams {
   int cin, cout, K;
   int accumulate;
   int G;                // offset groups (blockIdx.z); >1 -> partial sums, reduced afterwards
+  int TM;               // tile-compacted kernel: output rows per workgroup
   // pairs form
   const int32_t* rows_in;
   const int32_t* rows_out;
@@ -58,7 +59,7 @@ template <int NB>
 __device__ inline void load_b(const float* __restrict__ p, float (&b)[NB]) {
   if (NB == 4) {
     const float4 t = *reinterpret_cast<const float4*>(p);
-    b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3 % NB] = t.w;
+    b[0] = t.x; b[1 % NB] = t.y; b[2 % NB] = t.z; b[3 % NB] = t.w;
   } else if (NB == 2) {
     const float2 t = *reinterpret_cast<const float2*>(p);
     b[0] = t.x; b[1 % NB] = t.y;
@@ -186,6 +187,239 @@ __global__ __launch_bounds__(256) void gather_gemm_aligned_kernel(GemmParams p) 
       for (int nb = 0; nb < NB; ++nb) dst[nb] = v[nb];
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Tile-compacted gather GEMM (large maps).  A workgroup owns TM consecutive output rows and keeps
+// their [TM][32*NB] fp32 accumulators in LDS.  For every kernel offset k the rows that actually
+// have a neighbour are compacted (ballot + popcount prefix) into pair lists, so the matrix cores
+// only see groups of 32 REAL (in,out) pairs instead of 32 rows of which ~half are padding
+// (random-order surface voxels: 13 of 27 neighbours present).  The work items (k, group) of a
+// tile are dealt round-robin to the 4 waves; each wave gathers its 32 input rows, runs the MFMA
+// reduction over Cin into registers and then adds the 32xBN result into the LDS accumulators.
+// Flushes are serialised by an LDS ticket in item order, which makes the fp32 summation order —
+// and therefore the result — bit-reproducible without float atomics.
+constexpr int kMaxK = 27;
+
+constexpr int kCompactWaves = 8;   // one 512-thread workgroup per CU, two waves per SIMD
+
+template <int NB>
+__global__ __launch_bounds__(64 * kCompactWaves, 2) void gather_gemm_compact_kernel(GemmParams p) {
+  constexpr int BN = NB * 32;
+  constexpr int NT = 64 * kCompactWaves;
+  const int TM = p.TM;   // rows per tile (multiple of 4, <= 256), chosen so that tiles fill whole CU rounds
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* accT = reinterpret_cast<float*>(smem);                        // [TM][BN]
+  int32_t* pl_in = reinterpret_cast<int32_t*>(accT + TM * BN);         // [K][TM]
+  int32_t* cnt = pl_in + kMaxK * TM;                                   // [32]
+  int32_t* item_start = cnt + 32;                                      // [32]
+  volatile int32_t* ticket = item_start + 32;                          // [1] (+3 pad)
+  uint8_t* pl_loc = reinterpret_cast<uint8_t*>(item_start + 36);       // [K][TM]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.y * BN;
+  const int cin = p.cin, cout = p.cout, K = p.K;
+  const int64_t r0 = (int64_t)blockIdx.x * TM;
+
+  // ---- prologue: zero accumulators, compact the neighbour table of this tile per offset
+  for (int e = threadIdx.x; e < TM * BN / 4; e += NT) reinterpret_cast<float4*>(accT)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (threadIdx.x == 0) *ticket = 0;
+  for (int k = wave; k < K; k += kCompactWaves) {
+    int base = 0;
+    for (int c = 0; c * 64 < TM; ++c) {
+      const int lr = c * 64 + lane;
+      const int64_t row = r0 + lr;
+      const int v = (lr < TM && row < p.n_out) ? (p.nbr ? p.nbr[(int64_t)k * p.n_out + row] : (int)row) : -1;
+      const bool f = v >= 0;
+      const unsigned long long m = __ballot(f);
+      if (f) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        pl_in[k * TM + pos] = v;
+        pl_loc[k * TM + pos] = (uint8_t)(c * 64 + lane);
+      }
+      base += __popcll(m);
+    }
+    if (lane == 0) cnt[k] = base;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int c = (lane < K) ? cnt[lane] : 0;
+    const int items = (c + 31) >> 5;
+    const int inc = wave_inclusive_scan(items);
+    if (lane < 32) item_start[lane] = inc - items;   // exclusive prefix; entries >= K hold the total
+  }
+  __syncthreads();
+  const int total_items = item_start[K < 32 ? K : 31] + (K >= 32 ? 0 : 0);
+  const int my_start = (lane < 32) ? item_start[lane] : 0x7fffffff;
+
+  // ---- main loop: software-pipelined over the flattened (item, Cin-chunk) steps of this wave.
+  // Register set X feeds the matrix cores while set Y receives the next step's gathers, then swap.
+  struct Step {
+    const float* arow;  // gathered input row of lane (i,h) (+4h), already offset to the chunk
+    const float* wk;    // weight slice of the chunk for this lane's columns
+    int loc;            // local output row of pair i (or -1)
+    int item;           // work item index (ticket) ; -1 = past the end (dummy loads, no MFMA)
+    int chunk;          // Cin chunk inside the item
+    bool valid;
+  };
+  const int nch = cin >> 5;
+  auto first_step = [&](int item) -> Step {
+    Step st;
+    st.chunk = 0;
+    if (item >= total_items) {
+      st.item = -1; st.loc = -1; st.valid = false;
+      st.arow = p.in + 4 * h;
+      st.wk = p.W + (int64_t)(4 * h) * cout + n0 + NB * i;
+      return st;
+    }
+    const unsigned long long le = __ballot(lane < K && my_start <= item);
+    const int k = 63 - __clzll(le);   // last offset whose first item index <= item
+    const int g = item - item_start[k];
+    const int npairs = cnt[k] - g * 32;
+    st.valid = i < npairs;
+    const int pidx = k * TM + g * 32 + i;
+    const int64_t in_row = st.valid ? (int64_t)pl_in[pidx] : 0;
+    st.loc = st.valid ? (int)pl_loc[pidx] : -1;
+    st.item = item;
+    st.arow = p.in + in_row * (int64_t)cin + 4 * h;
+    st.wk = p.W + (int64_t)k * cin * cout + (int64_t)(4 * h) * cout + n0 + NB * i;
+    return st;
+  };
+  auto next_step = [&](const Step& c) -> Step {
+    if (c.item < 0) return c;
+    if (c.chunk + 1 < nch) {
+      Step n = c;
+      n.chunk = c.chunk + 1;
+      n.arow = c.arow + 32;
+      n.wk = c.wk + (int64_t)32 * cout;
+      return n;
+    }
+    return first_step(c.item + kCompactWaves);
+  };
+  auto issue_loads = [&](const Step& st, float4 (&a)[4], float (&b)[16][NB]) {
+#ifdef USC_ABLATE_A
+    a[0] = *reinterpret_cast<const float4*>(st.arow);
+#pragma unroll
+    for (int t = 1; t < 4; ++t) a[t] = a[0];
+#else
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(st.arow + 8 * t);
+#endif
+#ifdef USC_ABLATE_B
+    load_b<NB>(st.wk, b[0]);
+#pragma unroll
+    for (int q = 1; q < 16; ++q)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) b[q][nb] = b[0][nb] + (float)q;
+#else
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) load_b<NB>(st.wk + (int64_t)(8 * t + j) * cout, b[4 * t + j]);
+#endif
+  };
+  f32x16 acc[NB];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+  };
+  auto run_mfma = [&](const Step& st, float4 (&a)[4], float (&b)[16][NB]) {
+    if (!st.valid) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float av[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA32(av[j], b[4 * t + j][nb], acc[nb]);
+    }
+  };
+  auto flush = [&](const Step& st) {
+#ifdef USC_ABLATE_FLUSH
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(acc[nb]));
+    zero_acc();
+    return;
+#endif
+    // ordered flush into the LDS accumulators (ticket == item index)
+    if (lane == 0) {
+      while (*ticket != st.item) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // Plain LDS read-add-write; the ticket gives this wave exclusive, ordered access (ds_add_f32
+    // atomics measured 2x slower for the whole kernel).  All reads are issued before the first
+    // dependent add so the 16 row updates pipeline instead of paying one LDS round trip each —
+    // the serialised flush is the critical section of the workgroup.
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      int lrs[8];
+      float old[8][NB];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = half * 8 + q;
+        lrs[q] = __shfl(st.loc, acc_row(r, h), 64);
+        const float* src = accT + (lrs[q] >= 0 ? lrs[q] : 0) * BN + NB * i;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) old[q][nb] = src[nb];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = half * 8 + q;
+        if (lrs[q] >= 0) {
+          float* dst = accT + lrs[q] * BN + NB * i;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) dst[nb] = old[q][nb] + acc[nb][r];
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // LDS updates done before the ticket moves
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) *ticket = st.item + 1;
+    zero_acc();
+  };
+
+  // (Double-buffering the gathers was measured to be worth <5 %: neither the A nor the B loads are
+  // on the critical path, the ordered flush is.  One register set keeps two waves per SIMD.)
+  float4 aX[4];
+  float bX[16][NB];
+  Step cur = first_step(wave);
+  zero_acc();
+  while (cur.item >= 0) {
+    issue_loads(cur, aX, bX);
+    run_mfma(cur, aX, bX);
+    if (cur.chunk + 1 == nch) flush(cur);
+    cur = next_step(cur);
+  }
+  __syncthreads();
+
+  // ---- epilogue: coalesced copy of the tile to HBM
+  for (int e = threadIdx.x; e < TM * BN / 4; e += NT) {
+    const int lr = e / (BN / 4), c4 = e - lr * (BN / 4);
+    const int64_t row = r0 + lr;
+    if (row >= p.n_out) continue;
+    float4 v = reinterpret_cast<const float4*>(accT)[e];
+    float* dst = p.out + row * (int64_t)cout + n0 + c4 * 4;
+    if (p.bias) {
+      const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + c4 * 4);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    if (p.accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(dst);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(dst) = v;
+  }
+}
+
+static size_t compact_lds_bytes(int NB, int TM) {
+  return (size_t)TM * NB * 32 * 4 + (size_t)kMaxK * TM * 4 + (32 + 32 + 4) * 4 + (size_t)kMaxK * TM;
 }
 
 // out = (accumulate ? out : 0) + bias + sum_g partial[g]   (fixed order)
@@ -447,14 +681,28 @@ static int pick_nb(int cout) {
 // groups (G).  Large maps keep the widest tile (least re-gathering of A rows); small maps
 // (coarse U-Net levels: hundreds to a few thousand rows, 128-256 channels) shrink the tile
 // and split the K offsets over blockIdx.z so that >= ~3 waves per SIMD are in flight.
-struct GemmPlan { int NB; int G; bool aligned; };
+struct GemmPlan { int NB; int G; bool aligned; int TM; };   // TM > 0: tile-compacted kernel
 constexpr int64_t kTargetWaves = 3072;
 
 static GemmPlan plan_table(int64_t n_out, int cin, int cout, int K) {
-  GemmPlan pl{pick_nb(cout), 1, false};
+  GemmPlan pl{pick_nb(cout), 1, false, 0};
   const bool al = (cin % 32 == 0) && (cout % 32 == 0);
   if (!al) return pl;
   pl.aligned = true;
+  if (K > 1 && K <= kMaxK && n_out >= 24576 && cin >= 64) {
+    // large maps: tile-compacted kernel (no MFMA work on absent neighbours).  One 8-wave workgroup
+    // per CU; the tile height is chosen so that the tiles fill an integer number of 256-CU rounds.
+    const int cb = cout / 32;
+    const int nb = (cb % 3 == 0) ? 3 : (cb % 2 == 0 ? 2 : 1);
+    const int tm_max = nb == 3 ? 192 : 256;
+    int64_t R = 1;
+    int64_t tm = ceil_div(n_out, 256 * R);
+    while (tm > tm_max) { ++R; tm = ceil_div(n_out, 256 * R); }
+    tm = (tm + 3) & ~3ll;
+    pl.NB = nb;
+    pl.TM = (int)tm;
+    return pl;
+  }
   const int64_t row_tiles = ceil_div(n_out, 32);
   const int cb = cout / 32;
   const int cands[4] = {4, 3, 2, 1};
@@ -474,7 +722,7 @@ static GemmPlan plan_table(int64_t n_out, int cin, int cout, int K) {
   return pl;
 }
 static GemmPlan plan_list(int64_t max_tiles, int cin, int cout) {
-  GemmPlan pl{pick_nb(cout), 1, false};
+  GemmPlan pl{pick_nb(cout), 1, false, 0};
   const bool al = (cin % 32 == 0) && (cout % 32 == 0);
   if (!al) return pl;
   pl.aligned = true;
@@ -527,8 +775,8 @@ int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout, int32_t 
   GemmPlan pl;
   if (kind == 0) pl = plan_table(n, cin, cout, K);
   else if (kind == 1) pl = plan_list(ceil_div(n, 32) + K, cin, cout);
-  else { const int NB = pick_nb(cout); pl = GemmPlan{NB, 1, (cin % 32 == 0) && (cout % (NB * 32) == 0)}; }
-  return pl.NB | ((pl.aligned ? 1 : 0) << 8) | (pl.G << 16);
+  else { const int NB = pick_nb(cout); pl = GemmPlan{NB, 1, (cin % 32 == 0) && (cout % (NB * 32) == 0), 0}; }
+  return pl.NB | ((pl.aligned ? 1 : 0) << 8) | ((pl.TM > 0 ? 1 : 0) << 12) | (pl.G << 16);
 }
 
 int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin, int32_t cout, int32_t K) {
@@ -552,8 +800,27 @@ int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const flo
     USC_REQUIRE(ws && ws_bytes >= (int64_t)pl.G * n_out * cout * 4, "usc_spconv_gather_gemm: workspace too small");
     p.out = (float*)ws;
   }
-  dim3 grid((unsigned)ceil_div(n_out, 128), (unsigned)ceil_div(cout, pl.NB * 32), (unsigned)pl.G);
   hipStream_t st = as_stream(s);
+  if (pl.TM > 0) {
+    p.TM = pl.TM;
+    dim3 cgrid((unsigned)ceil_div(n_out, pl.TM), (unsigned)(cout / (pl.NB * 32)));
+    const size_t lds = compact_lds_bytes(pl.NB, pl.TM);
+#define USC_CG(NBv)                                                                                        \
+    {                                                                                                      \
+      static bool attr_set = false;                                                                        \
+      auto kfn = gather_gemm_compact_kernel<NBv>;                                                          \
+      if (!attr_set) {                                                                                     \
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        attr_set = true;                                                                                   \
+      }                                                                                                    \
+      hipLaunchKernelGGL(kfn, cgrid, dim3(64 * kCompactWaves), lds, st, p);                                \
+    }
+    if (pl.NB == 3) USC_CG(3) else if (pl.NB == 2) USC_CG(2) else USC_CG(1)
+#undef USC_CG
+    USC_CHECK_LAUNCH("usc_spconv_gather_gemm");
+    return USC_OK;
+  }
+  dim3 grid((unsigned)ceil_div(n_out, 128), (unsigned)ceil_div(cout, pl.NB * 32), (unsigned)pl.G);
   launch_gemm<false>(pl, grid, st, p);
   if (pl.G > 1) {
     const int64_t numel4 = n_out * cout / 4;

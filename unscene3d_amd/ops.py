@@ -98,6 +98,28 @@ def coordmap_build(coords: torch.Tensor, quant: int = 1, tensor_stride: int = 1)
     return cmap, unique_idx[:m], inverse
 
 
+def spatial_order(coords: torch.Tensor, shift: int = 3) -> torch.Tensor:
+    """Row permutation (i64[n]) that makes the rows of every 2^shift-voxel cell contiguous, cells in z-order,
+    batches kept in order; stable inside a cell.  An optional collate-side optimisation (see usc3d.h)."""
+    require_device()
+    _chk(coords, torch.int32, "coords")
+    n = coords.shape[0]
+    dev = coords.device
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64, device=dev)
+    lo = coords[:, 1:].amin(0).tolist()
+    hi = coords[:, 1:].amax(0).tolist()
+    nb = int(coords[:, 0].max().item()) + 1
+    extent = max(h - l for h, l in zip(hi, lo)) >> shift
+    bits = max(1, int(extent).bit_length())
+    if bits > 10:
+        raise RuntimeError("spatial_order: scene extent too large for 10-bit cells; raise `shift`")
+    ids = torch.empty(n, dtype=torch.int64, device=dev)
+    check(lib.usc_morton_cell_ids(_ptr(coords), n, shift, lo[0], lo[1], lo[2], bits, _ptr(ids), _stream()),
+          "usc_morton_cell_ids")
+    return segment_csr(ids, nb << (3 * bits)).order
+
+
 def kernel_map_cube(cmap: CoordMap, ksize: int = 3) -> torch.Tensor:
     """Dense neighbour table i32[K, n] of a stride-1 HYPER_CUBE kernel on `cmap`."""
     K = ksize ** 3
@@ -149,7 +171,9 @@ def _conv_cost(P, n_in, n_out, K, cin, cout):
 def _kernel_symbol(kind, n, cin, cout, K):
     """rocprof-style symbol of the kernel a launch will use (usc_spconv_plan)."""
     code = lib.usc_spconv_plan(kind, int(n), cin, cout, K)
-    nb, aligned = code & 0xFF, (code >> 8) & 1
+    nb, aligned, compact = code & 0xFF, (code >> 8) & 1, (code >> 12) & 1
+    if kind == 0 and compact:
+        return f"usc::gather_gemm_compact_kernel<{nb}>"
     if kind == 2:
         return f"usc::wgrad_kernel<{nb}, {'true' if aligned else 'false'}>"
     base = "usc::gather_gemm_aligned_kernel" if aligned else "usc::gather_gemm_kernel"
@@ -352,24 +376,22 @@ class _BatchNormAct(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, residual, relu, eps, running_mean, running_var, momentum, training):
         x = x.contiguous()
         n, c = x.shape
+        dev = x.device
         if training:
-            s1, s2 = colstats(x)
-            mean64 = s1 / n
-            var64 = (s2 / n - mean64 * mean64).clamp_(min=0.0)
-            mean = mean64.to(torch.float32)
-            invstd = torch.rsqrt(var64 + eps).to(torch.float32)
-            if running_mean is not None:
-                with torch.no_grad():
-                    unbiased = var64 * (n / max(n - 1, 1))
-                    running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(unbiased.to(torch.float32), alpha=momentum)
+            stats = torch.empty((4, c), dtype=torch.float32, device=dev)   # mean | invstd | scale | shift
+            mean, invstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
+            ws = _ws(lib.usc_colstats_ws_bytes(n, c), dev)
+            check(lib.usc_bn_forward_stats(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                                           _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
+                                           _ptr(scale), _ptr(shift), _ptr(ws), ws.numel(), _stream()),
+                  "usc_bn_forward_stats")
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
-        scale = gamma * invstd
-        shift = beta - mean * scale
+            scale = (gamma * invstd).contiguous()
+            shift = (beta - mean * scale).contiguous()
         res = None if residual is None else residual.contiguous()
-        y = bn_apply(x, scale.contiguous(), shift.contiguous(), res, relu)
+        y = bn_apply(x, scale, shift, res, relu)
         ctx.save_for_backward(x, gamma, mean, invstd, y if relu else None)
         ctx.relu, ctx.has_res, ctx.training = relu, residual is not None, training
         return y
@@ -380,24 +402,16 @@ class _BatchNormAct(torch.autograd.Function):
         dy = dy.contiguous()
         n, c = x.shape
         dev = x.device
-        sg = torch.empty(c, dtype=torch.float64, device=dev)
-        sgx = torch.empty(c, dtype=torch.float64, device=dev)
+        red = torch.empty((4, c), dtype=torch.float32, device=dev)   # dgamma | dbeta | mean_g | mean_gx
         ws = _ws(lib.usc_colstats_ws_bytes(n, c), dev)
-        check(lib.usc_bn_backward_stats(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), n, c, _ptr(sg),
-                                        _ptr(sgx), _ptr(ws), ws.numel(), _stream()), "usc_bn_backward_stats")
-        dgamma = sgx.to(torch.float32)
-        dbeta = sg.to(torch.float32)
-        if ctx.training:
-            mean_g = (sg / n).to(torch.float32)
-            mean_gx = (sgx / n).to(torch.float32)
-        else:  # eval mode: statistics are constants
-            mean_g = torch.zeros(c, dtype=torch.float32, device=dev)
-            mean_gx = torch.zeros(c, dtype=torch.float32, device=dev)
+        check(lib.usc_bn_backward_reduce(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), n, c,
+                                         int(ctx.training), _ptr(red[0]), _ptr(red[1]), _ptr(red[2]), _ptr(red[3]),
+                                         _ptr(ws), ws.numel(), _stream()), "usc_bn_backward_reduce")
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
-        check(lib.usc_bn_backward_dx(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(mean_g),
-                                     _ptr(mean_gx), _ptr(dx), _ptr(dres), n, c, _stream()), "usc_bn_backward_dx")
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None
+        check(lib.usc_bn_backward_dx(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(red[2]),
+                                     _ptr(red[3]), _ptr(dx), _ptr(dres), n, c, _stream()), "usc_bn_backward_dx")
+        return dx, red[0], red[1], dres, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, residual=None, relu=False, eps=1e-5, running_mean=None, running_var=None,
@@ -463,6 +477,12 @@ def gather_rows(src, idx):
     _chk(src, torch.float32, "src")
     _chk(idx, torch.int64, "idx")
     return _GatherRows.apply(src, idx)
+
+
+def gather_rows_i32(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """Row gather of an int32 table (coordinates) through the same kernel (bit pattern copy)."""
+    _chk(src, torch.int32, "src")
+    return _GatherRows.apply(src.view(torch.float32), idx.contiguous()).view(torch.int32)
 
 
 @dataclass
