@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--voxels", type=int, default=VOXELS)
+    ap.add_argument("--mode", choices=["mask3d", "backbone"], default="mask3d",
+                    help="mask3d: BASELINE.json configs[2] full self-train step (the metric's config); "
+                         "backbone: configs[1] Res16UNet34C fwd+bwd only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-voxels", type=int, default=15_000)
     return ap.parse_args()
@@ -73,8 +76,57 @@ def train_step(model, opt, xyz, colors, flat, world):
     return loss, coords.shape[0]
 
 
-def cpu_baseline(sample_voxels):
+WORKLOADS = {
+    "backbone": "BASELINE.json configs[1]: Res16UNet34C backbone fwd+bwd+AdamW, one synthetic ScanNet-shaped scene "
+                "per GPU, {nvox} voxels @2cm (voxelise + coordinate/kernel maps rebuilt every step), random-init weights",
+    "mask3d": "BASELINE.json configs[2]: full Mask3D self-train step (device collate/voxelise -> Res16UNet34C -> "
+              "100-query decoder 3x4 passes -> Hungarian (scipy, host) -> 52 losses -> backward -> AdamW + OneCycleLR), "
+              "one synthetic ScanNet-shaped scene per GPU, {nvox} voxels @2cm, pseudo-mask targets, random-init weights",
+}
+
+
+def make_mask3d_step(args, dev, rank, world):
+    """Full self-training step (reference trainer/trainer.py:99-163 + :953-966) on one scene per rank."""
+    from unscene3d_amd.config import apply_overrides, default_config
+    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+    from unscene3d_amd.ddp import flatten_grads
+    from unscene3d_amd.trainer.trainer import InstanceSegmentation
+
+    cfg = apply_overrides(default_config(), ["general.num_targets=3", f"data.batch_size={world}"])
+    torch.manual_seed(1234)
+    module = InstanceSegmentation(cfg).to(dev).train()
+    params = [p for n, p in module.named_parameters() if ".backbone.final." not in n]    # unused in forward
+    flat = flatten_grads(params)
+    opt = torch.optim.AdamW(params, lr=cfg.optimizer.lr, fused=True)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=cfg.optimizer.lr, total_steps=100000)
+    sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=args.voxels, seed=2000 + rank)[0]
+    # raw scene arrays resident in HBM before the timed region (the collate reads them from there)
+    sample = tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) if isinstance(x, np.ndarray) and i in (0, 1, 2)
+                   else x for i, x in enumerate(sample))
+    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(dev),
+                                      spatial_sort=True)
+
+    def step(w):
+        batch = collate([sample])
+        out = module.training_step(batch)
+        total, _ = out
+        opt.zero_grad(set_to_none=False)
+        total.backward()
+        if w > 1:
+            dist.all_reduce(flat)      # RCCL over xGMI: one flat ~158 MB gradient buffer
+            flat.div_(w)
+        opt.step()
+        sched.step()
+        return total.detach(), batch[0].coordinates.shape[0]
+
+    return step
+
+
+def cpu_baseline(sample_voxels, mode="mask3d"):
     """Oracle (CPU restatement of the same fwd+bwd) on a bounded sample, rank 0 only."""
+    if mode == "mask3d":
+        return cpu_baseline_mask3d(sample_voxels)
     import oracle.res16unet_ref as M
     from oracle import sparse_ref as R
     from unscene3d_amd.synthetic import make_scene
@@ -107,6 +159,55 @@ def cpu_baseline(sample_voxels):
     }
 
 
+def cpu_baseline_mask3d(sample_voxels):
+    """oracle/mask3d_ref.py forward + criterion + backward on one small scene, scaled by voxel count."""
+    import oracle.mask3d_ref as OM
+    from oracle import sparse_ref as R
+    from unscene3d_amd.config import apply_overrides, default_config, instantiate_model
+    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+    from unscene3d_amd.models.criterion import SetCriterion
+    from unscene3d_amd.models.matcher import HungarianMatcher
+
+    cfg = apply_overrides(default_config(), ["general.num_targets=3"])
+    sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=sample_voxels, seed=2999)[0]
+    torch.manual_seed(1234)
+    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point)
+          for k, v in instantiate_model(cfg).state_dict().items()}
+    t0 = time.perf_counter()
+    ec = R.voxel_floor(sample[0], 0.02)
+    eu, _ = R.sparse_quantize(ec)
+    coords4, feats = R.sparse_collate([ec[eu]], [sample[1][eu]])
+    table = torch.from_numpy(sample[2][eu].astype(np.int64))
+    _, p2s = np.unique(table[:, -1].numpy(), return_inverse=True)
+    p2s = torch.from_numpy(p2s.reshape(-1))
+    S = int(p2s.max()) + 1
+    masks = table[:, 1:-1].bool().T
+    masks = masks[masks.sum(1) > 0]
+    seg_mask = torch.zeros(masks.shape[0], S, dtype=torch.bool)
+    for t in range(masks.shape[0]):
+        seg_mask[t, p2s[masks[t]].unique()] = True
+    target = [{"labels": torch.ones(masks.shape[0], dtype=torch.int64), "masks": masks, "segment_mask": seg_mask,
+               "point2segment": p2s}]
+    feats = torch.from_numpy(feats)
+    out = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], [p2s],
+                            lambda n: torch.randperm(n))
+    m = cfg.matcher
+    matcher = HungarianMatcher(m.cost_class, m.cost_mask, m.cost_dice, m.cost_noise_robust, m.num_points)
+    wd = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 2.0, "loss_noise_robust": 0.0}
+    wd.update({f"{k}_{i}": v for i in range(12) for k, v in list(wd.items())})
+    crit = SetCriterion(3, matcher, wd, 0.1, ["labels", "masks"], -1, 3.0, 0.75, -1)
+    losses = crit(out, target, "segment_mask")
+    sum(v * wd[k] for k, v in losses.items() if k in wd).backward()
+    dt = time.perf_counter() - t0
+    nv = coords4.shape[0]
+    return {
+        "value": (nv / VOXELS) / dt, "unit": "scenes/s (150k-voxel-scene equivalents)",
+        "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle Mask3D self-train step (voxelise+maps+Res16UNet34C+decoder+Hungarian+losses, fwd+bwd, "
+                  f"no optimizer) on one {nv}-voxel synthetic scene, {dt:.1f} s, scaled by voxels/150000",
+    }
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -123,24 +224,27 @@ def main():
     from unscene3d_amd.ddp import flatten_grads
     from unscene3d_amd.synthetic import make_scene
 
-    model = build_model(dev)
-    params = [p for n, p in model.named_parameters() if not n.startswith("final.")]  # unused in forward
-    flat = flatten_grads(params)
-    opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
-
-    sc = make_scene(2000 + rank, target_voxels=args.voxels)
-    xyz = torch.from_numpy(sc["xyz"]).to(dev)
-    colors = torch.from_numpy(sc["colors"]).to(dev)
+    if args.mode == "backbone":
+        model = build_model(dev)
+        params = [p for n, p in model.named_parameters() if not n.startswith("final.")]  # unused in forward
+        flat = flatten_grads(params)
+        opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
+        sc = make_scene(2000 + rank, target_voxels=args.voxels)
+        xyz = torch.from_numpy(sc["xyz"]).to(dev)
+        colors = torch.from_numpy(sc["colors"]).to(dev)
+        step = lambda w: train_step(model, opt, xyz, colors, flat, w)
+    else:
+        step = make_mask3d_step(args, dev, rank, world)
 
     for _ in range(args.warmup):
-        loss, nvox = train_step(model, opt, xyz, colors, flat, world)
+        loss, nvox = step(world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, nvox = train_step(model, opt, xyz, colors, flat, world)
+        loss, nvox = step(world)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -156,7 +260,7 @@ def main():
     roof = None
     if rank == 0:
         with profiler.capture() as prof:
-            train_step(model, opt, xyz, colors, flat, 1)
+            step(1)
             torch.cuda.synchronize()
         roof = prof.roofline(MFMA_F32_PEAK_TFLOPS)
 
@@ -166,13 +270,11 @@ def main():
             "value": world * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: Res16UNet34C backbone fwd+bwd+AdamW, one synthetic "
-                                   f"ScanNet-shaped scene per GPU, {nvox} voxels @2cm (voxelise + coordinate/kernel "
-                                   "maps rebuilt every step), random-init weights",
+            "config": {"workload": WORKLOADS[args.mode].format(nvox=nvox),
                        "voxels_per_scene": int(nvox), "global_batch": world, "parallelism": f"dp{world}",
                        "loss": float(loss)},
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),
         }
         print(json.dumps(line))
     if world > 1:

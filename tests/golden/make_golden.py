@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""Golden-vector generator — runs ONLY in the build container, where /root/reference exists.
+
+Imports the importable parts of the reference in place (stub modules for the dependencies that are
+not installed: SURVEY.md Appendix A), feeds them seeded inputs and stores inputs + outputs as small
+.npz fixtures next to this script.  Nothing from /root/reference is copied; the fixtures are data.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+"""
+import importlib
+import os
+import sys
+import types
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+class _Stub(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        return MagicMock()
+
+
+def stub(*names):
+    for n in names:
+        try:
+            __import__(n)
+        except Exception:
+            sys.modules[n] = _Stub(n)
+
+
+def import_reference_models():
+    stub("MinkowskiEngine", "MinkowskiEngine.MinkowskiOps", "MinkowskiEngine.MinkowskiPooling", "custom_cuda_utils",
+         "detectron2", "detectron2.utils", "detectron2.utils.comm", "detectron2.projects",
+         "detectron2.projects.point_rend", "detectron2.projects.point_rend.point_features", "hydra", "torch_scatter",
+         "pointnet2", "pointnet2._ext", "torchvision")
+
+    class MinkowskiNetwork(nn.Module):
+        def __init__(self, D):
+            super().__init__()
+            self.D = D
+
+    sys.modules["MinkowskiEngine"].MinkowskiNetwork = MinkowskiNetwork
+    sys.modules["detectron2.utils.comm"].get_world_size = lambda: 1
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    mods = {n: importlib.import_module(f"models.{n}") for n in ("matcher", "criterion", "position_embedding", "mask3d")}
+    mods["helpers"] = importlib.import_module("models.modules.helpers_3detr")
+    return mods
+
+
+def t2n(d):
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
+def make_criterion(mods):
+    g = torch.Generator().manual_seed(11)
+    B, Q, C = 2, 100, 3
+    S = [310, 270]
+    T = [7, 9]
+    n_aux = 2
+    logits = [torch.randn(B, Q, C, generator=g) for _ in range(n_aux + 1)]
+    masks = [[torch.randn(S[b], Q, generator=g) * 2 for b in range(B)] for _ in range(n_aux + 1)]
+    targets = []
+    for b in range(B):
+        seg = torch.rand(T[b], S[b], generator=g) < 0.15
+        seg[:, :3] = True
+        targets.append({"labels": torch.ones(T[b], dtype=torch.int64), "segment_mask": seg})
+    for l in logits:
+        l.requires_grad_()
+    for lv in masks:
+        for m in lv:
+            m.requires_grad_()
+    matcher = mods["matcher"].HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=2.0, cost_noise_robust=0.0,
+                                               num_points=-1)
+    wd = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 2.0, "loss_noise_robust": 0.0}
+    wd.update({f"{k}_{i}": v for i in range(n_aux) for k, v in list(wd.items())})
+    crit = mods["criterion"].SetCriterion(num_classes=3, matcher=matcher, weight_dict=wd, eos_coef=0.1,
+                                          losses=["labels", "masks"], num_points=-1, oversample_ratio=3.0,
+                                          importance_sample_ratio=0.75, class_weights=-1)
+    outputs = {"pred_logits": logits[-1], "pred_masks": masks[-1],
+               "aux_outputs": [{"pred_logits": logits[i], "pred_masks": masks[i]} for i in range(n_aux)]}
+    losses = crit(outputs, targets, mask_type="segment_mask")
+    total = sum(losses[k] * wd[k] for k in losses if k in wd)
+    total.backward()
+    idx_final = matcher(outputs, targets, "segment_mask")
+    out = {"n_aux": np.int64(n_aux), "total": total.detach().numpy()}
+    for i in range(n_aux + 1):
+        out[f"logits_{i}"] = logits[i].detach().numpy()
+        out[f"logits_grad_{i}"] = logits[i].grad.numpy()
+        for b in range(B):
+            out[f"masks_{i}_{b}"] = masks[i][b].detach().numpy()
+            out[f"masks_grad_{i}_{b}"] = masks[i][b].grad.numpy()
+    for b in range(B):
+        out[f"tgt_mask_{b}"] = np.packbits(targets[b]["segment_mask"].numpy(), axis=1)
+        out[f"tgt_shape_{b}"] = np.array(targets[b]["segment_mask"].shape)
+        out[f"match_q_{b}"], out[f"match_t_{b}"] = idx_final[b][0].numpy(), idx_final[b][1].numpy()
+    for k, v in losses.items():
+        out["loss/" + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "criterion.npz"), **out)
+    print("criterion: total", float(total), "keys", len(losses))
+
+
+def make_posenc(mods):
+    torch.manual_seed(5)
+    pe = mods["position_embedding"].PositionEmbeddingCoordsSine(pos_type="fourier", d_pos=128, gauss_scale=1.0,
+                                                                 normalize=True)
+    g = torch.Generator().manual_seed(6)
+    xyz = torch.rand(2, 300, 3, generator=g) * torch.tensor([6.0, 4.0, 2.8]) - 1.0
+    mins, maxs = xyz.min(1)[0], xyz.max(1)[0]
+    out = pe(xyz.clone(), input_range=[mins, maxs])
+    np.savez_compressed(os.path.join(HERE, "posenc.npz"), gauss_B=pe.gauss_B.numpy(), xyz=xyz.numpy(),
+                        mins=mins.numpy(), maxs=maxs.numpy(), out=out.numpy())
+    print("posenc", tuple(out.shape))
+
+
+def make_decoder_layers(mods):
+    m3 = mods["mask3d"]
+    torch.manual_seed(9)
+    g = torch.Generator().manual_seed(10)
+    d, H, Q, K, B = 128, 8, 40, 48, 2
+    ca, sa, ffn = m3.CrossAttentionLayer(d, H), m3.SelfAttentionLayer(d, H), m3.FFNLayer(d, 256)
+    mlp = mods["helpers"].GenericMLP(input_dim=d, hidden_dims=[d], output_dim=d, use_conv=True,
+                                     output_use_activation=True, hidden_use_bias=True)
+    tgt = torch.randn(Q, B, d, generator=g)
+    mem = torch.randn(K, B, d, generator=g)
+    pos = torch.randn(K, B, d, generator=g)
+    qpos = torch.randn(Q, B, d, generator=g)
+    mask = torch.rand(B * H, Q, K, generator=g) < 0.3
+    mask[:, :, 0] = False
+    o1 = ca(tgt, mem, memory_mask=mask, memory_key_padding_mask=None, pos=pos, query_pos=qpos)
+    o2 = sa(o1, tgt_mask=None, tgt_key_padding_mask=None, query_pos=qpos)
+    o3 = ffn(o2)
+    qp = torch.randn(B, d, Q, generator=g)
+    o4 = mlp(qp)
+    out = {"tgt": tgt, "mem": mem, "pos": pos, "qpos": qpos, "o1": o1, "o2": o2, "o3": o3, "qp": qp, "o4": o4}
+    out = t2n(out)
+    out["mask"] = np.packbits(mask.numpy(), axis=2)
+    for name, mod in (("ca", ca), ("sa", sa), ("ffn", ffn), ("mlp", mlp)):
+        for k, v in mod.state_dict().items():
+            out[f"{name}/{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "decoder_layers.npz"), **out)
+    print("decoder layers ok")
+
+
+if __name__ == "__main__":
+    cwd = os.getcwd()
+    mods = import_reference_models()
+    make_criterion(mods)
+    make_posenc(mods)
+    make_decoder_layers(mods)
+    os.chdir(cwd)

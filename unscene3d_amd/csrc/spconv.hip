@@ -539,7 +539,7 @@ struct WgradParams {
 // ALIGNED: cin % 32 == 0 and cout % (32*NB) == 0 -> unconditional vector loads; the lane's NB
 // columns are contiguous (column of accumulator nb, MFMA column j = co0 + NB*j + nb).
 template <int NB, bool ALIGNED>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   extern __shared__ float red[];  // [3 waves][NB*16 regs][64 lanes]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -572,21 +572,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
   const bool ci_ok = ci0 + i < cin;
   const int acol = ci0 + i;
   const int bcol = ALIGNED ? co0 + NB * i : co0 + i;
-  for (int64_t q = cb; q < ce; q += 16) {
-    // 16 pairs per iteration: lanes 0-15 fetch a-row ids, 16-31 b-row ids
+  // 16 pairs per batch: lanes 0-15 fetch a-row ids, 16-31 b-row ids
+  auto load_idx = [&](int64_t q) -> int64_t {
     int64_t idxreg = -1;
-    {
-      const int l16 = lane & 15;
-      const int64_t pp = q + l16;
-      if (lane < 32 && pp < ce) {
-        if (p.a_idx)
-          idxreg = (lane < 16) ? p.a_idx[pp] : p.b_idx[pp];
-        else
-          idxreg = pp;
-      }
+    const int l16 = lane & 15;
+    const int64_t pp = q + l16;
+    if (lane < 32 && pp < ce) {
+      if (p.a_idx)
+        idxreg = (lane < 16) ? p.a_idx[pp] : p.b_idx[pp];
+      else
+        idxreg = pp;
     }
-    float av[8];
-    float bv[8][NB];
+    return idxreg;
+  };
+  auto load_rows = [&](int64_t idxreg, float (&av)[8], float (&bv)[8][NB]) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int64_t ia = __shfl(idxreg, 2 * u + h, 64);
@@ -603,10 +602,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradParams p) {
           bv[u][nb] = (ib >= 0 && bcol + nb * 32 < cout) ? p.b[ib * cout + bcol + nb * 32] : 0.f;
       }
     }
+  };
+  auto run = [&](float (&av)[8], float (&bv)[8][NB]) {
 #pragma unroll
     for (int u = 0; u < 8; ++u)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA32(av[u], bv[u][nb], acc[nb]);
+  };
+  if (ALIGNED) {
+    // software pipeline: row ids two batches ahead, gathered rows one batch ahead of the MFMAs
+    float aX[8], aY[8];
+    float bX[8][NB], bY[8][NB];
+    int64_t id1 = load_idx(cb), id2 = load_idx(cb + 16);
+    load_rows(id1, aX, bX);
+    for (int64_t q = cb; q < ce; q += 32) {
+      int64_t id3 = load_idx(q + 32);
+      load_rows(id2, aY, bY);
+      run(aX, bX);
+      id2 = load_idx(q + 48);
+      load_rows(id3, aX, bX);
+      if (q + 16 < ce) run(aY, bY);
+    }
+  } else {
+    float av[8];
+    float bv[8][NB];
+    for (int64_t q = cb; q < ce; q += 16) {
+      load_rows(load_idx(q), av, bv);
+      run(av, bv);
+    }
   }
 
   // ordered cross-wave reduction in LDS: wave 0 adds waves 1,2,3 in order

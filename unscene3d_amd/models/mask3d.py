@@ -1,0 +1,348 @@
+"""Mask3D (reference models/mask3d.py:16-664) on the MI355X operator façade.
+
+Same constructor signature, sub-module names (=> state_dict keys) and output dictionary as the
+reference.  Backbone, 1x1 mask head, segment means, FPS, Fourier encodings, attention-mask
+pooling and row gathers run on the hand-written HIP kernels; the 100-query transformer decoder
+(nn.MultiheadAttention / Linear / LayerNorm: ~1 GFLOP per pass) stays on PyTorch-ROCm's stock
+kernels, as planned in SURVEY.md §7.6.
+
+Randomness: the reference sub-samples cross-attention keys with `torch.randperm` (mask3d.py:325);
+`self.randperm` can be replaced to inject fixed indices (parity tests do that).
+"""
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from .. import MinkowskiEngine as ME
+from .. import ops
+from ..MinkowskiEngine import MinkowskiOps as me
+from ..MinkowskiEngine.MinkowskiPooling import MinkowskiAvgPooling
+from ..pointnet2_utils import furthest_point_sample
+from .modules.common import conv
+from .modules.helpers_3detr import GenericMLP
+from .position_embedding import PositionEmbeddingCoordsSine
+
+SINGLE_POINT_ERROR = "only a single point gives nans in cross-attention"   # trainer.py:125 string-matches this
+
+
+class Mask3D(nn.Module):
+    def __init__(self, config, hidden_dim, num_queries, num_heads, dim_feedforward, sample_sizes, shared_decoder,
+                 num_classes, num_decoders, dropout, pre_norm, positional_encoding_type, non_parametric_queries,
+                 train_on_segments, normalize_pos_enc, use_level_embed, scatter_type, hlevels, use_np_features,
+                 voxel_size, max_sample_size, random_queries, gauss_scale, random_query_both, random_normal):
+        super().__init__()
+        self.random_normal, self.random_query_both, self.random_queries = random_normal, random_query_both, random_queries
+        self.max_sample_size, self.gauss_scale, self.voxel_size = max_sample_size, gauss_scale, voxel_size
+        self.scatter_type, self.hlevels, self.use_level_embed = scatter_type, list(hlevels), use_level_embed
+        self.train_on_segments, self.normalize_pos_enc = train_on_segments, normalize_pos_enc
+        self.num_decoders, self.num_classes, self.dropout, self.pre_norm = num_decoders, num_classes, dropout, pre_norm
+        self.shared_decoder, self.sample_sizes = shared_decoder, list(sample_sizes)
+        self.non_parametric_queries, self.use_np_features = non_parametric_queries, use_np_features
+        self.mask_dim, self.num_heads, self.num_queries = hidden_dim, num_heads, num_queries
+        self.pos_enc_type = positional_encoding_type
+
+        self.backbone = config.backbone if hasattr(config, "backbone") else config["backbone"]
+        self.num_levels = len(self.hlevels)
+        sizes = self.backbone.PLANES[-5:]
+
+        self.mask_features_head = conv(self.backbone.PLANES[7], self.mask_dim, kernel_size=1, stride=1, bias=True, D=3)
+        if scatter_type != "mean":
+            raise NotImplementedError("scatter_type 'max' is not used by the shipped configs (conf/model/mask3d.yaml:31)")
+        assert (not use_np_features) or non_parametric_queries, "np features only with np queries"
+
+        if non_parametric_queries:
+            self.query_projection = GenericMLP(input_dim=self.mask_dim, hidden_dims=[self.mask_dim],
+                                               output_dim=self.mask_dim, use_conv=True, output_use_activation=True,
+                                               hidden_use_bias=True)
+            if use_np_features:
+                self.np_feature_projection = nn.Sequential(nn.Linear(sizes[-1], hidden_dim), nn.ReLU(),
+                                                           nn.Linear(hidden_dim, hidden_dim))
+        elif random_query_both:
+            self.query_projection = GenericMLP(input_dim=2 * self.mask_dim, hidden_dims=[2 * self.mask_dim],
+                                               output_dim=2 * self.mask_dim, use_conv=True,
+                                               output_use_activation=True, hidden_use_bias=True)
+        else:
+            self.query_feat = nn.Embedding(num_queries, hidden_dim)
+            self.query_pos = nn.Embedding(num_queries, hidden_dim)
+        if use_level_embed:
+            self.level_embed = nn.Embedding(self.num_levels, hidden_dim)
+
+        self.mask_embed_head = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.ReLU(),
+                                             nn.Linear(hidden_dim, hidden_dim))
+        self.class_embed_head = nn.Linear(hidden_dim, self.num_classes)
+
+        if positional_encoding_type not in ("fourier", "sine"):
+            raise NotImplementedError("positional_encoding_type 'legacy' is not used by the shipped configs")
+        self.pos_enc = PositionEmbeddingCoordsSine(pos_type=positional_encoding_type, d_pos=self.mask_dim,
+                                                   gauss_scale=gauss_scale, normalize=normalize_pos_enc)
+        self.pooling = MinkowskiAvgPooling(kernel_size=2, stride=2, dimension=3)
+
+        self.masked_transformer_decoder = nn.ModuleList()
+        self.cross_attention, self.self_attention = nn.ModuleList(), nn.ModuleList()
+        self.ffn_attention, self.lin_squeeze = nn.ModuleList(), nn.ModuleList()
+        for _ in range(1 if shared_decoder else num_decoders):
+            ca, sa, ffn, sq = nn.ModuleList(), nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+            for hlevel in self.hlevels:
+                ca.append(CrossAttentionLayer(d_model=self.mask_dim, nhead=num_heads, dropout=dropout,
+                                              normalize_before=pre_norm))
+                sq.append(nn.Linear(sizes[hlevel], self.mask_dim))
+                sa.append(SelfAttentionLayer(d_model=self.mask_dim, nhead=num_heads, dropout=dropout,
+                                             normalize_before=pre_norm))
+                ffn.append(FFNLayer(d_model=self.mask_dim, dim_feedforward=dim_feedforward, dropout=dropout,
+                                    normalize_before=pre_norm))
+            self.cross_attention.append(ca)
+            self.self_attention.append(sa)
+            self.ffn_attention.append(ffn)
+            self.lin_squeeze.append(sq)
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.randperm = lambda n, device: torch.randperm(n, device=device)
+
+    # ------------------------------------------------------------------
+    def get_pos_encs(self, coords):
+        """Per level, per scene Fourier encodings [N_l, d] of the pooled raw coordinates
+        (reference :183-198; same [level][0][scene] nesting)."""
+        out = []
+        for level in coords:
+            per_scene = []
+            for xyz in level.decomposed_features:
+                per_scene.append(self.pos_enc.fourier_rows(xyz, xyz.min(dim=0)[0], xyz.max(dim=0)[0])
+                                 if self.pos_enc_type == "fourier" else
+                                 self.pos_enc(xyz[None].float(), input_range=[xyz.min(0)[0][None], xyz.max(0)[0][None]])
+                                 .squeeze(0).permute(1, 0))
+            out.append([per_scene])
+        return out
+
+    def forward(self, x, point2segment=None, raw_coordinates=None, is_eval=False):
+        pcd_features, aux = self.backbone(x)
+        n_scenes = len(x.decomposed_coordinates)
+
+        with torch.no_grad():
+            coordinates = me.SparseTensor(features=raw_coordinates.float().contiguous(),
+                                          coordinate_manager=aux[-1].coordinate_manager,
+                                          coordinate_map_key=aux[-1].coordinate_map_key)
+            coords = [coordinates]
+            for _ in range(len(aux) - 1):
+                coords.append(self.pooling(coords[-1]))
+            coords.reverse()
+            pos_encodings_pcd = self.get_pos_encs(coords)
+
+        mask_features = self.mask_features_head(pcd_features)
+        mask_segments, seg_csr = None, None
+        if self.train_on_segments:
+            seg_csr = [ops.segment_csr(p2s.to(torch.int64).contiguous(), int(p2s.max().item()) + 1)
+                       for p2s in point2segment]
+            mask_segments = [ops.segment_mean(f, csr) for f, csr in zip(mask_features.decomposed_features, seg_csr)]
+
+        sampled_coords = None
+        if self.non_parametric_queries:
+            dec_coords = x.decomposed_coordinates
+            fps_idx = [furthest_point_sample(dec_coords[i][None].float().contiguous(), self.num_queries)
+                       .squeeze(0).long() for i in range(n_scenes)]
+            raw_per_scene = coordinates.decomposed_features
+            sampled_coords = torch.stack([raw_per_scene[i][fps_idx[i]] for i in range(n_scenes)])
+            mins = torch.stack([r.min(dim=0)[0] for r in raw_per_scene])
+            maxs = torch.stack([r.max(dim=0)[0] for r in raw_per_scene])
+            query_pos = self.pos_enc(sampled_coords.float(), input_range=[mins, maxs])      # B, d, Q
+            query_pos = self.query_projection(query_pos)
+            if self.use_np_features:
+                queries = torch.stack([pcd_features.decomposed_features[i][fps_idx[i]] for i in range(n_scenes)])
+                queries = self.np_feature_projection(queries)
+            else:
+                queries = torch.zeros_like(query_pos).permute(0, 2, 1)
+            query_pos = query_pos.permute(2, 0, 1)
+        elif self.random_queries:
+            query_pos = torch.rand(n_scenes, self.mask_dim, self.num_queries, device=x.device) - 0.5
+            queries = torch.zeros_like(query_pos).permute(0, 2, 1)
+            query_pos = query_pos.permute(2, 0, 1)
+        elif self.random_query_both:
+            shape = (n_scenes, 2 * self.mask_dim, self.num_queries)
+            qpf = torch.randn(*shape, device=x.device) if self.random_normal else torch.rand(*shape, device=x.device) - 0.5
+            queries = qpf[:, :self.mask_dim, :].permute(0, 2, 1)
+            query_pos = qpf[:, self.mask_dim:, :].permute(2, 0, 1)
+        else:
+            queries = self.query_feat.weight.unsqueeze(0).repeat(n_scenes, 1, 1)
+            query_pos = self.query_pos.weight.unsqueeze(1).repeat(1, n_scenes, 1)
+
+        predictions_class, predictions_mask = [], []
+        p2s_arg = point2segment if self.train_on_segments else None
+        for decoder_counter in range(self.num_decoders):
+            dec = 0 if self.shared_decoder else decoder_counter
+            for i, hlevel in enumerate(self.hlevels):
+                output_class, outputs_mask, attn_mask = self.mask_module(
+                    queries, mask_features, mask_segments, len(aux) - hlevel - 1, ret_attn_mask=True,
+                    point2segment=p2s_arg, coords=coords)
+
+                decomposed_aux = aux[hlevel].decomposed_features
+                decomposed_attn = attn_mask.decomposed_features
+                sizes = [f.shape[0] for f in decomposed_aux]
+                if min(sizes) == 1:
+                    raise RuntimeError(SINGLE_POINT_ERROR)
+                curr_sample_size = max(sizes)
+                if not (self.max_sample_size or is_eval):
+                    curr_sample_size = min(curr_sample_size, self.sample_sizes[hlevel])
+
+                rand_idx, mask_idx = [], []
+                for k, pcd_size in enumerate(sizes):
+                    if pcd_size <= curr_sample_size:      # take everything, pad with row 0 and mask the padding
+                        idx = torch.zeros(curr_sample_size, dtype=torch.long, device=queries.device)
+                        midx = torch.ones(curr_sample_size, dtype=torch.bool, device=queries.device)
+                        idx[:pcd_size] = torch.arange(pcd_size, device=queries.device)
+                        midx[:pcd_size] = False
+                    else:                                  # random subset, nothing masked
+                        idx = self.randperm(pcd_size, queries.device)[:curr_sample_size]
+                        midx = torch.zeros(curr_sample_size, dtype=torch.bool, device=queries.device)
+                    rand_idx.append(idx)
+                    mask_idx.append(midx)
+
+                batched_aux = torch.stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k])
+                                           for k in range(n_scenes)])
+                batched_attn = torch.stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
+                batched_pos_enc = torch.stack([pos_encodings_pcd[hlevel][0][k][rand_idx[k], :] for k in range(n_scenes)])
+
+                # a query whose sampled keys are all masked attends to everything (reference :346)
+                batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
+                batched_attn = torch.logical_or(batched_attn, torch.stack(mask_idx)[..., None])
+
+                src_pcd = self.lin_squeeze[dec][i](batched_aux.permute(1, 0, 2))
+                if self.use_level_embed:
+                    src_pcd = src_pcd + self.level_embed.weight[i]
+
+                output = self.cross_attention[dec][i](
+                    queries.permute(1, 0, 2), src_pcd,
+                    memory_mask=batched_attn.repeat_interleave(self.num_heads, dim=0).permute(0, 2, 1),
+                    memory_key_padding_mask=None, pos=batched_pos_enc.permute(1, 0, 2), query_pos=query_pos)
+                output = self.self_attention[dec][i](output, tgt_mask=None, tgt_key_padding_mask=None,
+                                                     query_pos=query_pos)
+                queries = self.ffn_attention[dec][i](output).permute(1, 0, 2)
+
+                predictions_class.append(output_class)
+                predictions_mask.append(outputs_mask)
+
+        output_class, outputs_mask = self.mask_module(queries, mask_features, mask_segments, 0, ret_attn_mask=False,
+                                                      point2segment=p2s_arg, coords=coords)
+        predictions_class.append(output_class)
+        predictions_mask.append(outputs_mask)
+
+        return {
+            "pred_logits": predictions_class[-1],
+            "pred_masks": predictions_mask[-1],
+            "aux_outputs": self._set_aux_loss(predictions_class, predictions_mask),
+            "sampled_coords": sampled_coords.detach().cpu().numpy() if sampled_coords is not None else None,
+            "backbone_features": pcd_features,
+        }
+
+    def mask_module(self, query_feat, mask_features, mask_segments, num_pooling_steps, ret_attn_mask=True,
+                    point2segment=None, coords=None):
+        query_feat = self.decoder_norm(query_feat)
+        mask_embed = self.mask_embed_head(query_feat)
+        outputs_class = self.class_embed_head(query_feat)
+
+        output_masks, output_segments = [], []
+        if point2segment is not None:
+            for i, seg_feat in enumerate(mask_segments):
+                output_segments.append(seg_feat @ mask_embed[i].T)
+                if ret_attn_mask:   # per-voxel logits only feed the (detached) attention masks
+                    with torch.no_grad():
+                        output_masks.append(ops.gather_rows(output_segments[-1].detach().contiguous(),
+                                                            point2segment[i].to(torch.int64).contiguous()))
+        else:
+            per_scene = mask_features.decomposed_features
+            for i in range(len(per_scene)):
+                output_masks.append(per_scene[i] @ mask_embed[i].T)
+
+        if ret_attn_mask:
+            attn_mask = me.SparseTensor(features=torch.cat(output_masks).detach(),
+                                        coordinate_manager=mask_features.coordinate_manager,
+                                        coordinate_map_key=mask_features.coordinate_map_key)
+            for _ in range(num_pooling_steps):
+                attn_mask = self.pooling(attn_mask.float())
+            attn_mask = me.SparseTensor(features=(attn_mask.F.detach().sigmoid() < 0.5),
+                                        coordinate_manager=attn_mask.coordinate_manager,
+                                        coordinate_map_key=attn_mask.coordinate_map_key)
+            if point2segment is not None:
+                return outputs_class, output_segments, attn_mask
+            return outputs_class, output_masks, attn_mask
+        if point2segment is not None:
+            return outputs_class, output_segments
+        return outputs_class, output_masks
+
+    @torch.jit.unused
+    def _set_aux_loss(self, outputs_class, outputs_seg_masks):
+        return [{"pred_logits": a, "pred_masks": b} for a, b in zip(outputs_class[:-1], outputs_seg_masks[:-1])]
+
+
+def _with_pos(t, pos):
+    return t if pos is None else t + pos
+
+
+def _xavier(module):
+    for p in module.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+class SelfAttentionLayer(nn.Module):
+    """Post-norm (default) / pre-norm self attention block (reference :491-545)."""
+
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.activation = _get_activation_fn(activation)
+        self.normalize_before = normalize_before
+        _xavier(self)
+
+    def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
+        src = self.norm(tgt) if self.normalize_before else tgt
+        q = k = _with_pos(src, query_pos)
+        upd = self.self_attn(q, k, value=src, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+        out = tgt + self.dropout(upd)
+        return out if self.normalize_before else self.norm(out)
+
+
+class CrossAttentionLayer(nn.Module):
+    """Masked cross attention block (reference :547-605)."""
+
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.activation = _get_activation_fn(activation)
+        self.normalize_before = normalize_before
+        _xavier(self)
+
+    def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None):
+        src = self.norm(tgt) if self.normalize_before else tgt
+        upd = self.multihead_attn(query=_with_pos(src, query_pos), key=_with_pos(memory, pos), value=memory,
+                                  attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)[0]
+        out = tgt + self.dropout(upd)
+        return out if self.normalize_before else self.norm(out)
+
+
+class FFNLayer(nn.Module):
+    """Feed-forward block (reference :607-651)."""
+
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        self.activation = _get_activation_fn(activation)
+        self.normalize_before = normalize_before
+        _xavier(self)
+
+    def forward(self, tgt):
+        src = self.norm(tgt) if self.normalize_before else tgt
+        upd = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        out = tgt + self.dropout(upd)
+        return out if self.normalize_before else self.norm(out)
+
+
+def _get_activation_fn(activation):
+    try:
+        return {"relu": F.relu, "gelu": F.gelu, "glu": F.glu}[activation]
+    except KeyError:
+        raise RuntimeError(f"activation should be relu/gelu, not {activation}.")

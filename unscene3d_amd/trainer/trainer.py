@@ -1,0 +1,77 @@
+"""Training step of the self-training loop (reference trainer/trainer.py:44-163, :953-966).
+
+`InstanceSegmentation` mirrors the LightningModule's constructor logic (model + matcher + criterion
+with the 13-level weight_dict), `training_step` and `configure_optimizers`, without depending on
+PyTorch-Lightning / hydra (neither is part of the accelerated path).  Differences: losses are summed
+on the device and synchronised once per step (the reference does 52 `.cpu().item()` calls, :149)."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import MinkowskiEngine as ME
+from ..config import instantiate_model
+from ..models.criterion import SetCriterion
+from ..models.mask3d import SINGLE_POINT_ERROR
+from ..models.matcher import HungarianMatcher
+
+
+class InstanceSegmentation(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.mask_type = "segment_mask" if config.model.train_on_segments else "masks"
+        self.model = instantiate_model(config)
+        m = config.matcher
+        matcher = HungarianMatcher(cost_class=m.cost_class, cost_mask=m.cost_mask, cost_dice=m.cost_dice,
+                                   cost_noise_robust=m.cost_noise_robust, num_points=m.num_points)
+        weight_dict = {"loss_ce": matcher.cost_class, "loss_mask": matcher.cost_mask, "loss_dice": matcher.cost_dice,
+                       "loss_noise_robust": matcher.cost_noise_robust}
+        aux = {}
+        for i in range(self.model.num_levels * self.model.num_decoders):
+            ignored = i in config.general.ignore_mask_idx
+            aux.update({f"{k}_{i}": (0.0 if ignored else v) for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+        l = config.loss
+        self.criterion = SetCriterion(num_classes=l.num_classes, matcher=matcher, weight_dict=weight_dict,
+                                      eos_coef=l.eos_coef, losses=l.losses, num_points=l.num_points,
+                                      oversample_ratio=l.oversample_ratio,
+                                      importance_sample_ratio=l.importance_sample_ratio,
+                                      class_weights=l.class_weights, directions=l.directions,
+                                      use_droploss=l.use_droploss, droploss_iou_thresh=l.droploss_iou_thresh)
+
+    def forward(self, x, point2segment=None, raw_coordinates=None, is_eval=False):
+        return self.model(x, point2segment, raw_coordinates=raw_coordinates, is_eval=is_eval)
+
+    def training_step(self, batch, batch_idx=0):
+        """-> (total weighted loss tensor, dict of weighted loss tensors) or None when the step is skipped."""
+        data, target, file_names = batch
+        if data.features.shape[0] > self.config.general.max_batch_size:
+            raise RuntimeError("BATCH TOO BIG")
+        if len(target) == 0:
+            return None
+        feats, raw_coordinates = data.features, None
+        if self.config.data.add_raw_coordinates:
+            raw_coordinates = feats[:, -3:].contiguous()
+            feats = feats[:, :-3].contiguous()
+        dev = next(self.parameters()).device
+        x = ME.SparseTensor(coordinates=data.coordinates, features=feats, device=dev)
+        try:
+            output = self.forward(x, point2segment=[t["point2segment"] for t in target],
+                                  raw_coordinates=raw_coordinates)
+        except RuntimeError as err:
+            if err.args and err.args[0] == SINGLE_POINT_ERROR:
+                return None
+            raise
+        losses = self.criterion(output, target, mask_type=self.mask_type, coords=x.C)
+        wd = self.criterion.weight_dict
+        weighted = {k: v * wd[k] for k, v in losses.items() if k in wd}
+        return sum(weighted.values()), weighted
+
+    def configure_optimizers(self, steps_per_epoch: int, epochs: int = None):
+        o = self.config.optimizer
+        optimizer = torch.optim.AdamW(self.parameters(), lr=o.lr)
+        scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=o.lr,
+                                                        epochs=epochs or self.config.trainer.max_epochs,
+                                                        steps_per_epoch=steps_per_epoch)
+        return optimizer, scheduler
