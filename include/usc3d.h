@@ -249,6 +249,11 @@ int usc_avgpool_down2(const float* in, int32_t c, const int32_t* nbr2,
 int usc_gather_rows(const float* src, int32_t c, const int64_t* idx, int64_t n,
                     float* out, usc_stream_t s);
 
+/* dst[idx[i],:] += src[i,:]  (dst caller-zeroed) — backward of usc_gather_rows for sampled
+ * index sets (float atomics; exact and order-independent when idx has no duplicates). */
+int usc_scatter_add_rows(const float* src, int32_t c, const int64_t* idx,
+                         int64_t n, float* dst, usc_stream_t s);
+
 /* ------------------------------------------------------------------------
  * Q3  segment mean — replaces torch_scatter.scatter_mean(src, index, dim=0)
  * (models/mask3d.py:12,223; trainer/trainer.py:449) forward + backward.

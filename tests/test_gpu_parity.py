@@ -423,7 +423,7 @@ def test_config3_full_mask3d_step_loss_parity(device):
     from unscene3d_amd.trainer.trainer import InstanceSegmentation
 
     cfg = apply_overrides(default_config(), ["general.num_targets=3", "model.sample_sizes=[50,100,200,400,800]"])
-    ds = SyntheticFreeMaskDataset(n_scenes=2, target_voxels=3000, seed=3100)
+    ds = SyntheticFreeMaskDataset(n_scenes=2, target_voxels=12000, seed=3100)
     batch = [ds[0], ds[1]]
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device))
     data, target, names = collate(batch)

@@ -78,6 +78,94 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------
+// Multi-workgroup FPS.  The reference kernel is one block per scene that re-reads all n points
+// from memory for each of the m samples.  On MI355X the point set is spread over G workgroups
+// (G <= 240, all co-resident) that keep their points AND their running min-distances in registers;
+// each iteration every workgroup publishes its best candidate with one 64-bit atomicMax and the
+// workgroups meet at a monotonic arrival counter.  The candidate is packed so that integer max ==
+// the reference ordering (distance, then smallest k mod BS, then smallest k); 0 = "no candidate".
+//   hand-off protocol (cdna_hip_programming.md G16): relaxed agent-scope atomicMax on best[j] ->
+//   release agent-scope add on the counter; consumers poll relaxed, then acquire, then read best[j]
+//   with an agent-scope atomic load.  best[]/counter live in caller scratch zeroed before launch.
+constexpr int kFpsMaxSlots = 12;       // points per thread held in registers
+constexpr int kFpsGroupThreads = 256;
+
+__device__ inline unsigned long long fps_pack(float d, int k, int bs_mask) {
+  const unsigned int tie = ((unsigned int)(k & bs_mask) << 22) | (unsigned int)k;   // k < 2^22
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0x7fffffffu - tie);
+}
+
+__global__ __launch_bounds__(kFpsGroupThreads) void fps_multi_kernel(const float* __restrict__ xyz, int n, int m,
+                                                                    int bs_mask, int G,
+                                                                    unsigned long long* __restrict__ scratch,
+                                                                    int32_t* __restrict__ idx) {
+  __shared__ unsigned long long s_best[kFpsGroupThreads / 64];
+  __shared__ int s_old;
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  xyz += (int64_t)b * n * 3;
+  idx += (int64_t)b * m;
+  unsigned long long* best = scratch + (int64_t)b * (m + 2);     // best[0..m) | counter
+  unsigned int* counter = reinterpret_cast<unsigned int*>(best + m);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int stride = G * kFpsGroupThreads;
+
+  float px[kFpsMaxSlots], py[kFpsMaxSlots], pz[kFpsMaxSlots], td[kFpsMaxSlots];
+  bool ok[kFpsMaxSlots];
+#pragma unroll
+  for (int q = 0; q < kFpsMaxSlots; ++q) {
+    const int k = g * kFpsGroupThreads + tid + q * stride;
+    const bool in = k < n;
+    px[q] = in ? xyz[k * 3 + 0] : 0.f;
+    py[q] = in ? xyz[k * 3 + 1] : 0.f;
+    pz[q] = in ? xyz[k * 3 + 2] : 0.f;
+    const float mag = (px[q] * px[q]) + (py[q] * py[q]) + (pz[q] * pz[q]);
+    ok[q] = in && !(mag <= 1e-3f);
+    td[q] = 1e10f;
+  }
+  int old = 0;
+  if (g == 0 && tid == 0) idx[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    const float x1 = xyz[old * 3 + 0], y1 = xyz[old * 3 + 1], z1 = xyz[old * 3 + 2];
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int q = 0; q < kFpsMaxSlots; ++q) {
+      if (ok[q]) {
+        const float d = (px[q] - x1) * (px[q] - x1) + (py[q] - y1) * (py[q] - y1) + (pz[q] - z1) * (pz[q] - z1);
+        const float d2 = fminf(d, td[q]);
+        td[q] = d2;
+        const unsigned long long c = fps_pack(d2, g * kFpsGroupThreads + tid + q * stride, bs_mask);
+        v = c > v ? c : v;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(v, o, 64);
+      v = other > v ? other : v;
+    }
+    if (lane == 0) s_best[wave] = v;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long w = s_best[0];
+#pragma unroll
+      for (int q = 1; q < kFpsGroupThreads / 64; ++q) w = s_best[q] > w ? s_best[q] : w;
+      if (w) __hip_atomic_fetch_max(&best[j], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned int target = (unsigned int)G * (unsigned int)j;
+      while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+        __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const unsigned long long win = __hip_atomic_load(&best[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int k = 0;
+      if (win) k = (int)((0x7fffffffu - (unsigned int)(win & 0xffffffffull)) & 0x3fffffu);
+      s_old = k;
+      if (g == 0) idx[j] = k;
+    }
+    __syncthreads();
+    old = s_old;
+  }
+}
+
 __global__ __launch_bounds__(256) void fourier_posenc_kernel(const float* __restrict__ xyz, int64_t n,
                                                             const float* __restrict__ lo,
                                                             const float* __restrict__ hi,
@@ -116,8 +204,21 @@ int usc_furthest_point_sampling(const float* xyz, int32_t b, int32_t n, int32_t 
   // reference block size: opt_n_threads(n) = min(2^floor(log2 n), 512)  (cuda_utils.h:17-21)
   int bs = 1;
   while (bs * 2 <= n && bs < 512) bs *= 2;
-  hipLaunchKernelGGL(fps_kernel, dim3((unsigned)b), dim3(kFpsThreads), 0, as_stream(s), xyz, (int)n, (int)m, bs - 1,
-                     tmp, idx);
+  hipStream_t st = as_stream(s);
+  // workgroups per scene for the register-resident kernel
+  int G = (int)ceil_div(n, (int64_t)kFpsGroupThreads * 10);
+  if (G < 1) G = 1;
+  const bool fits = (int64_t)G * kFpsGroupThreads * kFpsMaxSlots >= n && n < (1 << 22) && (int64_t)b * G <= 240 &&
+                    (int64_t)n * 4 >= (int64_t)(m + 2) * 8 && n >= 4096;
+  if (fits) {
+    // scratch (best[m] + arrival counter per scene, compact at the start of `tmp`) is carved from the
+    // caller's buffer: the register-resident kernel keeps the running distances itself
+    (void)hipMemsetAsync(tmp, 0, (size_t)b * (m + 2) * 8, st);
+    hipLaunchKernelGGL(fps_multi_kernel, dim3((unsigned)(b * G)), dim3(kFpsGroupThreads), 0, st, xyz, (int)n, (int)m,
+                       bs - 1, G, reinterpret_cast<unsigned long long*>(tmp), idx);
+  } else {
+    hipLaunchKernelGGL(fps_kernel, dim3((unsigned)b), dim3(kFpsThreads), 0, st, xyz, (int)n, (int)m, bs - 1, tmp, idx);
+  }
   USC_CHECK_LAUNCH("usc_furthest_point_sampling");
   return USC_OK;
 }

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 
 // ---------------------------------------------------------------------------
 // Stable counting sort of rows by segment id -> CSR (order, seg_off).
-constexpr int kSegTile = 2048;
+constexpr int kSegTile = 1024;
 
 __global__ __launch_bounds__(256) void seg_hist_kernel(const int64_t* __restrict__ seg, int64_t n, int64_t S,
                                                       int32_t* __restrict__ hist /*[T][S]*/) {
@@ -387,39 +387,52 @@ struct SegOffEmit {
   int64_t* seg_off;
   __device__ void operator()(int64_t i, int64_t pos, int) const { seg_off[i] = pos; }
 };
-// one wave per tile walks its rows in order; equal ids inside a 64-row chunk are
-// ranked by lane order, so the placement is stable.
+// One wave per tile walks its rows in order.  Inside a 64-row chunk the rank of a row among the
+// lower lanes holding the same id (and the id's chunk total) comes from a fixed 64-step shuffle
+// sweep — no data-dependent loop — so the placement is stable and its cost independent of how many
+// distinct ids a chunk holds.
 __global__ __launch_bounds__(64) void seg_place_kernel(const int64_t* __restrict__ seg, int64_t n, int64_t S,
                                                       int32_t* __restrict__ base /*[T][S] tile offsets*/,
                                                       const int64_t* __restrict__ seg_off,
                                                       int64_t* __restrict__ order) {
   const int64_t t = blockIdx.x;
   const int lane = threadIdx.x;
-  int32_t* mybase = base + t * S;
+  volatile int32_t* mybase = base + t * S;   // re-read after this wave's own stores
   for (int ch = 0; ch < kSegTile / 64; ++ch) {
     const int64_t i = t * kSegTile + ch * 64 + lane;
     const bool act = i < n;
-    const int64_t sid = act ? seg[i] : -1;
-    unsigned long long todo = __ballot(act);
-    int64_t dst = -1;
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int64_t lsid = __shfl(sid, leader, 64);
-      const unsigned long long m = __ballot(act && sid == lsid);
-      const int cnt = __popcll(m);
-      int old = 0;
-      if (lane == leader) {
-        old = mybase[lsid];
-        mybase[lsid] = old + cnt;
-      }
-      old = __shfl(old, leader, 64);
-      if (act && sid == lsid) {
-        const int rank = __popcll(m & ((1ull << lane) - 1ull));
-        dst = seg_off[lsid] + old + rank;
-      }
-      todo &= ~m;
+    const int sid = act ? (int)seg[i] : -1 - lane;   // inactive lanes get unique negative ids
+    int rank = 0, total = 0;
+#pragma unroll 16
+    for (int j = 0; j < 64; ++j) {
+      const int other = __shfl(sid, j, 64);
+      const int same = other == sid;
+      total += same;
+      rank += same & (j < lane);
     }
-    if (act) order[dst] = i;
+    if (act) {
+      const int old = mybase[sid];                  // all lanes of one id read the same word ...
+      order[seg_off[sid] + old + rank] = i;
+      if (rank == total - 1) mybase[sid] = old + total;   // ... and only its last lane advances it
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// dst[idx[i], :] += src[i, :]   (float atomics; used for the backward of row gathers whose
+// indices are a sampled subset — duplicates only occur on masked padding rows)
+template <int VEC>
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int c,
+                                                              const int64_t* __restrict__ idx, int64_t n,
+                                                              float* __restrict__ dst) {
+  const int CT = c / VEC;
+  const int64_t total = n * CT;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = j / CT;
+    const int cg = (int)(j - r * CT);
+    const int64_t d = idx[r];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) atomicAdd(dst + d * c + cg * VEC + v, src[r * c + cg * VEC + v]);
   }
 }
 
@@ -607,6 +620,20 @@ int usc_gather_rows(const float* src, int32_t c, const int64_t* idx, int64_t n, 
     hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(stream_grid(n * c, 256)), dim3(256), 0, as_stream(s), src, (int)c,
                        idx, n, out);
   USC_CHECK_LAUNCH("usc_gather_rows");
+  return USC_OK;
+}
+
+int usc_scatter_add_rows(const float* src, int32_t c, const int64_t* idx, int64_t n, float* dst, usc_stream_t s) {
+  USC_REQUIRE(c >= 1 && n >= 0, "usc_scatter_add_rows: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(src && idx && dst, "usc_scatter_add_rows: null pointer");
+  if (c % 4 == 0)
+    hipLaunchKernelGGL((scatter_add_rows_kernel<4>), dim3(stream_grid(n * (c / 4), 256)), dim3(256), 0, as_stream(s),
+                       src, (int)c, idx, n, dst);
+  else
+    hipLaunchKernelGGL((scatter_add_rows_kernel<1>), dim3(stream_grid(n * c, 256)), dim3(256), 0, as_stream(s), src,
+                       (int)c, idx, n, dst);
+  USC_CHECK_LAUNCH("usc_scatter_add_rows");
   return USC_OK;
 }
 

@@ -468,9 +468,11 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (idx,) = ctx.saved_tensors
-        # scatter-add of rows: deterministic segment sum over the CSR of idx
-        csr = segment_csr(idx, ctx.n_src)
-        return segment_sum_from_csr(dout.contiguous(), csr), None
+        dout = dout.contiguous()
+        dsrc = torch.zeros((ctx.n_src, dout.shape[1]), dtype=torch.float32, device=dout.device)
+        check(lib.usc_scatter_add_rows(_ptr(dout), dout.shape[1], _ptr(idx), idx.shape[0], _ptr(dsrc), _stream()),
+              "usc_scatter_add_rows")
+        return dsrc, None
 
 
 def gather_rows(src, idx):
