@@ -85,6 +85,7 @@ class CoordinateManager:
         self._down = {}       # fine ts -> dict(parent, nbr2, kidx, rulebook)
         self._cube = {}       # (ts, ksize) -> dict(nbr, rulebook)
         self._batch_rows = {}  # ts -> list of (start, end) per batch, or index lists
+        self._sorted_input = None
 
     # -- maps
     def insert(self, coords: torch.Tensor, tensor_stride: int = 1):
@@ -131,19 +132,23 @@ class CoordinateManager:
 
     # -- batch decomposition
     def batch_slices(self, ts: int):
+        """Row ranges of every scene in the map at tensor stride ts.  Rows are grouped by batch in every
+        map this manager builds (first-occurrence order of batch-sorted input), so one bincount and one
+        host read per level suffice; unsorted input falls back to index lists."""
         if ts not in self._batch_rows:
             b = self._maps[ts].coords[:, 0]
             if b.numel() == 0:
                 self._batch_rows[ts] = []
             else:
-                nb = int(b.max().item()) + 1
-                counts = torch.bincount(b.long(), minlength=nb)
-                sorted_ok = bool((b[1:] >= b[:-1]).all().item()) if b.numel() > 1 else True
-                if sorted_ok:
-                    ends = torch.cumsum(counts, 0).tolist()
+                if self._sorted_input is None:
+                    b1 = self._maps[min(self._maps)].coords[:, 0]
+                    self._sorted_input = bool((b1[1:] >= b1[:-1]).all().item()) if b1.numel() > 1 else True
+                if self._sorted_input:
+                    ends = torch.cumsum(torch.bincount(b.long()), 0).tolist()
                     starts = [0] + ends[:-1]
                     self._batch_rows[ts] = [slice(s, e) for s, e in zip(starts, ends)]
                 else:
+                    nb = int(b.max().item()) + 1
                     self._batch_rows[ts] = [torch.nonzero(b == i).reshape(-1) for i in range(nb)]
         return self._batch_rows[ts]
 

@@ -38,27 +38,25 @@ class NoGpu:
 def get_instance_freemasks(list_freemasks, list_segments=None):
     """Targets from [labels | K mask columns | segment id] tables (reference :480-527).
 
-    Every non-empty mask column becomes one foreground target (label 1).  With segments, the
-    segment mask is set at `unique(all values of the masked rows)` — the reference takes the
-    unique over whole rows (label and 0/1 mask values included), which is reproduced here."""
+    Every non-empty mask column becomes one foreground target (label 1).  With segments, the segment
+    mask of a target is set at `unique(ALL values of the rows inside the mask)` — the reference takes
+    the unique over whole table rows (label column and the 0/1 mask values included, :503), which is
+    reproduced here.  Vectorised over the K columns (one host sync per scene instead of K)."""
     target = []
     for b, table in enumerate(list_freemasks):
-        labels, masks, seg_masks = [], [], []
-        for inst in range(table.shape[1] - 2):
-            hard = table[:, inst + 1].bool()
-            if hard.sum() == 0:
-                continue
-            labels.append(torch.as_tensor(1, device=table.device))
-            masks.append(hard)
-            if list_segments:
-                sm = torch.zeros(list_segments[b].shape[0], dtype=torch.bool, device=table.device)
-                sm[table[hard].unique()] = True
-                seg_masks.append(sm)
-        if not labels:
+        cols = table[:, 1:-1] != 0                                  # [N, K] hard masks
+        keep = torch.nonzero(cols.any(0)).reshape(-1)               # non-empty columns (host sync)
+        if keep.numel() == 0:
             return []
-        entry = {"labels": torch.stack(labels), "masks": torch.stack(masks)}
+        masks = cols[:, keep].T.contiguous()                        # [T, N]
+        entry = {"labels": torch.ones(keep.numel(), dtype=torch.int64, device=table.device), "masks": masks}
         if list_segments:
-            entry["segment_mask"] = torch.stack(seg_masks)
+            S = list_segments[b].shape[0]
+            tt, rr = torch.nonzero(masks, as_tuple=True)            # (target, row) pairs
+            vals = table[rr]                                        # [P, K+2] every value of those rows
+            sm = torch.zeros((keep.numel(), S), dtype=torch.bool, device=table.device)
+            sm[tt[:, None].expand_as(vals).reshape(-1), vals.reshape(-1)] = True
+            entry["segment_mask"] = sm
         target.append(entry)
     return target
 

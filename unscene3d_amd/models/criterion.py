@@ -110,15 +110,90 @@ class SetCriterion(nn.Module):
 
     # -- matching of every level with one host transfer ------------------------------------
     def match_all_levels(self, levels, targets, mask_type):
-        per_level = [self.matcher.cost_matrices(lv, targets, mask_type) for lv in levels]
+        """Cost matrices of ALL prediction levels in a handful of batched launches (the reference builds
+        them level by level, matcher.py:98-168), one device->host copy, then scipy per (level, scene)."""
+        m = self.matcher
+        if m.num_points != -1:      # random point sub-sampling: keep the reference's per-level path
+            per_level = [m.cost_matrices(lv, targets, mask_type) for lv in levels]
+        else:
+            per_level = [[None] * len(targets) for _ in levels]
+            L = len(levels)
+            with torch.no_grad():
+                for b, tgt in enumerate(targets):
+                    logits = torch.stack([lv["pred_logits"][b] for lv in levels]).float()          # [L,Q,C]
+                    masks = torch.stack([lv["pred_masks"][b] for lv in levels]).float().transpose(1, 2)   # [L,Q,S]
+                    tgt_ids = tgt["labels"].clone()
+                    ignore = tgt_ids == 253
+                    tgt_ids[ignore] = 0
+                    cost_class = -logits.softmax(-1)[:, :, tgt_ids]                                   # [L,Q,T]
+                    cost_class[:, :, ignore] = -1.0
+                    tm = tgt[mask_type].to(masks)                                                     # [T,S]
+                    S = masks.shape[2]
+                    pos = F.binary_cross_entropy_with_logits(masks, torch.ones_like(masks), reduction="none")
+                    neg = F.binary_cross_entropy_with_logits(masks, torch.zeros_like(masks), reduction="none")
+                    cost_mask = (pos @ tm.T + neg @ (1 - tm).T) / S
+                    p = masks.sigmoid()
+                    cost_dice = 1 - (2 * (p @ tm.T) + 1) / (p.sum(-1)[:, :, None] + tm.sum(-1)[None, None, :] + 1)
+                    C = m.cost_mask * cost_mask + m.cost_class * cost_class + m.cost_dice * cost_dice
+                    for l in range(L):
+                        per_level[l][b] = C[l]
         flat = [C for Cs in per_level for C in Cs]
         widths = [C.shape[1] for C in flat]
         host = torch.cat(flat, dim=1).cpu()                                   # the single D2H of the step
         pieces = torch.split(host, widths, dim=1)
-        out, p = [], 0
+        out, q = [], 0
         for Cs in per_level:
-            out.append([self.matcher.solve(pieces[p + b]) for b in range(len(Cs))])
-            p += len(Cs)
+            out.append([m.solve(pieces[q + b]) for b in range(len(Cs))])
+            q += len(Cs)
+        return out
+
+    def _batched_losses(self, levels, targets, all_indices, mask_type):
+        """All levels' classification and mask losses in batched launches; returns the same 4 scalars per
+        level as get_loss (arithmetic per level identical to loss_labels / loss_masks)."""
+        L, B = len(levels), len(targets)
+        dev = levels[0]["pred_logits"].device
+        # ---- labels (weighted CE, mean over B*Q with weights, ignore_index 253: F.cross_entropy semantics)
+        logits = torch.stack([lv["pred_logits"] for lv in levels]).float()                # [L,B,Q,C]
+        Q = logits.shape[2]
+        tc = torch.full((L, B, Q), self.num_classes, dtype=torch.int64)
+        for l in range(L):
+            for b, (src, J) in enumerate(all_indices[l]):
+                tc[l, b, src] = targets[b]["labels"].cpu()[J] if targets[b]["labels"].device.type != "cpu" \
+                    else targets[b]["labels"][J]
+        tc = tc.to(dev)
+        nll = F.cross_entropy(logits.reshape(L * B * Q, -1), tc.reshape(-1), self.empty_weight, ignore_index=253,
+                              reduction="none").reshape(L, -1)
+        w = self.empty_weight[tc.clamp(max=self.num_classes)].reshape(L, -1) * (tc != 253).reshape(L, -1)
+        loss_ce = nll.sum(1) / w.sum(1)                                                    # [L]
+        # ---- masks: per scene, all levels at once
+        loss_mask = torch.zeros(L, device=dev)
+        loss_dice = torch.zeros(L, device=dev)
+        for b, tgt in enumerate(targets):
+            pm = torch.stack([lv["pred_masks"][b] for lv in levels])                       # [L,S,Q]
+            src = torch.stack([all_indices[l][b][0] for l in range(L)]).to(dev)            # [L,T]
+            tid = torch.stack([all_indices[l][b][1] for l in range(L)]).to(dev)            # [L,T]
+            mp = torch.gather(pm, 2, src[:, None, :].expand(-1, pm.shape[1], -1)).transpose(1, 2)   # [L,T,S]
+            tm = tgt[mask_type].to(dev)[tid].float()                                      # [L,T,S]
+            T = tm.shape[1]
+            if self.use_droploss:
+                fg = mp > 0.0
+                iou = (fg * tm).sum(2) / (fg + tm).sum(2)
+                wts = (iou >= self.droploss_iou_thresh).float()
+            else:
+                wts = torch.ones(mp.shape[:2], device=dev)
+            bce = F.binary_cross_entropy_with_logits(mp, tm, reduction="none")
+            loss_mask = loss_mask + (wts[..., None] * bce).mean(2).sum(1) / T
+            p = mp.sigmoid()
+            dice = 1 - (2 * (p * tm).sum(2) + 1) / (p.sum(2) + tm.sum(2) + 1)
+            loss_dice = loss_dice + (wts * dice).sum(1) / T
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
+        out = {}
+        for l in range(L):
+            sfx = "" if l == 0 else f"_{l - 1}"
+            out["loss_ce" + sfx] = loss_ce[l]
+            out["loss_mask" + sfx] = loss_mask[l]
+            out["loss_dice" + sfx] = loss_dice[l]
+            out["loss_noise_robust" + sfx] = zero
         return out
 
     def forward(self, outputs, targets, mask_type, coords=None):
@@ -133,6 +208,13 @@ class SetCriterion(nn.Module):
             num_masks = torch.clamp(nm / get_world_size(), min=1).item()
         else:
             num_masks = max(float(num_masks), 1.0)
+
+        batchable = (self.losses == ["labels", "masks"] and self.num_points == -1
+                     and self.weight_dict.get("loss_noise_robust", 0) == 0)
+        same_T = all(len(all_indices[l][b][0]) == len(all_indices[0][b][0]) for l in range(len(levels))
+                     for b in range(len(targets)))
+        if batchable and same_T:
+            return self._batched_losses(levels, targets, all_indices, mask_type)
 
         losses = {}
         for loss in self.losses:

@@ -139,12 +139,20 @@ def kernel_map_down2(fine: CoordMap, parent: torch.Tensor, coarse: CoordMap):
     return nbr2, kidx
 
 
-@dataclass
 class Rulebook:
-    in_idx: torch.Tensor   # i32[P]
-    out_idx: torch.Tensor  # i32[P]
-    koff: torch.Tensor     # i64[K+1] (device)
-    P: int                 # host copy of koff[K]
+    """Per-offset (in,out) pair lists.  in_idx/out_idx are allocated at capacity K*n_out; only the first
+    koff[K] entries are meaningful.  `P` (the pair count) is read back from the device lazily — the
+    kernels take the device-side koff and an upper bound, so the hot path never synchronises on it."""
+
+    def __init__(self, in_idx, out_idx, koff, capacity, P=None):
+        self.in_idx, self.out_idx, self.koff, self.capacity = in_idx, out_idx, koff, capacity
+        self._P = P
+
+    @property
+    def P(self) -> int:
+        if self._P is None:
+            self._P = int(self.koff[-1].item())
+        return self._P
 
 
 def rulebook_compact(nbr: torch.Tensor) -> Rulebook:
@@ -157,8 +165,7 @@ def rulebook_compact(nbr: torch.Tensor) -> Rulebook:
     ws = _ws(lib.usc_rulebook_ws_bytes(K, n_out), dev)
     check(lib.usc_rulebook_compact(_ptr(nbr), K, n_out, _ptr(in_idx), _ptr(out_idx), _ptr(koff), _ptr(ws),
                                    ws.numel(), _stream()), "usc_rulebook_compact")
-    P = int(koff[K].item())
-    return Rulebook(in_idx[:P], out_idx[:P], koff, P)
+    return Rulebook(in_idx, out_idx, koff, K * n_out)
 
 
 # ------------------------------------------------------------------ convolution
@@ -298,7 +305,7 @@ class _ConvDown2(torch.autograd.Function):
         dfeats = dW = None
         if ctx.needs_input_grad[0]:
             Wt = weight_transpose(W.contiguous(), mirror=False)
-            dfeats = pairs_gemm(dout, Wt, rb.out_idx, rb.in_idx, rb.koff, rb.P, feats.shape[0])
+            dfeats = pairs_gemm(dout, Wt, rb.out_idx, rb.in_idx, rb.koff, feats.shape[0], feats.shape[0])
         if ctx.needs_input_grad[1]:
             dW = wgrad(feats, dout, W.shape[0], rb.in_idx, rb.out_idx, rb.koff)
         return dfeats, dW, None, None
@@ -311,7 +318,7 @@ class _ConvTrUp2(torch.autograd.Function):
     def forward(ctx, feats, W, nbr2, get_rulebook, n_fine):
         feats = feats.contiguous()
         rb = get_rulebook()
-        out = pairs_gemm(feats, W.contiguous(), rb.out_idx, rb.in_idx, rb.koff, rb.P, n_fine)
+        out = pairs_gemm(feats, W.contiguous(), rb.out_idx, rb.in_idx, rb.koff, n_fine, n_fine)
         ctx.save_for_backward(feats, W)
         ctx.nbr2, ctx.rb = nbr2, rb
         return out
