@@ -305,6 +305,37 @@ int usc_fourier_posenc(const float* xyz, int64_t n, const float* lo,
                        const float* hi, const float* gauss_B, int32_t d,
                        float* out, usc_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * N2-N4  normalized-cut pseudo masks — replaces the numpy/scipy functions of
+ * pseudo_masks/unscene3d_pseudo_main.py:82-153 (normalize_mat,
+ * get_affinity_matrix, second_smallest_eigenvector) and cosine_sim
+ * (utils/freemask_utils.py:8-18).
+ * ---------------------------------------------------------------------- */
+/* normed f32[S,d] = F.normalize(F) (cosine_mode=1: divided once more by ||.||+1e-9);
+ * sim f32[S,S] = normed normed^T; cosine_mode=1 also applies cosine_sim's per-row
+ * min-max (attn -= rowmin; attn /= rowmax + 1e-9). */
+int usc_ncut_similarity(const float* F, int64_t S, int32_t d,
+                        int32_t cosine_mode, float* normed, float* sim,
+                        usc_stream_t s);
+/* In-place normalize_mat: A -= min(A[A != 0]) if any(A > 0); A[A < 0] = 0;
+ * A /= max(A) + 1e-5.  ws >= 12288 bytes. */
+int usc_ncut_normalize_mat(float* A, int64_t S, void* ws, int64_t ws_bytes,
+                           usc_stream_t s);
+/* Abin u8[S,S] = ((simA [+ simB]) / (1|2)) > tau with painted rows/columns forced
+ * off (unscene3d_pseudo_main.py:426-427); deg f64[S] = column sums of
+ * (A ? 1 : eps) BEFORE the painting overwrite (:111-118).  simB, painted may be NULL. */
+int usc_ncut_binarize(const float* simA, const float* simB, int64_t S, float tau,
+                      double eps, const uint8_t* painted, uint8_t* Abin,
+                      double* deg, usc_stream_t s);
+/* Eigenvector #2 (second smallest eigenvalue) of (D - A) v = lambda D v, i.e.
+ * scipy.linalg.eigh(D - A, D, subset_by_index=[1, 2])[1][:, 0], fp64, with LAPACK's
+ * sign (dsygvx sequence restated: lower triangle, dsytrd 'L' reflectors, dstein
+ * normalisation).  A = Abin ? 1 : eps.  evec f64[S], eval f64[2] = (lambda_1, lambda_2). */
+int64_t usc_ncut_fiedler_ws_bytes(int64_t S);
+int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double eps,
+                     double* evec, double* eval, void* ws, int64_t ws_bytes,
+                     usc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

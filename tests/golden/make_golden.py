@@ -5,7 +5,8 @@ Imports the importable parts of the reference in place (stub modules for the dep
 not installed: SURVEY.md Appendix A), feeds them seeded inputs and stores inputs + outputs as small
 .npz fixtures next to this script.  Nothing from /root/reference is copied; the fixtures are data.
 
-    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py            # criterion / posenc / decoder_layers fixtures
+    python tests/golden/make_golden.py ncut       # NCut fixtures (separate interpreter: different stubs)
 """
 import importlib
 import os
@@ -150,10 +151,102 @@ def make_decoder_layers(mods):
     print("decoder layers ok")
 
 
+def import_reference_ncut():
+    """pseudo_masks/unscene3d_pseudo_main.py with stubs (recipe 2). Run in a fresh
+    interpreter state: its `models`/`datasets`/`utils.*` imports are stubbed, unlike recipe 1."""
+    stub("hydra", "omegaconf", "pyviz3d", "pyviz3d.visualizer", "MinkowskiEngine", "open3d", "hdbscan", "datasets",
+         "datasets.dataset", "models", "models.encoders_2d", "utils.utils", "utils.cuda_utils",
+         "utils.cuda_utils.raycast_image")
+    sys.modules["hydra"].main = lambda **kw: (lambda f: f)
+    os.chdir(os.path.join(REF, "pseudo_masks"))
+    sys.path.insert(0, os.path.join(REF, "pseudo_masks"))
+    sys.path.insert(0, REF)
+    return importlib.import_module("unscene3d_pseudo_main")
+
+
+def planted_scene(seed, side, dims, n_objects, pts_per_seg=6):
+    """Config-5 inputs: a side x side grid of segments; `n_objects` compact rectangular
+    objects of DISTINCT sizes (distinct sizes keep the small eigenvalues of the weakly coupled blocks
+    simple) scattered over a background cluster that separates them spatially, like furniture on a floor."""
+    rng = np.random.default_rng(seed)
+    S = side * side
+    label = np.zeros((side, side), np.int64)            # 0 = background
+    sizes = [(2 + (k % 4), 3 + (k // 3)) for k in range(n_objects)]
+    placed = 0
+    for k, (h, w) in enumerate(sizes):
+        for _ in range(200):
+            r, c = int(rng.integers(1, side - h - 1)), int(rng.integers(1, side - w - 1))
+            if not label[r - 1:r + h + 1, c - 1:c + w + 1].any():
+                label[r:r + h, c:c + w] = k + 1
+                placed += 1
+                break
+    label = label.reshape(-1)
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    gx, gy = gx.reshape(-1), gy.reshape(-1)
+    feats = []
+    for d in dims:
+        cent = rng.normal(size=(n_objects + 1, d))
+        feats.append((cent[label] + 0.25 * rng.normal(size=(S, d))).astype(np.float32))
+    conn = []
+    for i in range(S):
+        for da, db in ((1, 0), (0, 1)):
+            a, b = gx[i] + da, gy[i] + db
+            if a < side and b < side:
+                j = a * side + b
+                conn += [(i, j), (j, i)]
+    conn = np.asarray(conn, np.int64)
+    seg_ids = np.repeat(np.arange(S), pts_per_seg)
+    coords = np.stack([gx[seg_ids] + rng.random(len(seg_ids)), gy[seg_ids] + rng.random(len(seg_ids)),
+                       rng.random(len(seg_ids))], 1).astype(np.float32)
+    return feats, conn, seg_ids, coords, label, placed
+
+
+def make_ncut(ref):
+    out = {}
+    for name, (side, dims, k, tau) in {"single": (15, (96,), 8, 0.6), "dual": (25, (384, 96), 16, 0.6)}.items():
+        feats, conn, seg_ids, coords, label, placed = planted_scene(50 + side, side, dims, k)
+        S = side * side
+        tf = [torch.from_numpy(f) for f in feats]
+        mk = lambda: tf[0].clone() if len(tf) == 1 else (tf[0].clone(), tf[1].clone())
+        uniq = torch.arange(S)
+        # per-iteration internals straight from the reference's own functions (logged by wrapping them)
+        trace = []
+        orig = ref.second_smallest_eigenvector
+
+        def logged(A, D, _orig=orig, _trace=trace):
+            res = _orig(A, D)
+            w = __import__("scipy.linalg").linalg.eigh(D - A, D, subset_by_index=[1, 2], eigvals_only=True)
+            _trace.append((A > 0.5, np.diag(D).copy(), res[1].copy(), w))
+            return res
+
+        ref.second_smallest_eigenvector = logged
+        masks = ref.unscene3d(mk(), uniq, torch.from_numpy(conn), torch.from_numpy(seg_ids), torch.from_numpy(coords),
+                              torch.from_numpy(coords), affinity_tau=tau, max_number_of_instances=20,
+                              similarity_metric="cos", min_segment_size=4, separation_mode="max",
+                              max_extent_ratio=0.8)
+        ref.second_smallest_eigenvector = orig
+        for j, f in enumerate(feats):
+            out[f"{name}/feat{j}"] = f
+        out[f"{name}/conn"], out[f"{name}/label"] = conn, label
+        out[f"{name}/tau"] = np.float64(tau)
+        out[f"{name}/n_iter"] = np.int64(len(trace))
+        for it, (A, d, vec, w) in enumerate(trace):
+            out[f"{name}/it{it}/A"] = np.packbits(A, axis=1)
+            out[f"{name}/it{it}/deg"], out[f"{name}/it{it}/vec"], out[f"{name}/it{it}/evals"] = d, vec, w
+        out[f"{name}/masks"] = np.packbits(masks.astype(bool), axis=1)
+        out[f"{name}/n_masks"] = np.int64(masks.shape[0])
+        gaps = [float((w[1] - w[0]) / max(w[1], 1e-300)) for (_, _, _, w) in trace]
+        print("ncut", name, "S", S, "objects placed", placed, "masks", masks.shape, "rel gaps", np.round(gaps, 4))
+    np.savez_compressed(os.path.join(HERE, "ncut.npz"), **out)
+
+
 if __name__ == "__main__":
     cwd = os.getcwd()
-    mods = import_reference_models()
-    make_criterion(mods)
-    make_posenc(mods)
-    make_decoder_layers(mods)
+    if len(sys.argv) > 1 and sys.argv[1] == "ncut":
+        make_ncut(import_reference_ncut())
+    else:
+        mods = import_reference_models()
+        make_criterion(mods)
+        make_posenc(mods)
+        make_decoder_layers(mods)
     os.chdir(cwd)

@@ -1,0 +1,44 @@
+"""CPU: oracle/ncut_ref.py (affinity + scipy eigenvector) against the golden vectors captured from the
+reference's own get_affinity_matrix / second_smallest_eigenvector (tests/golden/ncut.npz)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import ncut_ref as NR
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ncut.npz")
+
+
+def _case(z, name, it=0):
+    feats = [torch.from_numpy(z[f"{name}/feat{j}"]) for j in range(2) if f"{name}/feat{j}" in z.files]
+    S = feats[0].shape[0]
+    A = np.unpackbits(z[f"{name}/it{it}/A"], axis=1)[:, :S].astype(bool)
+    return feats, S, A, z[f"{name}/it{it}/deg"], z[f"{name}/it{it}/vec"], float(z[f"{name}/tau"])
+
+
+def test_affinity_and_eigenvector_match_reference():
+    z = np.load(GOLD)
+    for name in ("single", "dual"):
+        feats, S, A0, deg0, vec0, tau = _case(z, name)
+        A, d = NR.affinity(feats[0] if len(feats) == 1 else (feats[0], feats[1]), tau)
+        assert np.array_equal(A > 0.5, A0)
+        np.testing.assert_allclose(d, deg0, rtol=1e-12)
+        w, v = NR.fiedler(A, d)
+        # LAPACK's eigenvector sign is not portable across BLAS builds / core counts (observed: this
+        # container and the GPU box disagree), so the oracle is compared up to sign here; the device
+        # kernel restates netlib's conventions and is compared WITH sign against the golden vector.
+        assert abs(float(v @ (d * vec0))) > 0.999999
+        np.testing.assert_allclose(w, z[f"{name}/it0/evals"], rtol=1e-6)
+
+
+def test_oracle_loop_reproduces_reference_masks_up_to_lapack_sign():
+    """The restated loop gives the reference's masks when LAPACK returns the same signs as in the build
+    container; elsewhere it must still produce valid masks (disjoint, non-empty)."""
+    z = np.load(GOLD)
+    name = "single"
+    f = torch.from_numpy(z[f"{name}/feat0"])
+    S = f.shape[0]
+    masks = NR.unscene3d_ref(f.clone(), np.arange(S), z[f"{name}/conn"], tau=float(z[f"{name}/tau"]))
+    assert masks.shape[1] == S and masks.shape[0] >= 1
+    assert (masks.sum(0) <= 1).all() and (masks.sum(1) > 0).all()

@@ -1,0 +1,455 @@
+// ncut.hip — masked Normalized-Cut pseudo masks on the device (SURVEY.md §8a rows N2-N4;
+// reference pseudo_masks/unscene3d_pseudo_main.py:82-153, utils/freemask_utils.py:8-18).
+//
+// The reference builds a binary segment affinity matrix on the host (numpy) and calls
+// scipy.linalg.eigh(D-A, D, subset_by_index=[1,2]) -> LAPACK dsygvx: Cholesky of the diagonal D,
+// reduction to C = D^-1/2 (D-A) D^-1/2 from the LOWER triangle, Householder tridiagonalisation
+// (dsytrd, uplo='L'), bisection for eigenvalue #2 (dstebz), inverse iteration (dstein: eigenvector
+// of T scaled so that its largest-magnitude component is positive), back-transformation with the
+// reflectors (dormtr) and x = D^-1/2 y.  The SIGN of that vector decides which side of the cut is
+// "foreground" downstream (get_salient_areas, argmax seed), so the same sequence of orthogonal
+// transformations is restated here in fp64 — the result matches LAPACK's vector including its sign
+// (verified against scipy on the golden fixtures).  Everything is S x S (S = 600..3000 segments):
+// latency-bound; the trailing-matrix symv / rank-2 update of every Householder step run chip-wide.
+#include "common.h"
+
+namespace usc {
+
+// ---------------------------------------------------------------------------
+// similarity
+__global__ __launch_bounds__(256) void ncut_rownorm_kernel(const float* __restrict__ F, int64_t S, int d, int cosine_again,
+                                                          float* __restrict__ out) {
+  // F.normalize(p=2, eps=1e-12) [+ cosine_sim's own x / (||x|| + 1e-9)]; one wave per row
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= S) return;
+  float ss = 0.f;
+  for (int c = lane; c < d; c += 64) { const float v = F[r * d + c]; ss += v * v; }
+  ss = wave_reduce_addf(ss);
+  const float n1 = fmaxf(sqrtf(ss), 1e-12f);
+  float ss2 = 0.f;
+  for (int c = lane; c < d; c += 64) { const float v = F[r * d + c] / n1; ss2 += v * v; }
+  ss2 = wave_reduce_addf(ss2);
+  const float n2 = sqrtf(ss2) + 1e-9f;
+  for (int c = lane; c < d; c += 64) {
+    float v = F[r * d + c] / n1;
+    if (cosine_again) v = v / n2;
+    out[r * d + c] = v;
+  }
+}
+
+// sim[i][j] = sum_c X[i][c] * X[j][c]   (fp32, 16x16 register-free tile per block through LDS)
+__global__ __launch_bounds__(256) void ncut_gram_kernel(const float* __restrict__ X, int64_t S, int d,
+                                                       float* __restrict__ sim) {
+  __shared__ float a[16][33], b[16][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.y * 16 + ty, j = (int64_t)blockIdx.x * 16 + tx;
+  float acc = 0.f;
+  for (int c0 = 0; c0 < d; c0 += 32) {
+    for (int q = threadIdx.x; q < 16 * 32; q += 256) {
+      const int r = q >> 5, c = q & 31;
+      const int64_t ri = (int64_t)blockIdx.y * 16 + r, rj = (int64_t)blockIdx.x * 16 + r;
+      a[r][c] = (ri < S && c0 + c < d) ? X[ri * d + c0 + c] : 0.f;
+      b[r][c] = (rj < S && c0 + c < d) ? X[rj * d + c0 + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc = fmaf(a[ty][c], b[tx][c], acc);
+    __syncthreads();
+  }
+  if (i < S && j < S) sim[i * S + j] = acc;
+}
+
+// cosine_sim's per-row min-max: attn -= rowmin; attn /= rowmax(after) + 1e-9
+__global__ __launch_bounds__(256) void ncut_row_minmax_kernel(float* __restrict__ sim, int64_t S) {
+  __shared__ float smin[4], smax[4];
+  const int64_t r = blockIdx.x;
+  float mn = 3.4e38f, mx = -3.4e38f;
+  for (int64_t c = threadIdx.x; c < S; c += 256) { const float v = sim[r * S + c]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  mn = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+  mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  const float den = (mx - mn) + 1e-9f;
+  for (int64_t c = threadIdx.x; c < S; c += 256) sim[r * S + c] = (sim[r * S + c] - mn) / den;
+}
+
+// normalize_mat: A -= min(A[A != 0]) if any(A > 0); A[A<0] = 0; A /= A.max() + 1e-5
+// pass 1: block partials of (min over nonzero, any positive, max)
+__global__ __launch_bounds__(256) void ncut_normmat_reduce_kernel(const float* __restrict__ A, int64_t numel,
+                                                                 float* __restrict__ part /*[blocks][3]*/) {
+  __shared__ float s0[4], s1[4], s2[4];
+  float mn = 3.4e38f, mx = -3.4e38f, pos = 0.f;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < numel; q += (int64_t)gridDim.x * 256) {
+    const float v = A[q];
+    if (v != 0.f) mn = fminf(mn, v);
+    if (v > 0.f) pos = 1.f;
+    mx = fmaxf(mx, v);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); pos = fmaxf(pos, __shfl_xor(pos, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) { s0[threadIdx.x >> 6] = mn; s1[threadIdx.x >> 6] = mx; s2[threadIdx.x >> 6] = pos; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x * 3 + 0] = fminf(fminf(s0[0], s0[1]), fminf(s0[2], s0[3]));
+    part[blockIdx.x * 3 + 1] = fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]));
+    part[blockIdx.x * 3 + 2] = fmaxf(fmaxf(s2[0], s2[1]), fmaxf(s2[2], s2[3]));
+  }
+}
+__global__ __launch_bounds__(256) void ncut_normmat_apply_kernel(float* __restrict__ A, int64_t numel,
+                                                                const float* __restrict__ part, int nparts) {
+  float mn = 3.4e38f, mx = -3.4e38f, pos = 0.f;
+  for (int b = 0; b < nparts; ++b) { mn = fminf(mn, part[b * 3]); mx = fmaxf(mx, part[b * 3 + 1]); pos = fmaxf(pos, part[b * 3 + 2]); }
+  const float sub = pos > 0.f ? mn : 0.f;
+  // max after the subtraction and the clip: max(mx - sub, 0)
+  const float den = fmaxf(mx - sub, 0.f) + 1e-5f;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < numel; q += (int64_t)gridDim.x * 256) {
+    float v = A[q] - sub;
+    if (v < 0.f) v = 0.f;
+    A[q] = v / den;
+  }
+}
+
+// A = ((simA [+ simB]) / (1 or 2)) > tau, painted rows/cols forced off; deg[j] = sum_i (A_ij ? 1 : eps)
+__global__ __launch_bounds__(256) void ncut_binarize_kernel(const float* __restrict__ simA, const float* __restrict__ simB,
+                                                           int64_t S, float tau, const uint8_t* __restrict__ painted,
+                                                           uint8_t* __restrict__ Abin) {
+  const int64_t numel = S * S;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < numel; q += (int64_t)gridDim.x * 256) {
+    float v = simA[q];
+    if (simB) v = (v + simB[q]) / 2.f;
+    uint8_t on = v > tau;
+    if (painted) {
+      const int64_t i = q / S, j = q - i * S;
+      if (painted[i] || painted[j]) on = 0;
+    }
+    Abin[q] = on;
+  }
+}
+__global__ __launch_bounds__(256) void ncut_degree_kernel(const float* __restrict__ simA, const float* __restrict__ simB,
+                                                         int64_t S, float tau, double eps, double* __restrict__ deg) {
+  // D is computed BEFORE the painted rows/cols are overwritten (reference :111-118 vs :426-427)
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= S) return;
+  double s = 0.0;
+  for (int64_t i = 0; i < S; ++i) {
+    float v = simA[i * S + j];
+    if (simB) v = (v + simB[i * S + j]) / 2.f;
+    s += (v > tau) ? 1.0 : eps;
+  }
+  deg[j] = s;
+}
+
+// C = D^-1/2 (D - A) D^-1/2 from the LOWER triangle of A (mirrored), full symmetric storage
+__global__ __launch_bounds__(256) void ncut_laplacian_kernel(const uint8_t* __restrict__ Abin, const double* __restrict__ deg,
+                                                            int64_t S, double eps, double* __restrict__ C) {
+  const int64_t numel = S * S;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < numel; q += (int64_t)gridDim.x * 256) {
+    const int64_t i = q / S, j = q - i * S;
+    const int64_t lo = i >= j ? i * S + j : j * S + i;
+    const double a = Abin[lo] ? 1.0 : eps;
+    const double v = ((i == j) ? deg[i] : 0.0) - a;
+    C[q] = v / (sqrt(deg[i]) * sqrt(deg[j]));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Householder tridiagonalisation, LAPACK dsytd2 uplo='L' conventions.
+// step i:  (1) reflector from column i  (2) p = C22 v  (3) C22 -= v w^T + w v^T, w = tau p - (tau^2/2)(p.v) v
+struct TriState {
+  double* C;      // [n][n] symmetric working matrix
+  double* Vt;     // [n][n] row i = reflector i (v[i+1] = 1, zeros above)
+  double* d;      // [n]
+  double* e;      // [n-1]
+  double* tau;    // [n-1]
+  double* p;      // [n] scratch
+  int64_t n;
+};
+
+__global__ __launch_bounds__(1024) void tri_reflector_kernel(TriState t, int64_t i) {
+  __shared__ double red[16];
+  __shared__ double s_beta, s_tau, s_scale;
+  const int64_t n = t.n;
+  const int tid = threadIdx.x;
+  double* col = t.C;  // column i entries C[r][i], r > i
+  double ss = 0.0;
+  for (int64_t r = i + 2 + tid; r < n; r += 1024) { const double x = col[r * n + i]; ss += x * x; }
+  ss = wave_reduce_addd(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    const double alpha = col[(i + 1) * n + i];
+    const double xnorm = sqrt(tot);
+    if (xnorm == 0.0) {
+      s_beta = alpha; s_tau = 0.0; s_scale = 0.0;
+    } else {
+      const double nrm = hypot(alpha, xnorm);
+      const double beta = alpha >= 0.0 ? -nrm : nrm;     // -sign(alpha) * ||(alpha, x)||
+      s_beta = beta;
+      s_tau = (beta - alpha) / beta;
+      s_scale = 1.0 / (alpha - beta);
+    }
+    t.d[i] = col[i * n + i];
+    t.e[i] = s_beta;
+    t.tau[i] = s_tau;
+    if (i == n - 2) t.d[n - 1] = 0.0;  // set by the final step below
+  }
+  __syncthreads();
+  const double scale = s_scale;
+  double* v = t.Vt + i * n;
+  for (int64_t r = tid; r < n; r += 1024) {
+    double val = 0.0;
+    if (r == i + 1) val = 1.0;
+    else if (r > i + 1) val = col[r * n + i] * scale;
+    v[r] = val;
+  }
+}
+
+// p[r] = sum_c C[r][c] v[c] over the trailing block (r, c > i); one wave per row
+__global__ __launch_bounds__(256) void tri_symv_kernel(TriState t, int64_t i) {
+  const int64_t n = t.n;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = i + 1 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const double* v = t.Vt + i * n;
+  const double* row = t.C + r * n;
+  double s = 0.0;
+  for (int64_t c = i + 1 + lane; c < n; c += 64) s += row[c] * v[c];
+  s = wave_reduce_addd(s);
+  if (lane == 0) t.p[r] = s;
+}
+
+// C22 -= v w^T + w v^T with w = tau p + a2 v, a2 = -tau^2/2 (p.v); each block recomputes the scalar
+__global__ __launch_bounds__(256) void tri_update_kernel(TriState t, int64_t i) {
+  __shared__ double red[4];
+  const int64_t n = t.n;
+  const double tau = t.tau[i];
+  if (tau == 0.0) return;
+  const double* v = t.Vt + i * n;
+  double dot = 0.0;
+  for (int64_t c = i + 1 + threadIdx.x; c < n; c += 256) dot += t.p[c] * v[c];
+  dot = wave_reduce_addd(dot);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  dot = red[0] + red[1] + red[2] + red[3];
+  const double a2 = -0.5 * tau * (tau * dot);
+  const int64_t m = n - i - 1;
+  const int64_t total = m * m;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+    const int64_t r = i + 1 + q / m, c = i + 1 + q % m;
+    const double wr = tau * t.p[r] + a2 * v[r], wc = tau * t.p[c] + a2 * v[c];
+    t.C[r * n + c] -= v[r] * wc + wr * v[c];
+  }
+}
+__global__ void tri_last_diag_kernel(TriState t) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) t.d[t.n - 1] = t.C[(t.n - 1) * t.n + (t.n - 1)];
+}
+
+// ---------------------------------------------------------------------------
+// eigenvalue #k of the tridiagonal (Sturm counts, 64 shifts per round) + inverse iteration with partial
+// pivoting; the vector is scaled to unit norm with its largest-magnitude component positive (dstein).
+__device__ inline int sturm_count(const double* d, const double* e, int64_t n, double x) {
+  int cnt = 0;
+  double q = d[0] - x;
+  if (q < 0.0) ++cnt;
+  for (int64_t j = 1; j < n; ++j) {
+    const double den = (q != 0.0) ? q : 1e-300;
+    q = d[j] - x - e[j - 1] * e[j - 1] / den;
+    if (q < 0.0) ++cnt;
+  }
+  return cnt;
+}
+
+__global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ d, const double* __restrict__ e, int64_t n,
+                                                    int k, double* __restrict__ eval_out /*[2]*/,
+                                                    double* __restrict__ z /*[n]*/, double* __restrict__ work /*[5n]*/) {
+  const int lane = threadIdx.x;
+  __shared__ double s_lam[2];
+  // Gershgorin interval
+  double lo = 1e300, hi = -1e300;
+  for (int64_t j = lane; j < n; j += 64) {
+    const double r = (j > 0 ? fabs(e[j - 1]) : 0.0) + (j < n - 1 ? fabs(e[j]) : 0.0);
+    lo = fmin(lo, d[j] - r);
+    hi = fmax(hi, d[j] + r);
+  }
+  for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
+  for (int which = 0; which < 2; ++which) {
+    double a = lo - 1e-12 - 1e-12 * fabs(lo), b = hi + 1e-12 + 1e-12 * fabs(hi);
+    const int target = k + which;   // eigenvalue index (0-based): smallest x with count(x) > target
+    for (int round = 0; round < 14; ++round) {
+      const double x = a + (b - a) * (double)(lane + 1) / 65.0;
+      const int cnt = sturm_count(d, e, n, x);
+      const unsigned long long m = __ballot(cnt > target);   // lanes whose shift is above the eigenvalue
+      const int first = m ? (__ffsll((long long)m) - 1) : 64;
+      const double na = first == 0 ? a : a + (b - a) * (double)first / 65.0;
+      const double nb = first == 64 ? b : a + (b - a) * (double)(first + 1) / 65.0;
+      a = na; b = nb;
+    }
+    if (lane == 0) s_lam[which] = 0.5 * (a + b);
+    __syncthreads();
+  }
+  if (lane != 0) return;
+  eval_out[0] = s_lam[0];
+  eval_out[1] = s_lam[1];
+  // ---- inverse iteration (single lane; n is a few thousand at most)
+  const double lam = s_lam[0];
+  double tnorm = 0.0;
+  for (int64_t j = 0; j < n; ++j) tnorm = fmax(tnorm, fabs(d[j]) + (j > 0 ? fabs(e[j - 1]) : 0.0) + (j < n - 1 ? fabs(e[j]) : 0.0));
+  const double shift = lam;
+  double* dl = work;            // sub-diagonal multipliers
+  double* dd = work + n;        // U diagonal
+  double* du = work + 2 * n;    // U first super-diagonal
+  double* du2 = work + 3 * n;   // U second super-diagonal (from pivoting)
+  double* piv = work + 4 * n;   // 1.0 if rows were swapped
+  // LU with partial pivoting of T - shift*I
+  const double tiny = 2.3e-16 * fmax(tnorm, 1e-300);
+  for (int64_t j = 0; j < n; ++j) { dd[j] = d[j] - shift; du[j] = (j < n - 1) ? e[j] : 0.0; du2[j] = 0.0; }
+  for (int64_t j = 0; j < n - 1; ++j) {
+    const double sub = e[j];
+    if (fabs(dd[j]) >= fabs(sub)) {
+      if (fabs(dd[j]) < tiny) dd[j] = tiny;
+      const double mlt = sub / dd[j];
+      dl[j] = mlt; piv[j] = 0.0;
+      dd[j + 1] -= mlt * du[j];
+    } else {
+      const double mlt = dd[j] / sub;
+      dl[j] = mlt; piv[j] = 1.0;
+      const double t1 = dd[j + 1];
+      dd[j] = sub;
+      dd[j + 1] = du[j] - mlt * t1;
+      du[j] = t1;
+      if (j < n - 2) { du2[j] = du[j + 1]; du[j + 1] = -mlt * du2[j]; }
+    }
+  }
+  if (fabs(dd[n - 1]) < tiny) dd[n - 1] = tiny;
+  // start vector: fixed pseudo-random in (-1,1)
+  unsigned long long st = 0x9E3779B97F4A7C15ull;
+  for (int64_t j = 0; j < n; ++j) {
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    z[j] = ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+  }
+  for (int it = 0; it < 6; ++it) {
+    // forward: apply L^-1 with the recorded row swaps
+    for (int64_t j = 0; j < n - 1; ++j) {
+      if (piv[j] != 0.0) { const double tmp = z[j]; z[j] = z[j + 1]; z[j + 1] = tmp - dl[j] * z[j]; }
+      else z[j + 1] -= dl[j] * z[j];
+    }
+    // backward: U x = z
+    z[n - 1] /= dd[n - 1];
+    if (n > 1) z[n - 2] = (z[n - 2] - du[n - 2] * z[n - 1]) / dd[n - 2];
+    for (int64_t j = n - 3; j >= 0; --j) z[j] = (z[j] - du[j] * z[j + 1] - du2[j] * z[j + 2]) / dd[j];
+    double nrm = 0.0, big = 0.0;
+    for (int64_t j = 0; j < n; ++j) { nrm += z[j] * z[j]; big = fmax(big, fabs(z[j])); }
+    nrm = sqrt(nrm);
+    for (int64_t j = 0; j < n; ++j) z[j] /= nrm;
+  }
+  int64_t jmax = 0;
+  for (int64_t j = 1; j < n; ++j) if (fabs(z[j]) > fabs(z[jmax])) jmax = j;
+  if (z[jmax] < 0.0) for (int64_t j = 0; j < n; ++j) z[j] = -z[j];
+}
+
+// y = H(0) H(1) ... H(n-2) z, then x = y / sqrt(deg)
+__global__ __launch_bounds__(1024) void tri_backtransform_kernel(TriState t, const double* __restrict__ deg,
+                                                                double* __restrict__ z, double* __restrict__ x) {
+  __shared__ double red[16];
+  __shared__ double s_dot;
+  const int64_t n = t.n;
+  const int tid = threadIdx.x;
+  for (int64_t i = n - 2; i >= 0; --i) {
+    const double tau = t.tau[i];
+    if (tau == 0.0) continue;   // block-uniform
+    const double* v = t.Vt + i * n;
+    double dot = 0.0;
+    for (int64_t r = i + 1 + tid; r < n; r += 1024) dot += v[r] * z[r];
+    dot = wave_reduce_addd(dot);
+    if ((tid & 63) == 0) red[tid >> 6] = dot;
+    __syncthreads();
+    if (tid == 0) { double s = 0.0; for (int k = 0; k < 16; ++k) s += red[k]; s_dot = s; }
+    __syncthreads();
+    const double f = tau * s_dot;
+    for (int64_t r = i + 1 + tid; r < n; r += 1024) z[r] -= f * v[r];
+    __syncthreads();
+  }
+  for (int64_t r = tid; r < n; r += 1024) x[r] = z[r] / sqrt(deg[r]);
+}
+
+}  // namespace usc
+
+using namespace usc;
+
+extern "C" {
+
+int usc_ncut_similarity(const float* F, int64_t S, int32_t d, int32_t cosine_mode, float* normed, float* sim,
+                        usc_stream_t s) {
+  USC_REQUIRE(S >= 1 && d >= 1 && F && normed && sim, "usc_ncut_similarity: bad argument");
+  hipStream_t st = as_stream(s);
+  hipLaunchKernelGGL(ncut_rownorm_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, st, F, S, (int)d,
+                     (int)cosine_mode, normed);
+  hipLaunchKernelGGL(ncut_gram_kernel, dim3((unsigned)ceil_div(S, 16), (unsigned)ceil_div(S, 16)), dim3(256), 0, st,
+                     (const float*)normed, S, (int)d, sim);
+  if (cosine_mode) hipLaunchKernelGGL(ncut_row_minmax_kernel, dim3((unsigned)S), dim3(256), 0, st, sim, S);
+  USC_CHECK_LAUNCH("usc_ncut_similarity");
+  return USC_OK;
+}
+
+int usc_ncut_normalize_mat(float* A, int64_t S, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(S >= 1 && A && ws && ws_bytes >= 1024 * 3 * 4, "usc_ncut_normalize_mat: bad argument");
+  hipStream_t st = as_stream(s);
+  const int64_t numel = S * S;
+  int nb = (int)ceil_div(numel, 256 * 8);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(ncut_normmat_reduce_kernel, dim3(nb), dim3(256), 0, st, (const float*)A, numel, (float*)ws);
+  hipLaunchKernelGGL(ncut_normmat_apply_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, A, numel,
+                     (const float*)ws, nb);
+  USC_CHECK_LAUNCH("usc_ncut_normalize_mat");
+  return USC_OK;
+}
+
+int usc_ncut_binarize(const float* simA, const float* simB, int64_t S, float tau, double eps, const uint8_t* painted,
+                      uint8_t* Abin, double* deg, usc_stream_t s) {
+  USC_REQUIRE(S >= 1 && simA && Abin && deg, "usc_ncut_binarize: bad argument");
+  hipStream_t st = as_stream(s);
+  hipLaunchKernelGGL(ncut_degree_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, st, simA, simB, S, tau, eps, deg);
+  hipLaunchKernelGGL(ncut_binarize_kernel, dim3(stream_grid(S * S, 256)), dim3(256), 0, st, simA, simB, S, tau, painted,
+                     Abin);
+  USC_CHECK_LAUNCH("usc_ncut_binarize");
+  return USC_OK;
+}
+
+int64_t usc_ncut_fiedler_ws_bytes(int64_t S) { return (2 * S * S + 12 * S + 16) * 8; }
+
+int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double eps, double* evec, double* eval,
+                     void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(S >= 3 && Abin && deg && evec && eval && ws, "usc_ncut_fiedler: bad argument");
+  USC_REQUIRE(ws_bytes >= usc_ncut_fiedler_ws_bytes(S), "usc_ncut_fiedler: workspace too small");
+  hipStream_t st = as_stream(s);
+  double* w = (double*)ws;
+  TriState t{};
+  t.n = S;
+  t.C = w;
+  t.Vt = w + S * S;
+  t.d = w + 2 * S * S;
+  t.e = t.d + S;
+  t.tau = t.e + S;
+  t.p = t.tau + S;
+  double* z = t.p + S;
+  double* work = z + S;   // 5 S
+  hipLaunchKernelGGL(ncut_laplacian_kernel, dim3(stream_grid(S * S, 256)), dim3(256), 0, st, Abin, deg, S, eps, t.C);
+  for (int64_t i = 0; i + 1 < S; ++i) {
+    hipLaunchKernelGGL(tri_reflector_kernel, dim3(1), dim3(1024), 0, st, t, i);
+    const int64_t m = S - i - 1;
+    hipLaunchKernelGGL(tri_symv_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(256), 0, st, t, i);
+    hipLaunchKernelGGL(tri_update_kernel, dim3(stream_grid(m * m, 256)), dim3(256), 0, st, t, i);
+  }
+  hipLaunchKernelGGL(tri_last_diag_kernel, dim3(1), dim3(64), 0, st, t);
+  hipLaunchKernelGGL(tri_eig_kernel, dim3(1), dim3(64), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
+  hipLaunchKernelGGL(tri_backtransform_kernel, dim3(1), dim3(1024), 0, st, t, deg, z, evec);
+  USC_CHECK_LAUNCH("usc_ncut_fiedler");
+  return USC_OK;
+}
+
+}  // extern "C"

@@ -454,12 +454,10 @@ __global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* __re
       const int64_t r = order[q];
       bool use = true;
       if (only_nonzero) {
-        // row counts when any channel is non-zero (reference: feats.sum(1) != 0 is
-        // approximated by the reference itself as "non-zero row"; see oracle)
-        float rs = 0.f;
-        for (int cc = lane; cc < c; cc += 64) rs += src[r * c + cc];
-        rs = wave_reduce_addf(rs);
-        use = rs != 0.f;
+        // valid row = torch.any(features != 0, dim=-1)  (unscene3d_pseudo_main.py:362)
+        bool nz = false;
+        for (int cc = lane; cc < c; cc += 64) nz |= src[r * c + cc] != 0.f;
+        use = __any(nz);
       }
       if (use) {
         ++cnt;
