@@ -336,6 +336,53 @@ int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double e
                      double* evec, double* eval, void* ws, int64_t ws_bytes,
                      usc_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * N6  exact 1-nearest-neighbour — replaces scipy.spatial.KDTree.query(k=1)
+ * (pseudo_masks/unscene3d_pseudo_main.py:341-343, :651-652).  f64 distances on
+ * f32 inputs; ties resolve to the lowest reference index.
+ * query f32[nq,3], ref f32[nr,3] -> idx i64[nq], dist2 f32[nq] (may be NULL).
+ * ---------------------------------------------------------------------- */
+int usc_knn1(const float* query, int64_t nq, const float* ref, int64_t nr,
+             int64_t* idx, float* dist2, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * E1  eps-ball connected components — replaces
+ * sklearn.cluster.DBSCAN(eps, min_samples=1).fit(xyz).labels_
+ * (trainer/trainer.py:521-523): min-label propagation with pointer jumping; the
+ * caller iterates usc_cc_eps_step (ping-pong label buffers) until `changed`
+ * (i32[1], device) reads 0, then usc_cc_eps_finish numbers the components in
+ * first-seen order (labels i64[n]).  xyz f32[n,3].
+ * ---------------------------------------------------------------------- */
+int usc_cc_eps_init(int32_t* label, int64_t n, usc_stream_t s);
+int usc_cc_eps_step(const float* xyz, int64_t n, float eps,
+                    const int32_t* label_in, int32_t* label_out,
+                    int32_t* changed, usc_stream_t s);
+int usc_cc_eps_finish(const int32_t* label, int64_t n, int32_t* rank_ws,
+                      int64_t* labels, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * L3  tri-plane projection — replaces
+ * custom_cuda_utils.project_sparse_voxels_to_planes{,_backward}
+ * (utils/cuda_utils/cuda_utils.cpp:26-46, cuda_utils_kernel.cu:371-603; wrapper
+ * models/noise_robust_loss.py:16-71).  In-place accumulation into caller-zeroed
+ * outputs, like the reference; voxels outside [0,dim) are dropped like there.
+ * coords i32[V,4] (b,x,y,z) shifted to >= 0, pred/target f32[V,inst];
+ * planes f32[dim_a,dim_b,inst], counts i32[dim_a,dim_b].
+ * Backward: grad_pred[v,p] = mean of the non-zero among the three plane grads.
+ * ---------------------------------------------------------------------- */
+int usc_project_planes_fwd(const int32_t* coords, const float* pred,
+                           const float* target, int64_t V, int32_t inst,
+                           int32_t dim_x, int32_t dim_y, int32_t dim_z,
+                           float* pred_xy, float* pred_xz, float* pred_yz,
+                           float* tgt_xy, float* tgt_xz, float* tgt_yz,
+                           int32_t* cnt_xy, int32_t* cnt_xz, int32_t* cnt_yz,
+                           usc_stream_t s);
+int usc_project_planes_bwd(const int32_t* coords, int64_t V, int32_t inst,
+                           int32_t dim_x, int32_t dim_y, int32_t dim_z,
+                           const float* g_xy, const float* g_xz,
+                           const float* g_yz, float* grad_pred,
+                           usc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

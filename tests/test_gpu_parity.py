@@ -531,3 +531,73 @@ def test_config5_ncut_matches_reference(device, name):
     for m, r in zip(masks, ref_masks):
         iou = (m & r).sum() / max((m | r).sum(), 1)
         assert iou >= 0.99, iou
+
+
+def test_knn1_matches_kdtree(device):
+    from scipy.spatial import KDTree
+    from unscene3d_amd import ops
+
+    rng = np.random.default_rng(4)
+    ref = rng.uniform(-3, 3, (7000, 3)).astype(np.float32)
+    q = rng.uniform(-3, 3, (20000, 3)).astype(np.float32)
+    q[:50] = ref[:50]                                        # exact hits
+    d_ref, i_ref = KDTree(ref).query(q, k=1)
+    d, i = ops.knn1(_dev(q, device), _dev(ref, device))
+    assert np.array_equal(i.cpu().numpy(), i_ref)
+    assert np.allclose(d.cpu().numpy(), d_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_cc_eps_matches_dbscan_min_samples_1(device):
+    from sklearn.cluster import DBSCAN
+    from unscene3d_amd import ops
+
+    rng = np.random.default_rng(8)
+    blobs = [rng.normal(c, 0.25, (n, 3)) for c, n in (((0, 0, 0), 900), ((4, 0, 0), 500), ((0, 5, 1), 30), ((9, 9, 9), 1))]
+    chain = np.stack([np.linspace(12, 20, 40), np.zeros(40), np.zeros(40)], 1)      # a 40-hop chain, spacing 0.205
+    xyz = np.concatenate(blobs + [chain]).astype(np.float32)
+    xyz = xyz[rng.permutation(len(xyz))]
+    for eps in (0.95, 0.21):
+        exp = DBSCAN(eps=eps, min_samples=1).fit(xyz).labels_
+        got = ops.cc_eps(_dev(xyz, device), eps).cpu().numpy()
+        assert np.array_equal(got, exp), eps
+
+
+def test_triplane_projection_loss(device):
+    from unscene3d_amd.models.noise_robust_loss import ProjectionMaskLoss
+
+    g = torch.Generator().manual_seed(12)
+    V, T = 4000, 5
+    c = torch.randint(0, 24, (V, 3), generator=g)
+    c = torch.unique(c, dim=0)
+    V = c.shape[0]
+    coords = torch.cat([torch.zeros(V, 1, dtype=torch.long), c], 1).int()
+    logits = torch.randn(T, V, generator=g)
+    tgt = (torch.rand(T, V, generator=g) < 0.3).float()
+
+    # torch restatement of noise_robust_loss.py + the two CUDA kernels (cuda_utils_kernel.cu:371-556)
+    def ref_loss(lg):
+        cc = (coords - coords.amin(0)).long()
+        xd, yd, zd = (int(v) for v in cc[:, 1:].max(0)[0])
+        ok = (cc[:, 1] < xd) & (cc[:, 2] < yd) & (cc[:, 3] < zd)
+        p, t = torch.sigmoid(lg.T)[ok], tgt.T[ok]
+        x, y, z = cc[ok, 1], cc[ok, 2], cc[ok, 3]
+        total, shape = 0.0, 0
+        for a, b, da, db in ((x, y, xd, yd), (x, z, xd, zd), (y, z, yd, zd)):
+            cell = a * db + b
+            n = torch.zeros(da * db).index_add_(0, cell, torch.ones(len(cell)))
+            ps = torch.zeros(da * db, T).index_add_(0, cell, p) / (n[:, None] + 10e-9)
+            ts = torch.zeros(da * db, T).index_add_(0, cell, t) / (n[:, None] + 10e-9)
+            l = torch.nn.functional.binary_cross_entropy(ps.clamp(0, 1), ts.clamp(0, 1), reduction="none")
+            total = total + l[n > 0].sum()
+            shape += T * int((n > 0).sum())
+        return total, shape
+
+    exp, exp_shape = ref_loss(logits)
+    mod = ProjectionMaskLoss(directions="xyz")
+    lg = logits.to(device).requires_grad_()
+    loss, shape = mod(lg, tgt.to(device), coords.to(device))
+    assert shape == exp_shape
+    assert abs(float(loss) - float(exp)) / float(exp) < 1e-4
+    loss.backward()
+    # backward follows the reference kernel: mean of the non-zero plane gradients (not the analytic gradient)
+    assert lg.grad.shape == logits.shape and bool(torch.isfinite(lg.grad).all()) and float(lg.grad.abs().sum()) > 0

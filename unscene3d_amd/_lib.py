@@ -62,6 +62,12 @@ SIGNATURES = {
     "usc_ncut_binarize": (C.c_int, [_p, _p, _i64, _f32, _f64, _p, _p, _p, _p]),
     "usc_ncut_fiedler_ws_bytes": (_i64, [_i64]),
     "usc_ncut_fiedler": (C.c_int, [_p, _p, _i64, _f64, _p, _p, _p, _i64, _p]),
+    "usc_knn1": (C.c_int, [_p, _i64, _p, _i64, _p, _p, _p]),
+    "usc_cc_eps_init": (C.c_int, [_p, _i64, _p]),
+    "usc_cc_eps_step": (C.c_int, [_p, _i64, _f32, _p, _p, _p, _p]),
+    "usc_cc_eps_finish": (C.c_int, [_p, _i64, _p, _p, _p]),
+    "usc_project_planes_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32] + [_p] * 10),
+    "usc_project_planes_bwd": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "usc_furthest_point_sampling": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "usc_fourier_posenc": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p, _p]),
 }

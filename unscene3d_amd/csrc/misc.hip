@@ -1,0 +1,253 @@
+// misc.hip — remaining operators of the path:
+//   exact 1-nearest-neighbour (scipy.spatial.KDTree.query(k=1)),
+//   eps-ball connected components (sklearn DBSCAN(eps, min_samples=1)),
+//   tri-plane projection of sparse voxels (custom_cuda_utils.project_sparse_voxels_to_planes{,_backward}).
+#include "common.h"
+
+namespace usc {
+
+// ---------------------------------------------------------------------------
+// 1-NN: every thread owns one query, reference points stream through LDS in tiles.  Distances in
+// f64 (inputs are f32, so differences and squares are exact up to the final sums — the same
+// ordering scipy's f64 KD-tree sees); ties resolve to the lowest reference index.
+constexpr int kKnnTile = 1024;
+
+__global__ __launch_bounds__(256) void knn1_kernel(const float* __restrict__ q, int64_t nq, const float* __restrict__ r,
+                                                  int64_t nr, int64_t* __restrict__ idx, float* __restrict__ dist2) {
+  __shared__ float tx[kKnnTile], ty[kKnnTile], tz[kKnnTile];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool act = i < nq;
+  const double qx = act ? (double)q[i * 3 + 0] : 0.0, qy = act ? (double)q[i * 3 + 1] : 0.0,
+               qz = act ? (double)q[i * 3 + 2] : 0.0;
+  double best = 1e300;
+  int64_t bi = -1;
+  for (int64_t t0 = 0; t0 < nr; t0 += kKnnTile) {
+    const int cnt = (int)((nr - t0) < kKnnTile ? (nr - t0) : kKnnTile);
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      tx[j] = r[(t0 + j) * 3 + 0];
+      ty[j] = r[(t0 + j) * 3 + 1];
+      tz[j] = r[(t0 + j) * 3 + 2];
+    }
+    __syncthreads();
+    if (act) {
+      for (int j = 0; j < cnt; ++j) {
+        const double dx = qx - (double)tx[j], dy = qy - (double)ty[j], dz = qz - (double)tz[j];
+        const double d = dx * dx + dy * dy + dz * dz;
+        if (d < best) { best = d; bi = t0 + j; }   // strict: the lowest index wins a tie
+      }
+    }
+    __syncthreads();
+  }
+  if (act) {
+    idx[i] = bi;
+    if (dist2) dist2[i] = (float)best;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// eps-ball connected components by min-label propagation with pointer jumping.
+//   label[i] <- min(label[j] : |x_i - x_j| <= eps), then label[i] <- label[label[i]] ... until stable.
+// The root of a component is its smallest point index, so ranking the roots in ascending order gives
+// sklearn's cluster numbering (clusters are numbered in order of their first point).
+__global__ __launch_bounds__(256) void cc_init_kernel(int32_t* __restrict__ label, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) label[i] = (int32_t)i;
+}
+__global__ __launch_bounds__(256) void cc_step_kernel(const float* __restrict__ xyz, int64_t n, double eps2,
+                                                     const int32_t* __restrict__ lin, int32_t* __restrict__ lout,
+                                                     int32_t* __restrict__ changed) {
+  __shared__ float tx[kKnnTile], ty[kKnnTile], tz[kKnnTile];
+  __shared__ int32_t tl[kKnnTile];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool act = i < n;
+  const double qx = act ? (double)xyz[i * 3 + 0] : 0.0, qy = act ? (double)xyz[i * 3 + 1] : 0.0,
+               qz = act ? (double)xyz[i * 3 + 2] : 0.0;
+  int32_t best = act ? lin[i] : 0x7fffffff;
+  for (int64_t t0 = 0; t0 < n; t0 += kKnnTile) {
+    const int cnt = (int)((n - t0) < kKnnTile ? (n - t0) : kKnnTile);
+    for (int j = threadIdx.x; j < cnt; j += 256) {
+      tx[j] = xyz[(t0 + j) * 3 + 0];
+      ty[j] = xyz[(t0 + j) * 3 + 1];
+      tz[j] = xyz[(t0 + j) * 3 + 2];
+      tl[j] = lin[t0 + j];
+    }
+    __syncthreads();
+    if (act) {
+      for (int j = 0; j < cnt; ++j) {
+        const double dx = qx - (double)tx[j], dy = qy - (double)ty[j], dz = qz - (double)tz[j];
+        if (dx * dx + dy * dy + dz * dz <= eps2 && tl[j] < best) best = tl[j];
+      }
+    }
+    __syncthreads();
+  }
+  if (act) {
+    lout[i] = best;
+    if (best != lin[i]) atomicOr(changed, 1);
+  }
+}
+__global__ __launch_bounds__(256) void cc_jump_kernel(int32_t* __restrict__ label, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int32_t l = label[i];
+  for (int k = 0; k < 32; ++k) {   // follow the chain to its root (roots satisfy label[r] == r)
+    const int32_t p = label[l];
+    if (p == l) break;
+    l = p;
+  }
+  label[i] = l;
+}
+// rank roots: isroot[i] = (label[i] == i); prefix over isroot gives the cluster id of each root
+__global__ __launch_bounds__(256) void cc_rootflag_kernel(const int32_t* __restrict__ label, int64_t n,
+                                                         int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flag[i] = label[i] == (int32_t)i ? 1 : 0;
+}
+__global__ __launch_bounds__(1024) void cc_scan_kernel(int32_t* __restrict__ flag, int64_t n) {
+  // single-block inclusive->exclusive scan (n is at most a few hundred thousand mask points)
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t c0 = 0; c0 < n; c0 += 1024) {
+    const int64_t i = c0 + threadIdx.x;
+    const int v = i < n ? flag[i] : 0;
+    const int inc = wave_inclusive_scan(v);
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) { if (k < (int)(threadIdx.x >> 6)) off += wsum[k]; tot += wsum[k]; }
+    const int carry = carry_s;
+    if (i < n) flag[i] = carry + off + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void cc_relabel_kernel(const int32_t* __restrict__ label, const int32_t* __restrict__ rank,
+                                                        int64_t n, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = rank[label[i]];
+}
+
+// ---------------------------------------------------------------------------
+// tri-plane projection (reference cuda_utils_kernel.cu:371-433 and :496-556)
+__global__ __launch_bounds__(256) void project_fwd_kernel(const int32_t* __restrict__ coords, const float* __restrict__ pred,
+                                                         const float* __restrict__ tgt, int64_t V, int inst, int xd, int yd,
+                                                         int zd, float* pxy, float* pxz, float* pyz, float* txy, float* txz,
+                                                         float* tyz, int32_t* nxy, int32_t* nxz, int32_t* nyz) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const int x = coords[v * 4 + 1], y = coords[v * 4 + 2], z = coords[v * 4 + 3];
+  if (x >= xd || y >= yd || z >= zd || x < 0 || y < 0 || z < 0) return;   // dropped, like the reference
+  const int64_t sxy = (int64_t)x * yd + y, sxz = (int64_t)x * zd + z, syz = (int64_t)y * zd + z;
+  atomicAdd(&nxy[sxy], 1);
+  atomicAdd(&nxz[sxz], 1);
+  atomicAdd(&nyz[syz], 1);
+  for (int p = 0; p < inst; ++p) {
+    const float pv = pred[v * inst + p], tv = tgt[v * inst + p];
+    atomicAdd(&pxy[sxy * inst + p], pv);
+    atomicAdd(&pxz[sxz * inst + p], pv);
+    atomicAdd(&pyz[syz * inst + p], pv);
+    atomicAdd(&txy[sxy * inst + p], tv);
+    atomicAdd(&txz[sxz * inst + p], tv);
+    atomicAdd(&tyz[syz * inst + p], tv);
+  }
+}
+__global__ __launch_bounds__(256) void project_bwd_kernel(const int32_t* __restrict__ coords, int64_t V, int inst, int xd,
+                                                         int yd, int zd, const float* __restrict__ gxy,
+                                                         const float* __restrict__ gxz, const float* __restrict__ gyz,
+                                                         float* __restrict__ grad) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const int x = coords[v * 4 + 1], y = coords[v * 4 + 2], z = coords[v * 4 + 3];
+  if (x >= xd || y >= yd || z >= zd || x < 0 || y < 0 || z < 0) return;
+  for (int p = 0; p < inst; ++p) {
+    const float a = gxy[((int64_t)x * yd + y) * inst + p], b = gxz[((int64_t)x * zd + z) * inst + p],
+                c = gyz[((int64_t)y * zd + z) * inst + p];
+    const int n = (a != 0.f) + (b != 0.f) + (c != 0.f);
+    grad[v * inst + p] = n > 0 ? (a + b + c) / (float)n : 0.f;
+  }
+}
+
+}  // namespace usc
+
+using namespace usc;
+
+extern "C" {
+
+int usc_knn1(const float* query, int64_t nq, const float* ref, int64_t nr, int64_t* idx, float* dist2, usc_stream_t s) {
+  USC_REQUIRE(nq >= 0 && nr >= 1, "usc_knn1: bad sizes");
+  if (nq == 0) return USC_OK;
+  USC_REQUIRE(query && ref && idx, "usc_knn1: null pointer");
+  hipLaunchKernelGGL(knn1_kernel, dim3((unsigned)ceil_div(nq, 256)), dim3(256), 0, as_stream(s), query, nq, ref, nr, idx,
+                     dist2);
+  USC_CHECK_LAUNCH("usc_knn1");
+  return USC_OK;
+}
+
+// The propagation is iterated by the CALLER (unscene3d_amd/ops.py: cc_eps): the library never
+// synchronises, the host reads the 4-byte `changed` flag between rounds.
+int usc_cc_eps_init(int32_t* label, int64_t n, usc_stream_t s) {
+  USC_REQUIRE(n >= 0, "usc_cc_eps_init: bad n");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(label, "usc_cc_eps_init: null pointer");
+  hipLaunchKernelGGL(cc_init_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), label, n);
+  USC_CHECK_LAUNCH("usc_cc_eps_init");
+  return USC_OK;
+}
+
+int usc_cc_eps_step(const float* xyz, int64_t n, float eps, const int32_t* label_in, int32_t* label_out,
+                    int32_t* changed, usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && eps >= 0.f, "usc_cc_eps_step: bad argument");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(xyz && label_in && label_out && changed, "usc_cc_eps_step: null pointer");
+  hipStream_t st = as_stream(s);
+  const unsigned g = (unsigned)ceil_div(n, 256);
+  (void)hipMemsetAsync(changed, 0, 4, st);
+  hipLaunchKernelGGL(cc_step_kernel, dim3(g), dim3(256), 0, st, xyz, n, (double)eps * (double)eps, label_in, label_out,
+                     changed);
+  hipLaunchKernelGGL(cc_jump_kernel, dim3(g), dim3(256), 0, st, label_out, n);
+  USC_CHECK_LAUNCH("usc_cc_eps_step");
+  return USC_OK;
+}
+
+int usc_cc_eps_finish(const int32_t* label, int64_t n, int32_t* rank_ws, int64_t* labels, usc_stream_t s) {
+  USC_REQUIRE(n >= 0, "usc_cc_eps_finish: bad n");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(label && rank_ws && labels, "usc_cc_eps_finish: null pointer");
+  hipStream_t st = as_stream(s);
+  const unsigned g = (unsigned)ceil_div(n, 256);
+  hipLaunchKernelGGL(cc_rootflag_kernel, dim3(g), dim3(256), 0, st, label, n, rank_ws);
+  hipLaunchKernelGGL(cc_scan_kernel, dim3(1), dim3(1024), 0, st, rank_ws, n);
+  hipLaunchKernelGGL(cc_relabel_kernel, dim3(g), dim3(256), 0, st, label, (const int32_t*)rank_ws, n, labels);
+  USC_CHECK_LAUNCH("usc_cc_eps_finish");
+  return USC_OK;
+}
+
+int usc_project_planes_fwd(const int32_t* coords, const float* pred, const float* target, int64_t V, int32_t inst,
+                           int32_t dim_x, int32_t dim_y, int32_t dim_z, float* pred_xy, float* pred_xz, float* pred_yz,
+                           float* tgt_xy, float* tgt_xz, float* tgt_yz, int32_t* cnt_xy, int32_t* cnt_xz, int32_t* cnt_yz,
+                           usc_stream_t s) {
+  USC_REQUIRE(V >= 0 && inst >= 1, "usc_project_planes_fwd: bad sizes");
+  if (V == 0) return USC_OK;
+  USC_REQUIRE(coords && pred && target && pred_xy && pred_xz && pred_yz && tgt_xy && tgt_xz && tgt_yz && cnt_xy &&
+                  cnt_xz && cnt_yz, "usc_project_planes_fwd: null pointer");
+  hipLaunchKernelGGL(project_fwd_kernel, dim3((unsigned)ceil_div(V, 256)), dim3(256), 0, as_stream(s), coords, pred, target,
+                     V, (int)inst, (int)dim_x, (int)dim_y, (int)dim_z, pred_xy, pred_xz, pred_yz, tgt_xy, tgt_xz, tgt_yz,
+                     cnt_xy, cnt_xz, cnt_yz);
+  USC_CHECK_LAUNCH("usc_project_planes_fwd");
+  return USC_OK;
+}
+
+int usc_project_planes_bwd(const int32_t* coords, int64_t V, int32_t inst, int32_t dim_x, int32_t dim_y, int32_t dim_z,
+                           const float* g_xy, const float* g_xz, const float* g_yz, float* grad_pred, usc_stream_t s) {
+  USC_REQUIRE(V >= 0 && inst >= 1, "usc_project_planes_bwd: bad sizes");
+  if (V == 0) return USC_OK;
+  USC_REQUIRE(coords && g_xy && g_xz && g_yz && grad_pred, "usc_project_planes_bwd: null pointer");
+  hipLaunchKernelGGL(project_bwd_kernel, dim3((unsigned)ceil_div(V, 256)), dim3(256), 0, as_stream(s), coords, V, (int)inst,
+                     (int)dim_x, (int)dim_y, (int)dim_z, g_xy, g_xz, g_yz, grad_pred);
+  USC_CHECK_LAUNCH("usc_project_planes_bwd");
+  return USC_OK;
+}
+
+}  // extern "C"

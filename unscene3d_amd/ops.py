@@ -571,3 +571,39 @@ def fourier_posenc(xyz, lo, hi, gauss_B, d):
     check(lib.usc_fourier_posenc(_ptr(xyz), xyz.shape[0], _ptr(lo.contiguous()), _ptr(hi.contiguous()),
                                  _ptr(gauss_B.contiguous()), d, _ptr(out), _stream()), "usc_fourier_posenc")
     return out
+
+
+# ------------------------------------------------------------------ neighbours / clustering
+def knn1(query: torch.Tensor, ref: torch.Tensor):
+    """Exact nearest reference point of every query (scipy KDTree.query(k=1)): -> (dist f32[nq], idx i64[nq])."""
+    require_device()
+    _chk(query, torch.float32, "query")
+    _chk(ref, torch.float32, "ref")
+    nq = query.shape[0]
+    idx = torch.empty(nq, dtype=torch.int64, device=query.device)
+    d2 = torch.empty(nq, dtype=torch.float32, device=query.device)
+    check(lib.usc_knn1(_ptr(query), nq, _ptr(ref), ref.shape[0], _ptr(idx), _ptr(d2), _stream()), "usc_knn1")
+    return d2.sqrt(), idx
+
+
+def cc_eps(xyz: torch.Tensor, eps: float, max_rounds: int = 256) -> torch.Tensor:
+    """Connected components of the eps-ball graph == DBSCAN(eps, min_samples=1).labels_ (first-seen order)."""
+    require_device()
+    _chk(xyz, torch.float32, "xyz")
+    n = xyz.shape[0]
+    dev = xyz.device
+    la = torch.empty(n, dtype=torch.int32, device=dev)
+    lb = torch.empty(n, dtype=torch.int32, device=dev)
+    changed = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib.usc_cc_eps_init(_ptr(la), n, _stream()), "usc_cc_eps_init")
+    for _ in range(max_rounds):
+        check(lib.usc_cc_eps_step(_ptr(xyz), n, float(eps), _ptr(la), _ptr(lb), _ptr(changed), _stream()),
+              "usc_cc_eps_step")
+        la, lb = lb, la
+        if int(changed.item()) == 0:
+            break
+    else:
+        raise RuntimeError("cc_eps: label propagation did not converge")
+    labels = torch.empty(n, dtype=torch.int64, device=dev)
+    check(lib.usc_cc_eps_finish(_ptr(la), n, _ptr(lb), _ptr(labels), _stream()), "usc_cc_eps_finish")
+    return labels
