@@ -220,7 +220,16 @@ __global__ __launch_bounds__(64 * kCompactWaves, 2) void gather_gemm_compact_ker
   const int i = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.y * BN;
   const int cin = p.cin, cout = p.cout, K = p.K;
-  const int64_t r0 = (int64_t)blockIdx.x * TM;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, speed only); give every XCD
+  // a CONTIGUOUS range of tiles so that the gathers of neighbouring tiles (which share most of their input
+  // rows once the rows are in z-order) hit the same 4 MB L2 instead of eight different ones.
+  int64_t tile;
+  {
+    const int64_t nwg = gridDim.x, bid = blockIdx.x;
+    const int64_t q = nwg / 8, r = nwg % 8, xcd = bid % 8, j = bid / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int64_t r0 = tile * TM;
 
   // ---- prologue: zero accumulators, compact the neighbour table of this tile per offset
   for (int e = threadIdx.x; e < TM * BN / 4; e += NT) reinterpret_cast<float4*>(accT)[e] = make_float4(0.f, 0.f, 0.f, 0.f);

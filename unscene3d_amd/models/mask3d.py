@@ -296,7 +296,10 @@ class SelfAttentionLayer(nn.Module):
     def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
         src = self.norm(tgt) if self.normalize_before else tgt
         q = k = _with_pos(src, query_pos)
-        upd = self.self_attn(q, k, value=src, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
+        # need_weights=False: same output; skips materialising/averaging the [B,Q,K] attention weights the
+        # reference computes and discards (`[0]`), and lets PyTorch take its fused SDPA path
+        upd = self.self_attn(q, k, value=src, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask,
+                             need_weights=False)[0]
         out = tgt + self.dropout(upd)
         return out if self.normalize_before else self.norm(out)
 
@@ -316,7 +319,8 @@ class CrossAttentionLayer(nn.Module):
     def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None):
         src = self.norm(tgt) if self.normalize_before else tgt
         upd = self.multihead_attn(query=_with_pos(src, query_pos), key=_with_pos(memory, pos), value=memory,
-                                  attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)[0]
+                                  attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask,
+                                  need_weights=False)[0]
         out = tgt + self.dropout(upd)
         return out if self.normalize_before else self.norm(out)
 
