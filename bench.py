@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--mode", choices=["mask3d", "backbone"], default="mask3d",
                     help="mask3d: BASELINE.json configs[2] full self-train step (the metric's config); "
                          "backbone: configs[1] Res16UNet34C fwd+bwd only")
+    ap.add_argument("--no-graphs", action="store_true", help="do not capture the decoder passes as HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-voxels", type=int, default=15_000)
     return ap.parse_args()
@@ -103,6 +104,8 @@ def make_mask3d_step(args, dev, rank, world):
     # raw scene arrays resident in HBM before the timed region (the collate reads them from there)
     sample = tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) if isinstance(x, np.ndarray) and i in (0, 1, 2)
                    else x for i, x in enumerate(sample))
+    if not args.no_graphs:
+        module.model.enable_decoder_graphs(batch_size=1, device=dev)
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(dev),
                                       spatial_sort=False)
 

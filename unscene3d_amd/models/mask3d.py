@@ -98,6 +98,43 @@ class Mask3D(nn.Module):
         self.randperm = lambda n, device: torch.randperm(n, device=device)
 
     # ------------------------------------------------------------------
+    def _eager_pass(self, dec, i):
+        return _DecoderPass(self.lin_squeeze[dec][i], self.cross_attention[dec][i], self.self_attention[dec][i],
+                            self.ffn_attention[dec][i], self.level_embed.weight[i] if self.use_level_embed else None,
+                            self.num_heads)
+
+    def _decoder_pass(self, decoder_counter, dec, i):
+        """The callable for pass (decoder_counter, level i): a captured HIP graph when enabled, else eager."""
+        graphs = getattr(self, "_graphed_passes", None)
+        if graphs is not None:
+            return graphs[decoder_counter * self.num_levels + i]
+        return self._eager_pass(dec, i)
+
+    def enable_decoder_graphs(self, batch_size: int, device):
+        """Capture the 12 decoder passes (forward and backward) as HIP graphs for the static shapes
+        [batch_size, sample_sizes[hlevel]] — valid while every scene has at least that many voxels per level
+        (checked per call; otherwise the eager path runs).  Weights stay shared: the graphs read the live
+        parameter tensors."""
+        passes, samples = [], []
+        sizes = self.backbone.PLANES[-5:]
+        B, Q, d = batch_size, self.num_queries, self.mask_dim
+        for decoder_counter in range(self.num_decoders):
+            dec = 0 if self.shared_decoder else decoder_counter
+            for i, hlevel in enumerate(self.hlevels):
+                K = self.sample_sizes[hlevel]
+                passes.append(self._eager_pass(dec, i))
+                samples.append((torch.zeros(B, Q, d, device=device, requires_grad=True),
+                                torch.zeros(Q, B, d, device=device, requires_grad=True),
+                                torch.zeros(B, K, sizes[hlevel], device=device, requires_grad=True),
+                                torch.zeros(B, K, Q, device=device, dtype=torch.bool),
+                                torch.zeros(B, K, d, device=device)))
+        graphed = torch.cuda.make_graphed_callables(tuple(passes), tuple(samples), allow_unused_input=True)
+        self._graph_shapes = [tuple(a.shape for a in smp) for smp in samples]
+        object.__setattr__(self, "_graphed_passes", list(graphed))
+
+    def disable_decoder_graphs(self):
+        object.__setattr__(self, "_graphed_passes", None)
+
     def get_pos_encs(self, coords):
         """Per level, per scene Fourier encodings [N_l, d] of the pooled raw coordinates
         (reference :183-198; same [level][0][scene] nesting)."""
@@ -203,17 +240,15 @@ class Mask3D(nn.Module):
                 batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
                 batched_attn = torch.logical_or(batched_attn, torch.stack(mask_idx)[..., None])
 
-                src_pcd = self.lin_squeeze[dec][i](batched_aux.permute(1, 0, 2))
-                if self.use_level_embed:
-                    src_pcd = src_pcd + self.level_embed.weight[i]
-
-                output = self.cross_attention[dec][i](
-                    queries.permute(1, 0, 2), src_pcd,
-                    memory_mask=batched_attn.repeat_interleave(self.num_heads, dim=0).permute(0, 2, 1),
-                    memory_key_padding_mask=None, pos=batched_pos_enc.permute(1, 0, 2), query_pos=query_pos)
-                output = self.self_attention[dec][i](output, tgt_mask=None, tgt_key_padding_mask=None,
-                                                     query_pos=query_pos)
-                queries = self.ffn_attention[dec][i](output).permute(1, 0, 2)
+                step_fn = self._decoder_pass(decoder_counter, dec, i)
+                if getattr(self, "_graphed_passes", None) is not None:
+                    want = self._graph_shapes[decoder_counter * self.num_levels + i]
+                    have = (queries.shape, query_pos.shape, batched_aux.shape, batched_attn.shape,
+                            batched_pos_enc.shape)
+                    if tuple(have) != tuple(want):
+                        step_fn = self._eager_pass(dec, i)
+                queries = step_fn(queries, query_pos, batched_aux.contiguous(), batched_attn.contiguous(),
+                                  batched_pos_enc.contiguous())
 
                 predictions_class.append(output_class)
                 predictions_mask.append(outputs_mask)
@@ -269,6 +304,29 @@ class Mask3D(nn.Module):
     @torch.jit.unused
     def _set_aux_loss(self, outputs_class, outputs_seg_masks):
         return [{"pred_logits": a, "pred_masks": b} for a, b in zip(outputs_class[:-1], outputs_seg_masks[:-1])]
+
+
+class _DecoderPass(nn.Module):
+    """lin_squeeze -> masked cross attention -> self attention -> FFN of one (decoder, level) pass
+    (reference mask3d.py:351-373).  Pure tensor-in / tensor-out with static shapes whenever every scene
+    has at least `sample_sizes[hlevel]` voxels at that level, which makes it capturable as a HIP graph
+    (Mask3D.enable_decoder_graphs): ~45 forward and ~90 backward launches per pass become one graph launch
+    each, removing most of the host launch overhead of the 12 passes."""
+
+    def __init__(self, squeeze, cross, self_attn, ffn, level_embed, num_heads):
+        super().__init__()
+        self.squeeze, self.cross, self.self_attn, self.ffn = squeeze, cross, self_attn, ffn
+        self.level_embed, self.num_heads = level_embed, num_heads
+
+    def forward(self, queries, query_pos, batched_aux, batched_attn, batched_pos_enc):
+        src = self.squeeze(batched_aux.permute(1, 0, 2))
+        if self.level_embed is not None:
+            src = src + self.level_embed
+        out = self.cross(queries.permute(1, 0, 2), src,
+                         memory_mask=batched_attn.repeat_interleave(self.num_heads, dim=0).permute(0, 2, 1),
+                         memory_key_padding_mask=None, pos=batched_pos_enc.permute(1, 0, 2), query_pos=query_pos)
+        out = self.self_attn(out, tgt_mask=None, tgt_key_padding_mask=None, query_pos=query_pos)
+        return self.ffn(out).permute(1, 0, 2)
 
 
 def _with_pos(t, pos):
