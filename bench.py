@@ -265,6 +265,16 @@ def main():
             step(1)
             torch.cuda.synchronize()
         roof = prof.roofline(MFMA_F32_PEAK_TFLOPS)
+        if roof is not None:
+            # PMC counters cannot be read from inside the process; `traffic` is the per-launch HBM byte count
+            # of the same kernel from the committed rocprofv3 --pmc passes over this very command.
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    ent = json.load(f).get(roof["kernel"])
+                if ent:
+                    roof["traffic"] = ent["bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/pmc_traffic.json"
 
     if rank == 0:
         line = {

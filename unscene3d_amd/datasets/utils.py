@@ -44,11 +44,11 @@ def get_instance_freemasks(list_freemasks, list_segments=None):
     reproduced here.  Vectorised over the K columns (one host sync per scene instead of K)."""
     target = []
     for b, table in enumerate(list_freemasks):
-        cols = table[:, 1:-1] != 0                                  # [N, K] hard masks
-        keep = torch.nonzero(cols.any(0)).reshape(-1)               # non-empty columns (host sync)
+        colsT = (table[:, 1:-1] != 0).T.contiguous()                # [K, N] hard masks (row reductions are fast)
+        keep = torch.nonzero(colsT.any(1)).reshape(-1)              # non-empty columns (host sync)
         if keep.numel() == 0:
             return []
-        masks = cols[:, keep].T.contiguous()                        # [T, N]
+        masks = colsT[keep]                                         # [T, N]
         entry = {"labels": torch.ones(keep.numel(), dtype=torch.int64, device=table.device), "masks": masks}
         if list_segments:
             S = list_segments[b].shape[0]
