@@ -163,3 +163,31 @@ def make_scene(seed: int, target_voxels: int = 150_000, points_per_cell: float =
         "xyz": pts.astype(np.float64), "colors": colors, "segment_ids": segment_ids, "masks": masks,
         "segment_connectivity": conn, "n_objects": n_obj, "n_segments": S, "n_voxels_estimate": nv,
     }
+
+
+def make_segment_scene(seed: int, side: int = 25, dims=(384, 96), n_objects: int = 16):
+    """Config-5 inputs: a side x side grid of oversegmentation segments (side=25 -> 625, the
+    "600-segment scene"), `n_objects` compact rectangular objects of distinct sizes on a background cluster,
+    per-modality features = cluster centre + 0.25 sigma noise (dims: DINO-like 384, CSC-like 96), and the
+    4-neighbour directed segment connectivity.  -> (feats list of f32[S,d], conn i64[E,2], label i64[S])."""
+    rng = np.random.default_rng(seed)
+    S = side * side
+    label = np.zeros((side, side), np.int64)
+    for k in range(n_objects):
+        h, w = 2 + (k % 4), 3 + (k // 3)
+        for _ in range(200):
+            r, c = int(rng.integers(1, side - h - 1)), int(rng.integers(1, side - w - 1))
+            if not label[r - 1:r + h + 1, c - 1:c + w + 1].any():
+                label[r:r + h, c:c + w] = k + 1
+                break
+    label = label.reshape(-1)
+    feats = []
+    for d in dims:
+        cent = rng.normal(size=(n_objects + 1, d))
+        feats.append((cent[label] + 0.25 * rng.normal(size=(S, d))).astype(np.float32))
+    idx = np.arange(S).reshape(side, side)
+    right = np.stack([idx[:, :-1].reshape(-1), idx[:, 1:].reshape(-1)], 1)
+    down = np.stack([idx[:-1].reshape(-1), idx[1:].reshape(-1)], 1)
+    und = np.concatenate([right, down])
+    conn = np.concatenate([und, und[:, ::-1]]).astype(np.int64)
+    return feats, conn, label
