@@ -164,7 +164,7 @@ def import_reference_ncut():
     return importlib.import_module("unscene3d_pseudo_main")
 
 
-def planted_scene(seed, side, dims, n_objects, pts_per_seg=6):
+def planted_scene(seed, side, dims, n_objects, pts_per_seg=6, noise=None):
     """Config-5 inputs: a side x side grid of segments; `n_objects` compact rectangular
     objects of DISTINCT sizes (distinct sizes keep the small eigenvalues of the weakly coupled blocks
     simple) scattered over a background cluster that separates them spatially, like furniture on a floor."""
@@ -183,10 +183,13 @@ def planted_scene(seed, side, dims, n_objects, pts_per_seg=6):
     label = label.reshape(-1)
     gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
     gx, gy = gx.reshape(-1), gy.reshape(-1)
+    # noise=None: every segment 0.25 sigma (clean, block-constant affinities -> highly degenerate spectra);
+    # noise=(lo, hi): per-segment sigma ~ U(lo, hi) -> irregular thresholded graphs like real DINO/CSC features
+    sig = 0.25 if noise is None else rng.uniform(noise[0], noise[1], size=(S, 1))
     feats = []
     for d in dims:
         cent = rng.normal(size=(n_objects + 1, d))
-        feats.append((cent[label] + 0.25 * rng.normal(size=(S, d))).astype(np.float32))
+        feats.append((cent[label] + sig * rng.normal(size=(S, d))).astype(np.float32))
     conn = []
     for i in range(S):
         for da, db in ((1, 0), (0, 1)):
@@ -203,8 +206,10 @@ def planted_scene(seed, side, dims, n_objects, pts_per_seg=6):
 
 def make_ncut(ref):
     out = {}
-    for name, (side, dims, k, tau) in {"single": (15, (96,), 8, 0.6), "dual": (25, (384, 96), 16, 0.6)}.items():
-        feats, conn, seg_ids, coords, label, placed = planted_scene(50 + side, side, dims, k)
+    cases = {"single": (15, (96,), 8, 0.6, None), "dual": (25, (384, 96), 16, 0.6, None),
+             "irregular": (25, (384, 96), 16, 0.6, (0.3, 1.2))}
+    for name, (side, dims, k, tau, noise) in cases.items():
+        feats, conn, seg_ids, coords, label, placed = planted_scene(50 + side, side, dims, k, noise=noise)
         S = side * side
         tf = [torch.from_numpy(f) for f in feats]
         mk = lambda: tf[0].clone() if len(tf) == 1 else (tf[0].clone(), tf[1].clone())

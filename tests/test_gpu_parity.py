@@ -533,6 +533,42 @@ def test_config5_ncut_matches_reference(device, name):
         assert iou >= 0.99, iou
 
 
+def test_config5_ncut_irregular_scene_product_path(device):
+    """Config 5 on a 625-segment, two-modality scene with per-segment noise levels (irregular thresholded
+    graphs, like real DINO/CSC features): here the Householder chain has no near-breakdowns, LAPACK's
+    eigenvector sign is well defined, and the PRODUCT path (no hook) must reproduce the reference run:
+    per-iteration eigenvector WITH sign, and the final masks at IoU >= 0.99."""
+    from unscene3d_amd.pseudo_masks import ncut
+
+    name = "irregular"
+    z, feats, S, ref_masks = _ncut_case(name)
+    tf = [_dev(f, device) for f in feats]
+    tau = float(z[f"{name}/tau"])
+    checked = 0
+    for it in range(int(z[f"{name}/n_iter"])):
+        w = z[f"{name}/it{it}/evals"]
+        if (w[1] - w[0]) / max(w[1], 1e-300) < 1e-3:
+            continue
+        A_ref = np.unpackbits(z[f"{name}/it{it}/A"], axis=1)[:, :S].astype(bool)
+        painted = ~A_ref.any(1)
+        pt = torch.from_numpy(painted).to(device)
+        A, D = ncut.get_affinity_matrix(tuple(f * (~pt)[:, None] for f in tf), tau=tau, eps=1e-5, painting=pt)
+        Ad = A.cpu().numpy().astype(bool)
+        assert (Ad != A_ref).sum() <= max(2, int(2e-5 * S * S)), (it, int((Ad != A_ref).sum()))
+        if (Ad != A_ref).sum() == 0:
+            _, vec = ncut.second_smallest_eigenvector(A, D)
+            c = float(vec @ (z[f"{name}/it{it}/deg"] * z[f"{name}/it{it}/vec"]))
+            assert c > 0.99999, (it, c, int(painted.sum()))
+            checked += 1
+    assert checked >= 10
+    masks = ncut.unscene3d((tf[0], tf[1]), torch.arange(S), torch.from_numpy(z[f"{name}/conn"]), affinity_tau=tau,
+                           max_number_of_instances=20, min_segment_size=4, separation_mode="max",
+                           max_extent_ratio=0.8)
+    assert masks.shape[0] == ref_masks.shape[0], (masks.shape, ref_masks.shape)
+    for m, r in zip(masks, ref_masks):
+        assert (m & r).sum() / max((m | r).sum(), 1) >= 0.99
+
+
 def test_knn1_matches_kdtree(device):
     from scipy.spatial import KDTree
     from unscene3d_amd import ops

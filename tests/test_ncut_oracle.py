@@ -19,7 +19,7 @@ def _case(z, name, it=0):
 
 def test_affinity_and_eigenvector_match_reference():
     z = np.load(GOLD)
-    for name in ("single", "dual"):
+    for name in ("single", "dual", "irregular"):
         feats, S, A0, deg0, vec0, tau = _case(z, name)
         A, d = NR.affinity(feats[0] if len(feats) == 1 else (feats[0], feats[1]), tau)
         assert np.array_equal(A > 0.5, A0)
@@ -42,3 +42,16 @@ def test_oracle_loop_reproduces_reference_masks_up_to_lapack_sign():
     masks = NR.unscene3d_ref(f.clone(), np.arange(S), z[f"{name}/conn"], tau=float(z[f"{name}/tau"]))
     assert masks.shape[1] == S and masks.shape[0] >= 1
     assert (masks.sum(0) <= 1).all() and (masks.sum(1) > 0).all()
+
+
+def test_oracle_loop_reproduces_reference_masks_on_irregular_scene():
+    """Per-segment noise levels give irregular graphs without near-breakdowns in the tridiagonalisation:
+    LAPACK's sign is then well defined and the restated loop must give exactly the reference's masks."""
+    z = np.load(GOLD)
+    name = "irregular"
+    f = tuple(torch.from_numpy(z[f"{name}/feat{j}"]) for j in range(2))
+    S = f[0].shape[0]
+    masks = NR.unscene3d_ref(f, np.arange(S), z[f"{name}/conn"], tau=float(z[f"{name}/tau"]))
+    ref = np.unpackbits(z[f"{name}/masks"], axis=1)[:int(z[f"{name}/n_masks"]), :S].astype(bool)
+    assert masks.shape == ref.shape
+    assert np.array_equal(masks, ref)

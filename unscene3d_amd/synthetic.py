@@ -165,11 +165,12 @@ def make_scene(seed: int, target_voxels: int = 150_000, points_per_cell: float =
     }
 
 
-def make_segment_scene(seed: int, side: int = 25, dims=(384, 96), n_objects: int = 16):
+def make_segment_scene(seed: int, side: int = 25, dims=(384, 96), n_objects: int = 16, noise=(0.3, 1.2)):
     """Config-5 inputs: a side x side grid of oversegmentation segments (side=25 -> 625, the
     "600-segment scene"), `n_objects` compact rectangular objects of distinct sizes on a background cluster,
-    per-modality features = cluster centre + 0.25 sigma noise (dims: DINO-like 384, CSC-like 96), and the
-    4-neighbour directed segment connectivity.  -> (feats list of f32[S,d], conn i64[E,2], label i64[S])."""
+    per-modality features = cluster centre + per-segment sigma ~ U(noise) noise (dims: DINO-like 384, CSC-like
+    96; irregular thresholded graphs like real features rather than block-constant ones), and the 4-neighbour
+    directed segment connectivity.  -> (feats list of f32[S,d], conn i64[E,2], label i64[S])."""
     rng = np.random.default_rng(seed)
     S = side * side
     label = np.zeros((side, side), np.int64)
@@ -181,10 +182,11 @@ def make_segment_scene(seed: int, side: int = 25, dims=(384, 96), n_objects: int
                 label[r:r + h, c:c + w] = k + 1
                 break
     label = label.reshape(-1)
+    sig = rng.uniform(noise[0], noise[1], size=(S, 1))
     feats = []
     for d in dims:
         cent = rng.normal(size=(n_objects + 1, d))
-        feats.append((cent[label] + 0.25 * rng.normal(size=(S, d))).astype(np.float32))
+        feats.append((cent[label] + sig * rng.normal(size=(S, d))).astype(np.float32))
     idx = np.arange(S).reshape(side, side)
     right = np.stack([idx[:, :-1].reshape(-1), idx[:, 1:].reshape(-1)], 1)
     down = np.stack([idx[:-1].reshape(-1), idx[1:].reshape(-1)], 1)
