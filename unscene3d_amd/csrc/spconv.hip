@@ -200,11 +200,16 @@ __global__ __launch_bounds__(256) void gather_gemm_aligned_kernel(GemmParams p) 
 // Flushes are serialised by an LDS ticket in item order, which makes the fp32 summation order —
 // and therefore the result — bit-reproducible without float atomics.
 constexpr int kMaxK = 27;
+constexpr int kMaxItems = kMaxK * 8;   // TM <= 256 -> at most 8 groups of 32 pairs per offset
+constexpr int kZeroRowFloats = 4096;
+// padding lanes of a pair group gather from this all-zero row instead of selecting zeros after the load
+// (a select on a loaded register makes the compiler wait for the load — and everything older — first)
+__device__ float g_zero_row[kZeroRowFloats + 8];
 
 constexpr int kCompactWaves = 8;   // one 512-thread workgroup per CU, two waves per SIMD
 
 template <int NB>
-__global__ __launch_bounds__(64 * kCompactWaves, 2) void gather_gemm_compact_kernel(GemmParams p) {
+__global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_kernel(GemmParams p) {
   constexpr int BN = NB * 32;
   constexpr int NT = 64 * kCompactWaves;
   const int TM = p.TM;   // rows per tile (multiple of 4, <= 256), chosen so that tiles fill whole CU rounds
@@ -214,7 +219,10 @@ __global__ __launch_bounds__(64 * kCompactWaves, 2) void gather_gemm_compact_ker
   int32_t* cnt = pl_in + kMaxK * TM;                                   // [32]
   int32_t* item_start = cnt + 32;                                      // [32]
   volatile int32_t* ticket = item_start + 32;                          // [1] (+3 pad)
+  typedef __attribute__((address_space(3))) volatile int32_t lds_vint;
+  lds_vint* ticket3 = (lds_vint*)ticket;
   uint8_t* pl_loc = reinterpret_cast<uint8_t*>(item_start + 36);       // [K][TM]
+  int32_t* item_desc = reinterpret_cast<int32_t*>(pl_loc + kMaxK * TM);  // [kMaxItems]: pbase | npairs << 16 | k << 24
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -257,77 +265,63 @@ __global__ __launch_bounds__(64 * kCompactWaves, 2) void gather_gemm_compact_ker
     const int items = (c + 31) >> 5;
     const int inc = wave_inclusive_scan(items);
     if (lane < 32) item_start[lane] = inc - items;   // exclusive prefix; entries >= K hold the total
+    if (lane < K) {
+      for (int g = 0; g < items; ++g) {
+        const int np = c - g * 32 < 32 ? c - g * 32 : 32;
+        item_desc[inc - items + g] = (lane * TM + g * 32) | (np << 16) | (lane << 24);
+      }
+    }
   }
   __syncthreads();
   const int total_items = item_start[K < 32 ? K : 31] + (K >= 32 ? 0 : 0);
-  const int my_start = (lane < 32) ? item_start[lane] : 0x7fffffff;
 
-  // ---- main loop: software-pipelined over the flattened (item, Cin-chunk) steps of this wave.
-  // Register set X feeds the matrix cores while set Y receives the next step's gathers, then swap.
-  struct Step {
-    const float* arow;  // gathered input row of lane (i,h) (+4h), already offset to the chunk
-    const float* wk;    // weight slice of the chunk for this lane's columns
-    int loc;            // local output row of pair i (or -1)
-    int item;           // work item index (ticket) ; -1 = past the end (dummy loads, no MFMA)
-    int chunk;          // Cin chunk inside the item
-    bool valid;
+  // ---- main loop.  A wave walks its items (item = wave, wave + 8, ...); one item = 32 real pairs of one
+  // offset k, reduced over Cin in "quads" of 8 input channels (one 16-byte load of the gathered row per lane
+  // feeds four MFMA k-steps; each k-step needs NB weight operands = one NB-dword load).
+  // The loads run AHEAD of the matrix cores through two small register rings — gathered rows kDA quads
+  // ahead (HBM / Infinity-Cache latency), weights kDB quads ahead (L2 latency) — and the rings run across
+  // item boundaries, so the next item's first gathers are in flight while this item is flushed.  (The first
+  // version issued a quad's loads right before its MFMAs: the ISA showed `s_waitcnt vmcnt(0)` in front of
+  // every k-step, i.e. one exposed L2 round trip per 3 MFMAs, MFMA pipe 50 % busy.)
+  struct Item {
+    const float* arow;  // gathered input row of lane (i,h) (+4h); padding lanes: the zero row
+    const float* wk;    // packed weight slice of offset k for this column block (wave-uniform, lives in SGPRs)
+    int pbase;          // index of this item's pair 4h in the offset's pair list (flush: local output rows)
+    int npairs;         // real pairs of the item (<= 32)
+    int item;           // work item index (= flush ticket); -1 = past the end (dummy loads, no flush)
   };
-  const int nch = cin >> 5;
-  auto first_step = [&](int item) -> Step {
-    Step st;
-    st.chunk = 0;
+  const int nq = cin >> 3;   // quads per item (multiple of 4)
+  // this lane's byte offset inside a weight slice: rows 4h.., columns n0 + NB*i..  (constant for the kernel, so
+  // every weight load is  SGPR base + this VGPR  and costs no vector address arithmetic)
+  const float* wp_cb = p.W + (int64_t)blockIdx.y * K * cin * BN;   // p.W: weights packed by weight_pack_kernel
+  auto make_item = [&](int item) -> Item {
+    Item st;
     if (item >= total_items) {
-      st.item = -1; st.loc = -1; st.valid = false;
-      st.arow = p.in + 4 * h;
-      st.wk = p.W + (int64_t)(4 * h) * cout + n0 + NB * i;
+      st.item = -1; st.pbase = 0; st.npairs = 0;
+      st.arow = g_zero_row + 4 * h;
+      st.wk = wp_cb;
       return st;
     }
-    const unsigned long long le = __ballot(lane < K && my_start <= item);
-    const int k = 63 - __clzll(le);   // last offset whose first item index <= item
-    const int g = item - item_start[k];
-    const int npairs = cnt[k] - g * 32;
-    st.valid = i < npairs;
-    const int pidx = k * TM + g * 32 + i;
-    const int64_t in_row = st.valid ? (int64_t)pl_in[pidx] : 0;
-    st.loc = st.valid ? (int)pl_loc[pidx] : -1;
+    const int d = __builtin_amdgcn_readfirstlane(item_desc[item]);
+    const int k = d >> 24, npairs = (d >> 16) & 63, pb0 = d & 0xffff;
+    const int pidx = pb0 + i;
+    st.pbase = pb0 + 4 * h;
+    st.npairs = npairs;
     st.item = item;
-    st.arow = p.in + in_row * (int64_t)cin + 4 * h;
-    st.wk = p.W + (int64_t)k * cin * cout + (int64_t)(4 * h) * cout + n0 + NB * i;
+    st.arow = (i < npairs ? p.in + (int64_t)pl_in[pidx] * (int64_t)cin : g_zero_row) + 4 * h;
+    st.wk = wp_cb + (int64_t)k * cin * BN;
     return st;
   };
-  auto next_step = [&](const Step& c) -> Step {
-    if (c.item < 0) return c;
-    if (c.chunk + 1 < nch) {
-      Step n = c;
-      n.chunk = c.chunk + 1;
-      n.arow = c.arow + 32;
-      n.wk = c.wk + (int64_t)32 * cout;
-      return n;
-    }
-    return first_step(c.item + kCompactWaves);
-  };
-  auto issue_loads = [&](const Step& st, float4 (&a)[4], float (&b)[16][NB]) {
-#ifdef USC_ABLATE_A
-    a[0] = *reinterpret_cast<const float4*>(st.arow);
-#pragma unroll
-    for (int t = 1; t < 4; ++t) a[t] = a[0];
-#else
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(st.arow + 8 * t);
+#ifndef USC_KDB
+#define USC_KDB 1
 #endif
-#ifdef USC_ABLATE_B
-    load_b<NB>(st.wk, b[0]);
-#pragma unroll
-    for (int q = 1; q < 16; ++q)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) b[q][nb] = b[0][nb] + (float)q;
-#else
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) load_b<NB>(st.wk + (int64_t)(8 * t + j) * cout, b[4 * t + j]);
+#ifndef USC_KRB
+#define USC_KRB 2
 #endif
-  };
+  constexpr int kDA = 3, kDB = USC_KDB;  // prefetch distances in quads
+  constexpr int kRA = 4, kRB = USC_KRB;  // ring sizes (the quad loop is unrolled by 4: static slots)
+  float4 ra[kRA];
+  float4 rb[kRB][NB];   // [slot][accumulator] -> the 4 k-steps of the quad
   f32x16 acc[NB];
   auto zero_acc = [&]() {
 #pragma unroll
@@ -335,52 +329,83 @@ __global__ __launch_bounds__(64 * kCompactWaves, 2) void gather_gemm_compact_ker
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
   };
-  auto run_mfma = [&](const Step& st, float4 (&a)[4], float (&b)[16][NB]) {
-    if (!st.valid) {
+  auto load_a = [&](float4& dst, const float* src) {
+#ifdef USC_ABLATE_A
+    dst = make_float4(1.f, 2.f, 3.f, 4.f);
+#else
+    dst = *reinterpret_cast<const float4*>(src);
+#endif
+  };
+  auto load_bq = [&](float4 (&dst)[NB], const float* wq) {   // wq: uniform address of the quad's packed weights
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const float av[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = MFMA32(av[j], b[4 * t + j][nb], acc[nb]);
+    for (int nb = 0; nb < NB; ++nb) {
+#ifdef USC_ABLATE_B
+      dst[nb] = make_float4(1.f + nb, 2.f + nb, 3.f + nb, 4.f + nb);
+#else
+      dst[nb] = *reinterpret_cast<const float4*>(wq + nb * 256 + lane * 4);
+#endif
     }
   };
-  auto flush = [&](const Step& st) {
+  auto flush = [&](const Item& st) {
 #ifdef USC_ABLATE_FLUSH
+    float sink = 0.f;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(acc[nb]));
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sink += acc[nb][r];
+    if (sink == 1.2345e-30f) accT[lane] = sink;
     zero_acc();
     return;
 #endif
-    // ordered flush into the LDS accumulators (ticket == item index)
+    // ordered flush into the LDS accumulators (ticket == item index).  The ticket lives in LDS and is polled
+    // with ds_read (an address_space(3) pointer: the generic `volatile int*` compiled to flat_load sc0 sc1 +
+    // s_waitcnt vmcnt(0), draining the prefetch rings at every poll).  LDS executes one wave's instructions in
+    // issue order, so the hand-off needs no memory fence — which would also wait for vmcnt(0) — only the
+    // compiler barriers and lgkmcnt waits below.
+#ifndef USC_ABLATE_TICKET
     if (lane == 0) {
-      while (*ticket != st.item) __builtin_amdgcn_s_sleep(1);
+      while (*ticket3 != st.item) __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+#ifndef USC_NO_SETPRIO
+    // the ticket holder is the workgroup's critical path: without priority its ~300 LDS/VALU instructions queue
+    // behind the other waves' MFMAs (issue is arbitrated by priority, then age) and the serialised section
+    // stretched to ~10k cycles per item — measured: ticket alone +3 %, RMW alone +8 %, both together +77 %.
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    asm volatile("" ::: "memory");
     // Plain LDS read-add-write; the ticket gives this wave exclusive, ordered access (ds_add_f32
-    // atomics measured 2x slower for the whole kernel).  All reads are issued before the first
-    // dependent add so the 16 row updates pipeline instead of paying one LDS round trip each —
-    // the serialised flush is the critical section of the workgroup.
+    // atomics measured 2x slower for the whole kernel).  The reads of a batch of rows are issued
+    // before the first dependent add so the row updates pipeline instead of paying one LDS round
+    // trip each — the serialised flush is the critical section of the workgroup.
+    constexpr int kFB = 4;   // rows per batch (register budget: the load rings stay live across the flush)
+#ifdef USC_ABLATE_RMW
+    {
+      float sink = 0.f;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      int lrs[8];
-      float old[8][NB];
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int r = half * 8 + q;
-        lrs[q] = __shfl(st.loc, acc_row(r, h), 64);
+        for (int r = 0; r < 16; ++r) sink += acc[nb][r];
+      if (sink == 1.2345e-30f) accT[lane] = sink;
+    }
+#else
+#pragma unroll
+    for (int part = 0; part < 16 / kFB; ++part) {
+      int lrs[kFB];
+      float old[kFB][NB];
+#pragma unroll
+      for (int q = 0; q < kFB; ++q) {
+        const int r = part * kFB + q;
+        const int prow = (r & 3) + 8 * (r >> 2);   // pair index inside the item is prow + 4h (MFMA C layout)
+        lrs[q] = (prow + 4 * h < st.npairs) ? (int)pl_loc[st.pbase + prow] : -1;
         const float* src = accT + (lrs[q] >= 0 ? lrs[q] : 0) * BN + NB * i;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) old[q][nb] = src[nb];
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int r = half * 8 + q;
+      for (int q = 0; q < kFB; ++q) {
+        const int r = part * kFB + q;
         if (lrs[q] >= 0) {
           float* dst = accT + lrs[q] * BN + NB * i;
 #pragma unroll
@@ -388,23 +413,69 @@ __global__ __launch_bounds__(64 * kCompactWaves, 2) void gather_gemm_compact_ker
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // LDS updates done before the ticket moves
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS updates are done before the ticket moves
+#ifndef USC_ABLATE_TICKET
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) *ticket = st.item + 1;
+    if (lane == 0) *ticket3 = st.item + 1;
+#endif
+#ifndef USC_NO_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     zero_acc();
   };
 
-  // (Double-buffering the gathers was measured to be worth <5 %: neither the A nor the B loads are
-  // on the critical path, the ordered flush is.  One register set keeps two waves per SIMD.)
-  float4 aX[4];
-  float bX[16][NB];
-  Step cur = first_step(wave);
+  Item cur = make_item(wave);
+  Item nxt = make_item(wave + kCompactWaves);
   zero_acc();
-  while (cur.item >= 0) {
-    issue_loads(cur, aX, bX);
-    run_mfma(cur, aX, bX);
-    if (cur.chunk + 1 == nch) flush(cur);
-    cur = next_step(cur);
+  if (cur.item >= 0) {
+    // running prefetch cursors: `pa` (per lane) = gathered row position kDA quads ahead, `pb` (uniform) = weight
+    // row position kDB quads ahead; both hop to the next item's row / weight slice when they pass the item's end
+    const float* pa = cur.arow;
+    const float* pb = cur.wk;
+    int qa = 0, qb = 0;     // quad index (inside its item) the cursors point at
+    auto advance_a = [&]() {
+      pa += 8; ++qa;
+      if (qa == nq) { pa = nxt.arow; qa = 0; }
+    };
+    auto advance_b = [&]() {
+      pb += NB * 256; ++qb;
+      if (qb == nq) { pb = nxt.wk; qb = 0; }
+    };
+#pragma unroll
+    for (int q = 0; q < kDA; ++q) { load_a(ra[q % kRA], pa); advance_a(); }
+#pragma unroll
+    for (int q = 0; q < kDB; ++q) { load_bq(rb[q % kRB], pb); advance_b(); }
+    // ONE loop over groups of four quads (static ring slots); the item switch happens inside it, so the ring
+    // registers never have to be copied (and therefore waited for) at item boundaries.
+    int q0 = 0;
+    while (true) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        load_a(ra[(u + kDA) % kRA], pa); advance_a();
+        load_bq(rb[(u + kDB) % kRB], pb); advance_b();
+        __builtin_amdgcn_sched_barrier(0);
+        const float4 a4 = ra[u % kRA];
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float4 b4 = rb[u % kRB][nb];
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+            acc[nb] = MFMA32(av[j], bv[j], acc[nb]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      q0 += 4;
+      if (q0 >= nq) {
+        flush(cur);
+        if (nxt.item < 0) break;
+        cur = nxt;
+        nxt = make_item(cur.item + kCompactWaves);
+        q0 = 0;
+      }
+    }
   }
   __syncthreads();
 
@@ -428,7 +499,7 @@ __global__ __launch_bounds__(64 * kCompactWaves, 2) void gather_gemm_compact_ker
 }
 
 static size_t compact_lds_bytes(int NB, int TM) {
-  return (size_t)TM * NB * 32 * 4 + (size_t)kMaxK * TM * 4 + (32 + 32 + 4) * 4 + (size_t)kMaxK * TM;
+  return (size_t)TM * NB * 32 * 4 + (size_t)kMaxK * TM * 4 + (32 + 32 + 4) * 4 + (size_t)kMaxK * TM + kMaxItems * 4;
 }
 
 // out = (accumulate ? out : 0) + bias + sum_g partial[g]   (fixed order)
@@ -692,6 +763,29 @@ __global__ void weight_transpose_kernel(const float* __restrict__ W, int K, int 
   }
 }
 
+// Weight slices in matrix-core operand order for the tile-compacted kernel:
+//   Wp[cb][k][q][nb][lane = 32h + i][j] = W[k][8q + 4h + j][cb*32*NB + NB*i + nb]
+// so that the four B operands a lane needs for one quad and one accumulator are ONE 16-byte load and the
+// wave's 64 loads are 1 KiB contiguous.  (The natural [cin][cout] layout made every k-step a 12-byte-per-lane,
+// stride-12 load that the texture path splits into strided dword passes: measured 85 cycles per wave
+// instruction and 0.55 ms of a 0.60 ms kernel bound by it, independent of prefetch depth.)
+__global__ void weight_pack_kernel(const float* __restrict__ W, int K, int cin, int cout, int NB,
+                                   float* __restrict__ out) {
+  const int64_t total = (int64_t)K * cin * cout;
+  const int nq = cin >> 3, BN = NB * 32;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = e;
+    const int j = (int)(r & 3); r >>= 2;
+    const int ln = (int)(r & 63); r >>= 6;
+    const int nb = (int)(r % NB); r /= NB;
+    const int q = (int)(r % nq); r /= nq;
+    const int k = (int)(r % K);
+    const int cb = (int)(r / K);
+    const int i = ln & 31, h = ln >> 5;
+    out[e] = W[((int64_t)k * cin + 8 * q + 4 * h + j) * cout + cb * BN + NB * i + nb];
+  }
+}
+
 static int wgrad_splits(int K, int cin, int cout, int NB, int64_t n_rows) {
   const int64_t tiles = (int64_t)K * ceil_div(cin, 32) * ceil_div(cout, NB * 32);
   int64_t S = ceil_div(2048, tiles);
@@ -721,7 +815,7 @@ static GemmPlan plan_table(int64_t n_out, int cin, int cout, int K) {
   const bool al = (cin % 32 == 0) && (cout % 32 == 0);
   if (!al) return pl;
   pl.aligned = true;
-  if (K > 1 && K <= kMaxK && n_out >= 24576 && cin >= 64) {
+  if (K > 1 && K <= kMaxK && n_out >= 24576 && cin >= 64 && cin <= kZeroRowFloats) {
     // large maps: tile-compacted kernel (no MFMA work on absent neighbours).  One 8-wave workgroup
     // per CU; the tile height is chosen so that the tiles fill an integer number of 256-CU rounds.
     const int cb = cout / 32;
@@ -813,6 +907,7 @@ int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout, int32_t 
 
 int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin, int32_t cout, int32_t K) {
   const GemmPlan pl = plan_table(n_out, cin, cout, K);
+  if (pl.TM > 0) return (int64_t)K * cin * cout * 4;   // packed weights (weight_pack_kernel)
   return pl.G > 1 ? (int64_t)pl.G * n_out * cout * 4 : 0;
 }
 
@@ -835,6 +930,10 @@ int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const flo
   hipStream_t st = as_stream(s);
   if (pl.TM > 0) {
     p.TM = pl.TM;
+    USC_REQUIRE(ws && ws_bytes >= (int64_t)K * cin * cout * 4, "usc_spconv_gather_gemm: workspace too small");
+    hipLaunchKernelGGL(weight_pack_kernel, dim3(stream_grid((int64_t)K * cin * cout, 256)), dim3(256), 0, st, W, (int)K,
+                       (int)cin, (int)cout, pl.NB, (float*)ws);
+    p.W = (const float*)ws;
     dim3 cgrid((unsigned)ceil_div(n_out, pl.TM), (unsigned)(cout / (pl.NB * 32)));
     const size_t lds = compact_lds_bytes(pl.NB, pl.TM);
 #define USC_CG(NBv)                                                                                        \

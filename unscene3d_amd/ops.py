@@ -179,12 +179,13 @@ def _kernel_symbol(kind, n, cin, cout, K):
     """rocprof-style symbol of the kernel a launch will use (usc_spconv_plan)."""
     code = lib.usc_spconv_plan(kind, int(n), cin, cout, K)
     nb, aligned, compact = code & 0xFF, (code >> 8) & 1, (code >> 12) & 1
+    tag = f" [n={int(n)} cin={cin} cout={cout} K={K} G={code >> 16}]" if _prof.SHAPES else ""
     if kind == 0 and compact:
-        return f"usc::gather_gemm_compact_kernel<{nb}>"
+        return f"usc::gather_gemm_compact_kernel<{nb}>" + tag
     if kind == 2:
-        return f"usc::wgrad_kernel<{nb}, {'true' if aligned else 'false'}>"
+        return f"usc::wgrad_kernel<{nb}, {'true' if aligned else 'false'}>" + tag
     base = "usc::gather_gemm_aligned_kernel" if aligned else "usc::gather_gemm_kernel"
-    return f"{base}<{nb}, {'true' if kind == 1 else 'false'}>"
+    return f"{base}<{nb}, {'true' if kind == 1 else 'false'}>" + tag
 
 
 def weight_transpose(W: torch.Tensor, mirror: bool) -> torch.Tensor:

@@ -7,8 +7,11 @@ from contextlib import contextmanager
 
 import torch
 
+import os
+
 _active = None
 _pairs_cache = {}
+SHAPES = os.environ.get("USC3D_PROF_SHAPES") == "1"   # developer aid: one aggregate per launch shape
 
 
 def pick_nb(cout: int) -> int:   # mirrors csrc/spconv.hip pick_nb
