@@ -156,6 +156,31 @@ int usc_weight_transpose(const float* W, int32_t K, int32_t cin, int32_t cout,
  * (n = P_capacity), 2: wgrad. */
 int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout,
                     int32_t K);
+/* Mask-sorted form of the same convolution (all map sizes, cin and cout multiples
+ * of 32).  usc_rowsort_build groups the OUTPUT rows of a neighbour table by their
+ * neighbour bitmask (one bucket pass on up to 12 informative offset bits):
+ *   perm      i32[n_out]            output rows, similar masks adjacent
+ *   tile_mask u32[ceil(n_out/32)]   OR of the masks of each run of 32 rows of perm
+ * so that a 32-row matrix-core tile skips every offset none of its rows has.
+ * usc_spconv_sorted_gemm computes usc_spconv_gather_gemm's result; its output
+ * bits do not depend on perm (each output element is reduced by one lane over
+ * k ascending, channel ascending); weights are staged through LDS per workgroup.
+ * One perm serves the forward conv and, for a stride-1 map, its input gradient.
+ * Replaces the same MinkowskiEngine calls as usc_spconv_gather_gemm
+ * (models/res16unet.py:224-297; ME 0.5.4 src/convolution_kernel.cu, un-vendored). */
+int64_t usc_rowsort_ws_bytes(int32_t K, int64_t n_out);
+int usc_rowsort_build(const int32_t* nbr, int32_t K, int64_t n_out,
+                      int32_t* perm, uint32_t* tile_mask, void* ws,
+                      int64_t ws_bytes, usc_stream_t s);
+int64_t usc_spconv_sorted_ws_bytes(int64_t n_out, int32_t cin, int32_t cout,
+                                   int32_t K);
+int usc_spconv_sorted_gemm(const float* in, int64_t n_in, int32_t cin,
+                           const float* W, int32_t K, int32_t cout,
+                           const int32_t* nbr, const int32_t* perm,
+                           const uint32_t* tile_mask, int64_t n_out,
+                           const float* bias, float* out, int32_t accumulate,
+                           void* ws, int64_t ws_bytes, usc_stream_t s);
+
 int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin,
                                         int32_t cout, int32_t K);
 int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin,

@@ -118,6 +118,54 @@ def test_conv3_forward_backward(device, cin, cout):
     assert rel_err(Wd.grad, Wr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("n,extent,cin,cout", [(37, 3, 32, 32), (700, 6, 64, 96), (3000, 10, 128, 128),
+                                               (9000, 16, 96, 192), (60000, 40, 96, 96), (60000, 40, 32, 64)])
+def test_mask_sorted_conv_equals_row_order_conv(device, n, extent, cin, cout, monkeypatch):
+    """usc_rowsort_build invariants (perm is a permutation, tile masks are the OR of their rows' neighbour masks)
+    and usc_spconv_sorted_gemm vs the row-order kernels and the CPU oracle; permutation independence BIT FOR BIT
+    (every output element is reduced by one lane over k ascending, channel ascending); incl. a map smaller than one tile, ragged last tiles, the split-K partial-sum path (small maps) and bias/accumulate;
+    also against the CPU oracle."""
+    from unscene3d_amd import ops
+
+    c, cmap = _maps(device, seed=n + cin, n=n, extent=extent)
+    N = len(c)
+    nbr = ops.kernel_map_cube(cmap, 3)
+    perm, tmask = ops.rowsort(nbr)
+    pm = perm.cpu().numpy()
+    assert np.array_equal(np.sort(pm), np.arange(N))
+    has = (nbr.cpu().numpy() >= 0)
+    rowmask = np.zeros(N, np.int64)
+    for k in range(27):
+        rowmask |= has[k].astype(np.int64) << k
+    pad = (-N) % 32
+    sorted_masks = np.concatenate([rowmask[pm], np.zeros(pad, np.int64)]).reshape(-1, 32)
+    assert np.array_equal(np.bitwise_or.reduce(sorted_masks, axis=1), tmask.cpu().numpy().astype(np.int64) & 0xffffffff)
+
+    g = torch.Generator().manual_seed(n + cout)
+    x = _dev(torch.randn(N, cin, generator=g), device)
+    W = _dev(torch.randn(27, cin, cout, generator=g) / np.sqrt(27 * cin), device)
+    bias = _dev(torch.randn(cout, generator=g), device)
+    base = _dev(torch.randn(N, cout, generator=g), device)
+    monkeypatch.setattr(ops, "CONV_PATH", "sorted-all")
+    y_sorted = ops.gather_gemm(x, W, nbr, N)
+    y_sorted_b = ops.gather_gemm(x, W, nbr, N, bias=bias, out=base.clone(), accumulate=True)
+    monkeypatch.setattr(ops, "CONV_PATH", "legacy")
+    y_rows = ops.gather_gemm(x, W, nbr, N)
+    y_rows_b = ops.gather_gemm(x, W, nbr, N, bias=bias, out=base.clone(), accumulate=True)
+    yr = R.conv_gather(x.cpu(), W.cpu(), R.kernel_map_cube(c, 1), N)
+    assert rel_err(y_sorted, yr) < 1e-5
+    assert rel_err(y_sorted_b, yr + bias.cpu() + base.cpu()) < 1e-5
+    # same arithmetic up to the association of the per-offset partial sums (split-K groups / LDS tile flushes)
+    assert rel_err(y_sorted, y_rows) < 1e-6 and rel_err(y_sorted_b, y_rows_b) < 1e-6
+    # the result must not depend on the permutation: identity order with its own tile masks -> identical bits
+    ident = torch.arange(N, dtype=torch.int32, device=x.device)
+    tm_id = np.bitwise_or.reduce(np.concatenate([rowmask, np.zeros(pad, np.int64)]).reshape(-1, 32), axis=1)
+    nbr._usc_rowsort = (ident, _dev(tm_id.astype(np.uint32).view(np.int32), device))
+    monkeypatch.setattr(ops, "CONV_PATH", "sorted-all")
+    assert torch.equal(ops.gather_gemm(x, W, nbr, N), y_sorted)
+    nbr._usc_rowsort = (perm, tmask)
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 32), (128, 128), (256, 128), (96, 96)])
 def test_strided_and_transposed_conv(device, cin, cout):
     from unscene3d_amd import ops

@@ -130,6 +130,25 @@ class CoordinateManager:
             d["rulebook"] = ops.rulebook_compact(d["nbr"])
         return d["rulebook"]
 
+    def prepare(self, ts: int, n_down: int, ksize: int = 3):
+        """Build the whole pyramid a U-Net needs in one go: maps at ts, 2ts, ... (n_down halvings), their k2/s2
+        child tables, the ksize^3 neighbour tables with their mask-sorted row orders, and the per-scene row
+        ranges.  Map building reads counts back to the host; done lazily, each read-back would wait for all the
+        convolution work queued before it and leave the GPU idle while the host catches up (measured: ~18 ms of
+        idle per 71 ms profiled step, concentrated in the forward pass).  Done here, the device queue holds only
+        the short map kernels."""
+        t = ts
+        for lvl in range(n_down + 1):
+            if t not in self._maps:
+                break
+            nbr = self.cube_map(t, ksize)["nbr"]
+            ops.rowsort(nbr)
+            if lvl < n_down:
+                d = self.stride_map(t)
+                ops.rowsort(d["nbr2"])
+            self.batch_slices(t)
+            t *= 2
+
     # -- batch decomposition
     def batch_slices(self, ts: int):
         """Row ranges of every scene in the map at tensor stride ts.  Rows are grouped by batch in every

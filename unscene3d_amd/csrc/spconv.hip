@@ -521,6 +521,12 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restri
   }
 }
 
+void launch_group_reduce(const float* partial, int G, int64_t numel4, int cout, const float* bias, int accumulate,
+                         float* out, hipStream_t st) {   // also used by spconv_sorted.hip
+  hipLaunchKernelGGL(group_reduce_kernel, dim3(stream_grid(numel4, 256)), dim3(256), 0, st, partial, G, numel4, cout,
+                     bias, accumulate, out);
+}
+
 // Generic path (any cin / cout, e.g. the 3-channel stem and 20-class head): bounds-checked.
 template <int NB, bool LIST>
 __global__ __launch_bounds__(256) void gather_gemm_kernel(GemmParams p) {

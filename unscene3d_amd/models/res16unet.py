@@ -71,6 +71,9 @@ class Res16UNetBase(ResNetBase):
     # -- shared trunk ----------------------------------------------------------
     def _trunk(self, x):
         """-> (stride-1 output, [s16, s8, s4, s2, s1] block outputs)."""
+        # all coordinate / kernel maps of the pyramid first (their host read-backs would otherwise stall the
+        # convolution pipeline four times; see CoordinateManager.prepare)
+        x.coordinate_manager.prepare(x.tensor_stride[0], n_down=len(self._DOWN), ksize=3)
         skip = [self.bn0(self.conv0p1s1(x), relu=True)]          # out_p1
         out = skip[0]
         for cname, nname, bname in self._DOWN:
