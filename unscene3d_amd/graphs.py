@@ -1,0 +1,116 @@
+"""HIP-graph capture of fixed-shape sub-networks that are replayed many times per step (the 12 decoder passes).
+
+Differs from `torch.cuda.make_graphed_callables` in what matters for a module whose WEIGHTS ARE SHARED by all
+captured callables (Mask3D's shared decoder, reference models/mask3d.py:100-156):
+
+* parameter gradients are accumulated INSIDE the captured backward graph, straight into `p.grad`, by one
+  multi-tensor add per pass.  Routed through autograd instead, every pass hands ~40 gradient tensors to
+  AccumulateGrad, which issues one small add kernel each: 12 x 40 = 480 launches (~2 ms) per training step;
+* an input that already lives in its static buffer is not copied again.
+
+Requirements (checked at replay, RuntimeError otherwise): every parameter has a `.grad` tensor whose storage
+does not change after capture — use `optimizer.zero_grad(set_to_none=False)` (or `ddp.flatten_grads`).
+"""
+from __future__ import annotations
+
+import torch
+
+
+class _Runner:
+    def __init__(self, module, sample_inputs, params):
+        self.module = module
+        self.params = params
+        self.static_in = [torch.zeros_like(a).requires_grad_(a.requires_grad) for a in sample_inputs]
+        self.grad_in_idx = [j for j, a in enumerate(self.static_in) if a.requires_grad]
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        self.static_out = None
+        self.static_grad_out = None
+        self.static_grad_in = None
+        self.grad_ptrs = None
+
+    def check_param_grads(self):
+        for p, ptr in zip(self.params, self.grad_ptrs):
+            if p.grad is None or p.grad.data_ptr() != ptr:
+                raise RuntimeError(
+                    "graphed decoder pass: a parameter's .grad was freed or reallocated after capture; keep gradient "
+                    "buffers alive (optimizer.zero_grad(set_to_none=False) or ddp.flatten_grads) or disable the graphs")
+
+
+class _GraphedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, *inputs):
+        for s, a in zip(runner.static_in, inputs):
+            if s.data_ptr() != a.data_ptr():
+                s.copy_(a)
+        runner.fwd_graph.replay()
+        ctx.runner = runner
+        return runner.static_out.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        r = ctx.runner
+        r.check_param_grads()
+        if r.static_grad_out.data_ptr() != g.data_ptr():
+            r.static_grad_out.copy_(g)
+        r.bwd_graph.replay()
+        out = [None] * (1 + len(r.static_in))
+        for j, gi in zip(r.grad_in_idx, r.static_grad_in):
+            out[1 + j] = None if gi is None else gi.detach()
+        return tuple(out)
+
+
+class GraphedPass:
+    def __init__(self, runner):
+        self._runner = runner
+
+    def __call__(self, *inputs):
+        return _GraphedFn.apply(self._runner, *inputs)
+
+
+def capture_passes(modules, sample_inputs, warmup_iters: int = 3):
+    """modules: callables (nn.Modules sharing parameters or not); sample_inputs: one tuple of tensors per module
+    (requires_grad marks the inputs whose gradient is needed).  -> list of GraphedPass, replayed in the order
+    given for the forward direction and in reverse for the backward one (like the captured order)."""
+    assert len(modules) == len(sample_inputs)
+    runners = []
+    for m, smp in zip(modules, sample_inputs):
+        params = [p for p in m.parameters() if p.requires_grad]
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        runners.append(_Runner(m, smp, params))
+
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for r in runners:   # eager warm-up (library handles, autotuning) — gradients discarded
+            for _ in range(warmup_iters):
+                out = r.module(*r.static_in)
+                torch.autograd.grad((out,), [r.static_in[j] for j in r.grad_in_idx] + r.params,
+                                    (torch.zeros_like(out),), allow_unused=True)
+            del out
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    pool = torch.cuda.graph_pool_handle()
+    # all forward graphs first, then the backward graphs in reverse order: the pool's liveness during capture
+    # then mirrors the liveness during a training step (fwd 0..n-1, bwd n-1..0)
+    for r in runners:
+        with torch.cuda.graph(r.fwd_graph, pool=pool):
+            r.static_out = r.module(*r.static_in)
+    for r in reversed(runners):
+        r.static_grad_out = torch.zeros_like(r.static_out)
+        targets = [r.static_in[j] for j in r.grad_in_idx] + r.params
+        with torch.cuda.graph(r.bwd_graph, pool=pool):
+            grads = torch.autograd.grad((r.static_out,), targets, (r.static_grad_out,), allow_unused=True)
+            n_in = len(r.grad_in_idx)
+            dst = [p.grad for p, g in zip(r.params, grads[n_in:]) if g is not None]
+            src = [g for g in grads[n_in:] if g is not None]
+            if dst:
+                torch._foreach_add_(dst, src)
+        r.static_grad_in = list(grads[:n_in])
+        r.grad_ptrs = [p.grad.data_ptr() for p in r.params]
+    torch.cuda.synchronize()
+    return [GraphedPass(r) for r in runners]

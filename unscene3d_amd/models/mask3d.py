@@ -114,7 +114,8 @@ class Mask3D(nn.Module):
         """Capture the 12 decoder passes (forward and backward) as HIP graphs for the static shapes
         [batch_size, sample_sizes[hlevel]] — valid while every scene has at least that many voxels per level
         (checked per call; otherwise the eager path runs).  Weights stay shared: the graphs read the live
-        parameter tensors."""
+        parameter tensors and add their gradients straight into `p.grad` (unscene3d_amd/graphs.py), so gradient
+        buffers must stay allocated: `optimizer.zero_grad(set_to_none=False)`."""
         passes, samples = [], []
         sizes = self.backbone.PLANES[-5:]
         B, Q, d = batch_size, self.num_queries, self.mask_dim
@@ -128,7 +129,8 @@ class Mask3D(nn.Module):
                                 torch.zeros(B, K, sizes[hlevel], device=device, requires_grad=True),
                                 torch.zeros(B, K, Q, device=device, dtype=torch.bool),
                                 torch.zeros(B, K, d, device=device)))
-        graphed = torch.cuda.make_graphed_callables(tuple(passes), tuple(samples), allow_unused_input=True)
+        from ..graphs import capture_passes
+        graphed = capture_passes(passes, samples)
         self._graph_shapes = [tuple(a.shape for a in smp) for smp in samples]
         object.__setattr__(self, "_graphed_passes", list(graphed))
 
