@@ -305,6 +305,21 @@ int usc_segment_mean_nonzero(const float* feats, int32_t d,
                              int64_t S, float* out, int64_t* nonzero_cnt,
                              usc_stream_t s);
 
+/* LayerNorm over the last dimension of x f32[rows, d] (d in 64*{1,2,3,4,6,8}):
+ *   y = (x - mean) * rstd * gamma + beta,  rstd = 1/sqrt(var + eps)  (biased var);
+ * mean/rstd f32[rows] are saved for the backward, which is ONE launch for
+ * rows <= 1024 (dx, dgamma, dbeta; column sums reduced in a fixed wave order).
+ * Replaces nn.LayerNorm of the mask decoder (models/mask3d.py:174 decoder_norm,
+ * :515/:572/:627 post-norms of SelfAttentionLayer / CrossAttentionLayer / FFNLayer). */
+int usc_layernorm_fwd(const float* x, const float* gamma, const float* beta,
+                      int64_t rows, int32_t d, float eps, float* y, float* mean,
+                      float* rstd, usc_stream_t s);
+int64_t usc_layernorm_bwd_ws_bytes(int64_t rows, int32_t d);
+int usc_layernorm_bwd(const float* dy, const float* x, const float* mean,
+                      const float* rstd, const float* gamma, int64_t rows,
+                      int32_t d, float* dx, float* dgamma, float* dbeta,
+                      void* ws, int64_t ws_bytes, usc_stream_t s);
+
 /* ------------------------------------------------------------------------
  * Q1  furthest point sampling — replaces pointnet2._ext.furthest_point_sampling
  * (third_party/pointnet2/_ext_src/src/sampling.cpp:67-88,

@@ -617,6 +617,26 @@ def test_config5_ncut_irregular_scene_product_path(device):
         assert (m & r).sum() / max((m | r).sum(), 1) >= 0.99
 
 
+@pytest.mark.parametrize("rows,d", [(100, 128), (1, 64), (2500, 256), (37, 384)])
+def test_layernorm_matches_torch(device, rows, d):
+    """usc_layernorm_fwd/bwd vs F.layer_norm in float64 on the CPU (the reference's nn.LayerNorm)."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, d, generator=g) * 2 + 0.5
+    w = torch.randn(d, generator=g)
+    b = torch.randn(d, generator=g)
+    dy = torch.randn(rows, d, generator=g)
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    yr = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5)
+    yr.backward(dy.double())
+    xd, wd, bd = (_dev(t, device).requires_grad_() for t in (x, w, b))
+    y = ops.layer_norm(xd.view(rows, 1, d), wd, bd, 1e-5)
+    y.backward(_dev(dy, device).view(rows, 1, d))
+    assert rel_err(y.detach().view(rows, d), yr.detach()) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
 def test_knn1_matches_kdtree(device):
     from scipy.spatial import KDTree
     from unscene3d_amd import ops

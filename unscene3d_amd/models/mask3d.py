@@ -94,7 +94,7 @@ class Mask3D(nn.Module):
             self.self_attention.append(sa)
             self.ffn_attention.append(ffn)
             self.lin_squeeze.append(sq)
-        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.decoder_norm = LayerNorm(hidden_dim)
         self.randperm = lambda n, device: torch.randperm(n, device=device)
 
     # ------------------------------------------------------------------
@@ -308,6 +308,17 @@ class Mask3D(nn.Module):
         return [{"pred_logits": a, "pred_masks": b} for a, b in zip(outputs_class[:-1], outputs_seg_masks[:-1])]
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state_dict keys) computed by the HIP kernels of csrc/decoder.hip when the
+    width allows it; other widths use PyTorch's stock operator."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.float32 and self.elementwise_affine and len(self.normalized_shape) == 1
+                and self.normalized_shape[0] in ops._LN_DIMS and self.bias is not None):
+            return ops.layer_norm(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
 class _DecoderPass(nn.Module):
     """lin_squeeze -> masked cross attention -> self attention -> FFN of one (decoder, level) pass
     (reference mask3d.py:351-373).  Pure tensor-in / tensor-out with static shapes whenever every scene
@@ -347,7 +358,7 @@ class SelfAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
         self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = LayerNorm(d_model)
         self.dropout = nn.Dropout(dropout)
         self.activation = _get_activation_fn(activation)
         self.normalize_before = normalize_before
@@ -370,7 +381,7 @@ class CrossAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
         self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = LayerNorm(d_model)
         self.dropout = nn.Dropout(dropout)
         self.activation = _get_activation_fn(activation)
         self.normalize_before = normalize_before
@@ -393,7 +404,7 @@ class FFNLayer(nn.Module):
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = LayerNorm(d_model)
         self.activation = _get_activation_fn(activation)
         self.normalize_before = normalize_before
         _xavier(self)

@@ -659,3 +659,46 @@ def cc_eps(xyz: torch.Tensor, eps: float, max_rounds: int = 256) -> torch.Tensor
     labels = torch.empty(n, dtype=torch.int64, device=dev)
     check(lib.usc_cc_eps_finish(_ptr(la), n, _ptr(lb), _ptr(labels), _stream()), "usc_cc_eps_finish")
     return labels
+
+
+# ------------------------------------------------------------------ decoder-side small-row ops
+_LN_DIMS = {64, 128, 192, 256, 384, 512}
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        d = x.shape[-1]
+        x2 = x.contiguous().view(-1, d)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.usc_layernorm_fwd(_ptr(x2), _ptr(weight), _ptr(bias), rows, d, float(eps), _ptr(y), _ptr(mean),
+                                    _ptr(rstd), _stream()), "usc_layernorm_fwd")
+        ctx.save_for_backward(x2, weight, mean, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, mean, rstd = ctx.saved_tensors
+        rows, d = x2.shape
+        dy2 = dy.contiguous().view(rows, d)
+        dx = torch.empty_like(x2)
+        dgamma = torch.empty_like(weight)
+        dbeta = torch.empty_like(weight)
+        wsb = lib.usc_layernorm_bwd_ws_bytes(rows, d)
+        ws = _ws(wsb, x2.device) if wsb > 0 else None
+        check(lib.usc_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(mean), _ptr(rstd), _ptr(weight), rows, d, _ptr(dx),
+                                    _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream()), "usc_layernorm_bwd")
+        return dx.view(ctx.shape), dgamma, dbeta, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """F.layer_norm over the last dimension through the HIP kernels (f32, contiguous weight/bias, d in _LN_DIMS)."""
+    _chk(weight, torch.float32, "weight")
+    _chk(bias, torch.float32, "bias")
+    if x.dtype != torch.float32 or not x.is_cuda or x.shape[-1] not in _LN_DIMS:
+        raise RuntimeError(f"layer_norm: needs an f32 HIP tensor with last dim in {sorted(_LN_DIMS)}")
+    return _LayerNorm.apply(x, weight, bias, eps)
