@@ -305,6 +305,19 @@ int usc_segment_mean_nonzero(const float* feats, int32_t d,
                              int64_t S, float* out, int64_t* nonzero_cnt,
                              usc_stream_t s);
 
+/* Linear layer on a handful of rows (the 100 decoder queries):
+ *   y[M,N] = x[M,K] W[N,K]^T + b[N]   (b may be NULL);  N, K multiples of 32.
+ * usc_linear_bwd: dx[M,K] = dy W, dW[N,K] = dy^T x, db[N] = column sums of dy; each
+ * of dx / dW may be NULL to skip it (db is produced with dW).  One wave per 32x32
+ * output tile on the f32 matrix cores, one launch per product.
+ * Replaces nn.Linear / the nn.MultiheadAttention projections of the mask decoder
+ * (models/mask3d.py:491-651 attention layers and FFN, :70-72 mask_embed_head). */
+int usc_linear_fwd(const float* x, const float* W, const float* b, int32_t M,
+                   int32_t N, int32_t K, float* y, usc_stream_t s);
+int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M,
+                   int32_t N, int32_t K, float* dx, float* dW, float* db,
+                   usc_stream_t s);
+
 /* LayerNorm over the last dimension of x f32[rows, d] (d in 64*{1,2,3,4,6,8}):
  *   y = (x - mean) * rstd * gamma + beta,  rstd = 1/sqrt(var + eps)  (biased var);
  * mean/rstd f32[rows] are saved for the backward, which is ONE launch for

@@ -637,6 +637,52 @@ def test_layernorm_matches_torch(device, rows, d):
     assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("rows,n_in,n_out", [(100, 128, 128), (100, 128, 1024), (100, 1024, 128), (1, 32, 64), (333, 96, 160)])
+def test_small_row_linear_matches_torch(device, rows, n_in, n_out):
+    """usc_linear_fwd/bwd (few-row linear layers of the decoder) vs F.linear in float64."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(rows + n_in)
+    x = torch.randn(rows, n_in, generator=g)
+    W = torch.randn(n_out, n_in, generator=g) / np.sqrt(n_in)
+    b = torch.randn(n_out, generator=g)
+    dy = torch.randn(rows, n_out, generator=g)
+    xr, Wr, br = (t.double().requires_grad_() for t in (x, W, b))
+    yr = torch.nn.functional.linear(xr, Wr, br)
+    yr.backward(dy.double())
+    xd, Wd, bd = (_dev(t, device).requires_grad_() for t in (x, W, b))
+    y = ops.linear(xd.view(rows, 1, n_in), Wd, bd)
+    y.backward(_dev(dy, device).view(rows, 1, n_out))
+    assert rel_err(y.detach().view(rows, n_out), yr.detach()) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("S", [100, 3200])
+def test_multihead_attention_matches_nn_module(device, S):
+    """models.mask3d.multihead_attention (HIP projections + SDPA) vs nn.MultiheadAttention, forward and all
+    gradients, self-attention style (S = L) and masked cross-attention style (S keys)."""
+    from unscene3d_amd.models.mask3d import multihead_attention
+
+    torch.manual_seed(S)
+    E, H, L, B = 128, 8, 100, 1
+    mha = torch.nn.MultiheadAttention(E, H, dropout=0.0).to(device)
+    q = torch.randn(L, B, E, device=device)
+    k = torch.randn(S, B, E, device=device)
+    v = torch.randn(S, B, E, device=device)
+    mask = torch.rand(B * H, L, S, device=device) > 0.6
+    mask[:, :, 0] = False                                     # no fully masked row
+    dy = torch.randn(L, B, E, device=device)
+    outs = []
+    for fn in ("nn", "hip"):
+        mha.zero_grad()
+        qq, kk, vv = (t.clone().requires_grad_() for t in (q, k, v))
+        o = mha(qq, kk, vv, attn_mask=mask, need_weights=False)[0] if fn == "nn" else multihead_attention(mha, qq, kk, vv, mask)
+        o.backward(dy)
+        outs.append([o.detach(), qq.grad, kk.grad, vv.grad] + [p.grad.clone() for p in mha.parameters()])
+    for a, b in zip(*outs):
+        assert rel_err(b, a) < 1e-4
+
+
 def test_knn1_matches_kdtree(device):
     from scipy.spatial import KDTree
     from unscene3d_amd import ops

@@ -149,3 +149,161 @@ int usc_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------
+// Linear layers with a handful of rows (the 100 queries): y = x W^T + b and its two gradients on the f32
+// matrix cores, one workgroup per 32x32 output tile, everything in one launch each.  The library GEMM picks a
+// 128x128 macro tile for these shapes (one workgroup walking K): ~12 us per call, ~25 calls per decoder pass.
+// Reference: nn.Linear / nn.MultiheadAttention projections of models/mask3d.py:491-651 (attention layers, FFN)
+// and :70-72 (mask_embed_head).
+namespace usc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+__device__ inline int acc_row16(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+// All three products: a 256-thread workgroup per 32x32 output tile; the four waves split the REDUCTION dimension
+// (one wave per tile was latency bound: 32 dependent load->MFMA rounds for the 1024-wide FFN), partial tiles are
+// summed through LDS in wave order (deterministic), each wave finalising four of the sixteen accumulator rows.
+__device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int wave, int lane, float* __restrict__ out,
+                                         int64_t ld, int row0, int col0, int max_row, const float* __restrict__ bias) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 4 * wave + q;
+    const float v = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+    const int row = row0 + acc_row16(r, h);
+    if (row < max_row) out[(int64_t)row * ld + col0 + i] = v + (bias ? bias[col0 + i] : 0.f);
+  }
+}
+
+// y[M,N] = x[M,K] W[N,K]^T (+ b)      grid (N/32, ceil(M/32)); K % 32 == 0
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                        const float* __restrict__ b, int M, int N, int K,
+                                                        float* __restrict__ y) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int m = m0 + i;
+  const float* xa = x + (int64_t)(m < M ? m : 0) * K + 4 * h;
+  const float* wb = W + (int64_t)(n0 + i) * K + 4 * h;
+  const float keep = m < M ? 1.f : 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nchunk = K >> 5;
+  for (int c = wave; c < nchunk; c += 4) {
+    const int k0 = c * 32;
+    float4 a[4], bb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { a[t] = *reinterpret_cast<const float4*>(xa + k0 + 8 * t); bb[t] = *reinterpret_cast<const float4*>(wb + k0 + 8 * t); }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float av[4] = {a[t].x * keep, a[t].y * keep, a[t].z * keep, a[t].w * keep};
+      const float bv[4] = {bb[t].x, bb[t].y, bb[t].z, bb[t].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[j], acc);
+    }
+  }
+  tile_reduce_store(acc, red, wave, lane, y, N, m0, n0, M, b);
+}
+
+// dx[M,K] = dy[M,N] W[N,K]            grid (K/32, ceil(M/32)); N % 32 == 0
+__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W, int M,
+                                                       int N, int K, float* __restrict__ dx) {
+  __shared__ float red[4][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int c0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int m = m0 + i;
+  const float* ya = dy + (int64_t)(m < M ? m : 0) * N + 4 * h;
+  const float* wb = W + (int64_t)(4 * h) * K + c0 + i;
+  const float keep = m < M ? 1.f : 0.f;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int nchunk = N >> 5;
+  for (int c = wave; c < nchunk; c += 4) {
+    const int n0 = c * 32;
+    float4 a[4];
+    float bv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(ya + n0 + 8 * t);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[4 * t + j] = wb[(int64_t)(n0 + 8 * t + j) * K];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float av[4] = {a[t].x * keep, a[t].y * keep, a[t].z * keep, a[t].w * keep};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[4 * t + j], acc);
+    }
+  }
+  tile_reduce_store(acc, red, wave, lane, dx, K, m0, c0, M, nullptr);
+}
+
+// dW[N,K] = dy[M,N]^T x[M,K],  db[N] = sum_m dy[m][N]       grid (K/32, N/32)
+__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M,
+                                                       int N, int K, float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[4][16][64];
+  __shared__ float bred[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float bsum = 0.f;
+  for (int mb = wave * 32; mb < M; mb += 128) {
+    float av[16], bv[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = mb + 8 * t + 4 * h + j;
+        const bool ok = m < M;
+        av[4 * t + j] = ok ? dy[(int64_t)m * N + n0 + i] : 0.f;
+        bv[4 * t + j] = ok ? x[(int64_t)m * K + c0 + i] : 0.f;
+      }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { acc = MFMA32(av[q], bv[q], acc); bsum += av[q]; }
+  }
+  if (db && blockIdx.x == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (h == 0) bred[wave][i] = bsum;
+  }
+  tile_reduce_store(acc, red, wave, lane, dW, K, n0, c0, N, nullptr);   // contains the __syncthreads
+  if (db && blockIdx.x == 0 && threadIdx.x < 32)
+    db[n0 + threadIdx.x] = bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x];
+}
+
+}  // namespace
+}  // namespace usc
+
+extern "C" {
+
+int usc_linear_fwd(const float* x, const float* W, const float* b, int32_t M, int32_t N, int32_t K, float* y,
+                   usc_stream_t s) {
+  USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_fwd: N, K must be multiples of 32");
+  USC_REQUIRE(x && W && y, "usc_linear_fwd: null pointer");
+  hipLaunchKernelGGL(usc::linear_fwd_kernel, dim3(N / 32, (M + 31) / 32), dim3(256), 0, usc::as_stream(s), x, W, b, (int)M,
+                     (int)N, (int)K, y);
+  USC_CHECK_LAUNCH("usc_linear_fwd");
+  return USC_OK;
+}
+
+int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M, int32_t N, int32_t K, float* dx, float* dW,
+                   float* db, usc_stream_t s) {
+  USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_bwd: N, K must be multiples of 32");
+  USC_REQUIRE(dy && x && W, "usc_linear_bwd: null pointer");
+  hipStream_t st = usc::as_stream(s);
+  if (dx) hipLaunchKernelGGL(usc::linear_dx_kernel, dim3(K / 32, (M + 31) / 32), dim3(256), 0, st, dy, W, (int)M, (int)N, (int)K, dx);
+  if (dW) hipLaunchKernelGGL(usc::linear_dw_kernel, dim3(K / 32, N / 32), dim3(256), 0, st, dy, x, (int)M, (int)N, (int)K, dW, db);
+  USC_CHECK_LAUNCH("usc_linear_bwd");
+  return USC_OK;
+}
+
+}  // extern "C"

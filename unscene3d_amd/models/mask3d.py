@@ -67,8 +67,8 @@ class Mask3D(nn.Module):
         if use_level_embed:
             self.level_embed = nn.Embedding(self.num_levels, hidden_dim)
 
-        self.mask_embed_head = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.ReLU(),
-                                             nn.Linear(hidden_dim, hidden_dim))
+        self.mask_embed_head = nn.Sequential(Linear(hidden_dim, hidden_dim), nn.ReLU(),
+                                             Linear(hidden_dim, hidden_dim))
         self.class_embed_head = nn.Linear(hidden_dim, self.num_classes)
 
         if positional_encoding_type not in ("fourier", "sine"):
@@ -308,6 +308,36 @@ class Mask3D(nn.Module):
         return [{"pred_logits": a, "pred_masks": b} for a, b in zip(outputs_class[:-1], outputs_seg_masks[:-1])]
 
 
+class Linear(nn.Linear):
+    """nn.Linear whose few-row inputs (the 100 queries) run on the wave-per-tile kernels of csrc/decoder.hip."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32:
+            return ops.linear(x, self.weight, self.bias)
+        return super().forward(x)
+
+
+def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None):
+    """nn.MultiheadAttention.forward(query, key, value, attn_mask=…, need_weights=False)[0] for the
+    sequence-first layout, dropout 0 and a boolean mask (True = masked), with the input / output projections
+    through ops.in_proj / ops.linear (same parameters, same state_dict)."""
+    L, B, E = query.shape
+    S = key.shape[0]
+    H = mha.num_heads
+    hd = E // H
+    q, k, v = ops.in_proj(query, key, value, mha.in_proj_weight, mha.in_proj_bias)
+    q = q.reshape(L, B * H, hd).transpose(0, 1).reshape(B, H, L, hd)
+    k = k.reshape(S, B * H, hd).transpose(0, 1).reshape(B, H, S, hd)
+    v = v.reshape(S, B * H, hd).transpose(0, 1).reshape(B, H, S, hd)
+    mask = None
+    if attn_mask is not None:
+        mask = torch.zeros(attn_mask.shape, dtype=q.dtype, device=q.device).masked_fill_(attn_mask, float("-inf"))
+        mask = mask.reshape(B, H, L, S)
+    out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+    out = out.permute(2, 0, 1, 3).reshape(L, B, E)
+    return ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+
+
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm (same parameters / state_dict keys) computed by the HIP kernels of csrc/decoder.hip when the
     width allows it; other widths use PyTorch's stock operator."""
@@ -369,8 +399,11 @@ class SelfAttentionLayer(nn.Module):
         q = k = _with_pos(src, query_pos)
         # need_weights=False: same output; skips materialising/averaging the [B,Q,K] attention weights the
         # reference computes and discards (`[0]`), and lets PyTorch take its fused SDPA path
-        upd = self.self_attn(q, k, value=src, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask,
-                             need_weights=False)[0]
+        if tgt_key_padding_mask is None and self.self_attn.dropout == 0.0 and q.is_cuda:
+            upd = multihead_attention(self.self_attn, q, k, src, attn_mask=tgt_mask)
+        else:
+            upd = self.self_attn(q, k, value=src, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask,
+                                 need_weights=False)[0]
         out = tgt + self.dropout(upd)
         return out if self.normalize_before else self.norm(out)
 
@@ -389,9 +422,13 @@ class CrossAttentionLayer(nn.Module):
 
     def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None):
         src = self.norm(tgt) if self.normalize_before else tgt
-        upd = self.multihead_attn(query=_with_pos(src, query_pos), key=_with_pos(memory, pos), value=memory,
-                                  attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask,
-                                  need_weights=False)[0]
+        if memory_key_padding_mask is None and self.multihead_attn.dropout == 0.0 and src.is_cuda:
+            upd = multihead_attention(self.multihead_attn, _with_pos(src, query_pos), _with_pos(memory, pos), memory,
+                                      attn_mask=memory_mask)
+        else:
+            upd = self.multihead_attn(query=_with_pos(src, query_pos), key=_with_pos(memory, pos), value=memory,
+                                      attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask,
+                                      need_weights=False)[0]
         out = tgt + self.dropout(upd)
         return out if self.normalize_before else self.norm(out)
 
@@ -401,9 +438,9 @@ class FFNLayer(nn.Module):
 
     def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
         super().__init__()
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear1 = Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear2 = Linear(dim_feedforward, d_model)
         self.norm = LayerNorm(d_model)
         self.activation = _get_activation_fn(activation)
         self.normalize_before = normalize_before

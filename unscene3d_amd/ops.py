@@ -702,3 +702,95 @@ def layer_norm(x, weight, bias, eps=1e-5):
     if x.dtype != torch.float32 or not x.is_cuda or x.shape[-1] not in _LN_DIMS:
         raise RuntimeError(f"layer_norm: needs an f32 HIP tensor with last dim in {sorted(_LN_DIMS)}")
     return _LayerNorm.apply(x, weight, bias, eps)
+
+
+SMALL_ROWS = 512   # linear layers with at most this many rows go to the wave-per-tile kernels
+
+
+def _small_linear_ok(rows, n_in, n_out):
+    return rows <= SMALL_ROWS and n_in % 32 == 0 and n_out % 32 == 0 and n_in >= 32 and n_out >= 32
+
+
+def _lin_fwd(x2, W, b):
+    """y = x2 W^T + b for contiguous f32 x2 [M,K], W [N,K] (a contiguous row block is fine)."""
+    M, K = x2.shape
+    N = W.shape[0]
+    if _small_linear_ok(M, K, N):
+        y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
+        check(lib.usc_linear_fwd(_ptr(x2), _ptr(W), _ptr(b), M, N, K, _ptr(y), _stream()), "usc_linear_fwd")
+        return y
+    return torch.addmm(b, x2, W.t()) if b is not None else x2 @ W.t()
+
+
+def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True):
+    """-> dx (or None); writes dW_out [N,K] and db_out [N] (views of larger gradient tensors are fine)."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    if _small_linear_ok(M, K, N):
+        dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device) if need_dx else None
+        check(lib.usc_linear_bwd(_ptr(dy2), _ptr(x2), _ptr(W), M, N, K, _ptr(dx), _ptr(dW_out), _ptr(db_out), _stream()),
+              "usc_linear_bwd")
+        return dx
+    torch.mm(dy2.t(), x2, out=dW_out)
+    if db_out is not None:
+        torch.sum(dy2, 0, out=db_out)
+    return dy2 @ W if need_dx else None
+
+
+class _LinearRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        ctx.save_for_backward(x2, W)
+        ctx.has_bias, ctx.shape = b is not None, x.shape
+        return _lin_fwd(x2, W, b).view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, W = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, W.shape[0])
+        dW = torch.empty_like(W)
+        db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_bias else None
+        dx = _lin_bwd(dy2, x2, W, dW, db, need_dx=ctx.needs_input_grad[0])
+        return (None if dx is None else dx.view(ctx.shape)), dW, db
+
+
+def linear(x, W, b=None):
+    """F.linear(x, W, b) for f32 HIP tensors; few-row inputs run on the wave-per-tile MFMA kernels of decoder.hip."""
+    _chk(W, torch.float32, "W")
+    return _LinearRows.apply(x, W, b)
+
+
+class _InProj(torch.autograd.Function):
+    """q, k, v = the three input projections of nn.MultiheadAttention from its packed in_proj_weight [3E,E] /
+    in_proj_bias [3E] (reference: nn.MultiheadAttention inside models/mask3d.py:491-605).  One Function so that the
+    three weight gradients are written into ONE [3E,E] tensor instead of three sliced ones summed by autograd."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, W, b):
+        E = W.shape[1]
+        xs = [t.contiguous().view(-1, E) for t in (xq, xk, xv)]
+        outs = [_lin_fwd(xs[j], W[j * E:(j + 1) * E], b[j * E:(j + 1) * E]) for j in range(3)]
+        ctx.save_for_backward(xs[0], xs[1], xs[2], W)
+        ctx.shapes = (xq.shape, xk.shape, xv.shape)
+        ctx.same_qk = xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape
+        return tuple(o.view(*shp[:-1], E) for o, shp in zip(outs, ctx.shapes))
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        x0, x1, x2, W = ctx.saved_tensors
+        E = W.shape[1]
+        dW = torch.empty_like(W)
+        db = torch.empty(3 * E, dtype=torch.float32, device=W.device)
+        dxs = []
+        for j, (dyj, xj) in enumerate(zip((dq, dk, dv), (x0, x1, x2))):
+            dy2 = dyj.contiguous().view(-1, E)
+            dxs.append(_lin_bwd(dy2, xj, W[j * E:(j + 1) * E], dW[j * E:(j + 1) * E], db[j * E:(j + 1) * E],
+                                need_dx=ctx.needs_input_grad[j]))
+        return tuple(None if d is None else d.view(shp) for d, shp in zip(dxs, ctx.shapes)) + (dW, db)
+
+
+def in_proj(xq, xk, xv, W, b):
+    _chk(W, torch.float32, "in_proj_weight")
+    _chk(b, torch.float32, "in_proj_bias")
+    return _InProj.apply(xq, xk, xv, W, b)
