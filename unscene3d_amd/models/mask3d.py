@@ -329,11 +329,17 @@ def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask
     q = q.reshape(L, B * H, hd).transpose(0, 1).reshape(B, H, L, hd)
     k = k.reshape(S, B * H, hd).transpose(0, 1).reshape(B, H, S, hd)
     v = v.reshape(S, B * H, hd).transpose(0, 1).reshape(B, H, S, hd)
-    mask = None
-    if attn_mask is not None:
+    if attn_mask is None:
+        out = F.scaled_dot_product_attention(q, k, v)                      # 100 x 100: the fused kernel is fine
+    else:
+        # masked cross attention, 100 queries x up to 12 800 keys: softmax(q k^T / sqrt(hd) + mask) v as two batched
+        # GEMMs and one softmax.  (The fused memory-efficient kernel that scaled_dot_product_attention selects for
+        # contiguous operands with an arbitrary mask measured 122 us forward / 135 us backward per call here —
+        # 7.5 ms per training step; this path is the one nn.MultiheadAttention's strided operands fell back to.)
         mask = torch.zeros(attn_mask.shape, dtype=q.dtype, device=q.device).masked_fill_(attn_mask, float("-inf"))
-        mask = mask.reshape(B, H, L, S)
-    out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+        scores = torch.baddbmm(mask, q.reshape(B * H, L, hd), k.reshape(B * H, S, hd).transpose(1, 2),
+                               alpha=1.0 / (hd ** 0.5))
+        out = torch.bmm(torch.softmax(scores, dim=-1), v.reshape(B * H, S, hd)).reshape(B, H, L, hd)
     out = out.permute(2, 0, 1, 3).reshape(L, B, E)
     return ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
 
