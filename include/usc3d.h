@@ -205,10 +205,11 @@ int64_t usc_spconv_wgrad_ws_bytes(int32_t K, int32_t cin, int32_t cout);
  * a f32[*,cin], b f32[*,cout], dW f32[K,cin,cout]; pair lists as produced by
  * usc_rulebook_compact (a_idx/b_idx i32, koff i64[K+1] device).
  * a_idx==NULL && K==1: identity pairs over n_rows (1x1 conv). Deterministic
- * (fixed split + ordered reduction, no float atomics). */
+ * (fixed split + ordered reduction, no float atomics).  accumulate=1 adds into
+ * dW (a parameter's existing gradient buffer) instead of overwriting it. */
 int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout,
                      int32_t K, const int32_t* a_idx, const int32_t* b_idx,
-                     const int64_t* koff, int64_t n_rows, float* dW, void* ws,
+                     const int64_t* koff, int64_t n_rows, float* dW, int32_t accumulate, void* ws,
                      int64_t ws_bytes, usc_stream_t s);
 
 /* ------------------------------------------------------------------------
@@ -247,10 +248,11 @@ int usc_bn_backward_dx(const float* x, const float* dy, const float* y_out,
                        int64_t n, int32_t c, usc_stream_t s);
 /* Reductions needed by the above in one pass: dbeta[c] = sum g, dgamma[c] = sum g*xhat,
  * mean_g = dbeta/n, mean_gxhat = dgamma/n (both 0 when training==0: eval-mode BN
- * treats the statistics as constants).  g applies the ReLU mask of y_out when given. */
+ * treats the statistics as constants).  g applies the ReLU mask of y_out when given.  accumulate=1 adds dgamma / dbeta into the given
+ * buffers (the parameters' gradient tensors) instead of overwriting them. */
 int usc_bn_backward_reduce(const float* x, const float* dy, const float* y_out,
                            const float* mean, const float* invstd, int64_t n,
-                           int32_t c, int32_t training, float* dgamma,
+                           int32_t c, int32_t training, int32_t accumulate, float* dgamma,
                            float* dbeta, float* mean_g, float* mean_gxhat,
                            void* ws, int64_t ws_bytes, usc_stream_t s);
 /* y = max(x,0);  dx = (y>0) ? dy : 0 */

@@ -166,6 +166,35 @@ def test_mask_sorted_conv_equals_row_order_conv(device, n, extent, cin, cout, mo
     nbr._usc_rowsort = (perm, tmask)
 
 
+def test_parameter_gradients_accumulate_in_place(device):
+    """With gradient buffers already allocated (zero_grad(set_to_none=False) / flatten_grads) the conv and BN
+    backward kernels add straight into `p.grad`; two backward passes must give exactly twice the fresh gradient."""
+    from unscene3d_amd import MinkowskiEngine as ME
+
+    c, cmap = _maps(device, seed=9, n=2500, extent=9)
+    coords = _dev(c, device)
+    torch.manual_seed(5)
+    conv = ME.MinkowskiConvolution(32, 64, kernel_size=3, dimension=3).to(device)
+    bn = ME.MinkowskiBatchNorm(64).to(device)
+    x = torch.randn(len(c), 32, device=device)
+
+    def run():
+        st = ME.SparseTensor(features=x, coordinates=coords, device=device)
+        out = bn(conv(st), relu=True)
+        out.F.square().sum().backward()
+
+    run()                                                   # fresh gradients (grad was None)
+    ref = [p.grad.clone() for p in list(conv.parameters()) + list(bn.parameters())]
+    for p in list(conv.parameters()) + list(bn.parameters()):
+        p.grad.zero_()
+    ptrs = [p.grad.data_ptr() for p in list(conv.parameters()) + list(bn.parameters())]
+    run()
+    run()                                                   # accumulates in place, twice
+    for p, r, ptr in zip(list(conv.parameters()) + list(bn.parameters()), ref, ptrs):
+        assert p.grad.data_ptr() == ptr
+        assert rel_err(p.grad, 2 * r) < 1e-6
+
+
 @pytest.mark.parametrize("cin,cout", [(32, 32), (128, 128), (256, 128), (96, 96)])
 def test_strided_and_transposed_conv(device, cin, cout):
     from unscene3d_amd import ops

@@ -44,12 +44,12 @@ SIGNATURES = {
     "usc_spconv_sorted_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _p, _i64, _p]),
     "usc_spconv_pairs_gemm": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p]),
     "usc_spconv_wgrad_ws_bytes": (_i64, [_i32, _i32, _i32]),
-    "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i64, _p]),
+    "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p, _i64, _p]),
     "usc_colstats_ws_bytes": (_i64, [_i64, _i32]),
     "usc_colstats": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "usc_bn_apply": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i64, _i32, _p]),
     "usc_bn_backward_dx": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
-    "usc_bn_backward_reduce": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p]),
+    "usc_bn_backward_reduce": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     "usc_bn_forward_stats": (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "usc_relu_fwd": (C.c_int, [_p, _p, _i64, _p]),
     "usc_relu_bwd": (C.c_int, [_p, _p, _p, _i64, _p]),

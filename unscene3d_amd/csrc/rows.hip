@@ -155,15 +155,15 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const double* __res
   }
 }
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int c,
-                                                            int64_t n, int training, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, float* __restrict__ mean_g,
-                                                            float* __restrict__ mean_gx) {
+                                                            int64_t n, int training, int accumulate,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ mean_g, float* __restrict__ mean_gx) {
   const int ch = blockIdx.x;
   double sg, sgx;
   reduce_partials(partial, nblocks, c, ch, sg, sgx);
   if ((threadIdx.x & 63) == 0) {
-    dbeta[ch] = (float)sg;
-    dgamma[ch] = (float)sgx;
+    dbeta[ch] = accumulate ? dbeta[ch] + (float)sg : (float)sg;      // accumulate: into the parameters' .grad buffers
+    dgamma[ch] = accumulate ? dgamma[ch] + (float)sgx : (float)sgx;
     mean_g[ch] = training ? (float)(sg / (double)n) : 0.f;
     mean_gx[ch] = training ? (float)(sgx / (double)n) : 0.f;
   }
@@ -557,8 +557,8 @@ int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamm
 }
 
 int usc_bn_backward_reduce(const float* x, const float* dy, const float* y_out, const float* mean, const float* invstd,
-                           int64_t n, int32_t c, int32_t training, float* dgamma, float* dbeta, float* mean_g,
-                           float* mean_gxhat, void* ws, int64_t ws_bytes, usc_stream_t s) {
+                           int64_t n, int32_t c, int32_t training, int32_t accumulate, float* dgamma, float* dbeta,
+                           float* mean_g, float* mean_gxhat, void* ws, int64_t ws_bytes, usc_stream_t s) {
   USC_REQUIRE(x && dy && mean && invstd && dgamma && dbeta && mean_g && mean_gxhat && ws && n >= 1,
               "usc_bn_backward_reduce: bad argument");
   StatArgs a{x, dy, y_out, mean, invstd, n, (int)c};
@@ -566,7 +566,7 @@ int usc_bn_backward_reduce(const float* x, const float* dy, const float* y_out, 
   int rc = launch_colstats_partials<STAT_BN_BWD>(a, ws, ws_bytes, as_stream(s), "usc_bn_backward_reduce", &nb);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c,
-                     n, (int)training, dgamma, dbeta, mean_g, mean_gxhat);
+                     n, (int)training, (int)accumulate, dgamma, dbeta, mean_g, mean_gxhat);
   USC_CHECK_LAUNCH("usc_bn_backward_reduce");
   return USC_OK;
 }

@@ -747,11 +747,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t numel, float* __restrict__ dW) {
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t numel, int accumulate,
+                                    float* __restrict__ dW) {
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < numel; j += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += partial[(int64_t)s * numel + j];
-    dW[j] = v;
+    dW[j] = accumulate ? dW[j] + v : v;   // accumulate: straight into the parameter's gradient buffer
   }
 }
 
@@ -990,7 +991,7 @@ int64_t usc_spconv_wgrad_ws_bytes(int32_t K, int32_t cin, int32_t cout) {
 }
 
 int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, int32_t K, const int32_t* a_idx,
-                     const int32_t* b_idx, const int64_t* koff, int64_t n_rows, float* dW, void* ws, int64_t ws_bytes,
+                     const int32_t* b_idx, const int64_t* koff, int64_t n_rows, float* dW, int32_t accumulate, void* ws, int64_t ws_bytes,
                      usc_stream_t s) {
   USC_REQUIRE(cin >= 1 && cout >= 1 && K >= 1 && n_rows >= 0, "usc_spconv_wgrad: bad sizes");
   USC_REQUIRE(a && b && dW && ws, "usc_spconv_wgrad: null pointer");
@@ -1017,7 +1018,7 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
   }
 #undef USC_WG
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, S, numel,
-                     dW);
+                     (int)accumulate, dW);
   USC_CHECK_LAUNCH("usc_spconv_wgrad");
   return USC_OK;
 }

@@ -288,18 +288,32 @@ def pairs_gemm(feats, W, rows_in, rows_out, koff, P, n_out):
     return out
 
 
-def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None):
-    """dW[k] = sum_{p in list k} a[a_idx[p]]^T b[b_idx[p]] -> f32[K,cin,cout]."""
+# Parameter gradients straight into `p.grad`: when a leaf parameter already has a gradient buffer (the trainer
+# keeps them allocated: zero_grad(set_to_none=False), one flat buffer for the all-reduce), the backward kernels add
+# into it and the Function returns None, instead of returning a fresh tensor that autograd's AccumulateGrad then
+# adds with one more small kernel per parameter (~250 launches per step for the backbone).
+GRAD_IN_PLACE = os.environ.get("USC3D_GRAD_IN_PLACE", "1") == "1"
+
+
+def _grad_target(param):
+    if GRAD_IN_PLACE and isinstance(param, torch.nn.Parameter) and param.is_leaf and param.grad is not None \
+            and param.grad.is_contiguous() and not param._backward_hooks:
+        return param.grad
+    return None
+
+
+def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None, into=None):
+    """dW[k] = sum_{p in list k} a[a_idx[p]]^T b[b_idx[p]] -> f32[K,cin,cout] (added into `into` when given)."""
     _chk(a, torch.float32, "a")
     _chk(b, torch.float32, "b")
     cin, cout = a.shape[1], b.shape[1]
-    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=a.device)
+    dW = torch.empty((K, cin, cout), dtype=torch.float32, device=a.device) if into is None else into
     ws = _ws(lib.usc_spconv_wgrad_ws_bytes(K, cin, cout), a.device)
     n_rows = a.shape[0] if a_idx is None else int(a_idx.shape[0])
     with _prof.maybe(lambda: _kernel_symbol(2, n_rows, cin, cout, K),
                      lambda: _conv_cost(n_rows, a.shape[0], b.shape[0], K, cin, cout)):
         check(lib.usc_spconv_wgrad(_ptr(a), cin, _ptr(b), cout, K, _ptr(a_idx), _ptr(b_idx), _ptr(koff), n_rows,
-                                   _ptr(dW), _ptr(ws), ws.numel(), _stream()), "usc_spconv_wgrad")
+                                   _ptr(dW), int(into is not None), _ptr(ws), ws.numel(), _stream()), "usc_spconv_wgrad")
     return dW
 
 
@@ -314,6 +328,7 @@ class _ConvSame(torch.autograd.Function):
         ctx.save_for_backward(feats, W3)
         ctx.nbr, ctx.get_rulebook = nbr, get_rulebook
         ctx.w_dim, ctx.has_bias = W.dim(), bias is not None
+        ctx.w_param = W
         return out
 
     @staticmethod
@@ -326,12 +341,15 @@ class _ConvSame(torch.autograd.Function):
             Wt = weight_transpose(W3.contiguous(), mirror=K > 1)
             dfeats = gather_gemm(dout, Wt, ctx.nbr, feats.shape[0])
         if ctx.needs_input_grad[1]:
+            tgt = _grad_target(ctx.w_param)
             if ctx.nbr is None:
-                dW = wgrad(feats, dout, 1)
+                dW = wgrad(feats, dout, 1, into=tgt)
             else:
                 rb = ctx.get_rulebook()
-                dW = wgrad(feats, dout, K, rb.in_idx, rb.out_idx, rb.koff)
-            if ctx.w_dim == 2:
+                dW = wgrad(feats, dout, K, rb.in_idx, rb.out_idx, rb.koff, into=tgt)
+            if tgt is not None:
+                dW = None
+            elif ctx.w_dim == 2:
                 dW = dW[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = colsum(dout).reshape(1, -1)
@@ -347,6 +365,7 @@ class _ConvDown2(torch.autograd.Function):
         out = gather_gemm(feats, W.contiguous(), nbr2, nbr2.shape[1])
         ctx.save_for_backward(feats, W)
         ctx.nbr2, ctx.get_rulebook = nbr2, get_rulebook
+        ctx.w_param = W
         return out
 
     @staticmethod
@@ -359,7 +378,10 @@ class _ConvDown2(torch.autograd.Function):
             Wt = weight_transpose(W.contiguous(), mirror=False)
             dfeats = pairs_gemm(dout, Wt, rb.out_idx, rb.in_idx, rb.koff, feats.shape[0], feats.shape[0])
         if ctx.needs_input_grad[1]:
-            dW = wgrad(feats, dout, W.shape[0], rb.in_idx, rb.out_idx, rb.koff)
+            tgt = _grad_target(ctx.w_param)
+            dW = wgrad(feats, dout, W.shape[0], rb.in_idx, rb.out_idx, rb.koff, into=tgt)
+            if tgt is not None:
+                dW = None
         return dfeats, dW, None, None
 
 
@@ -373,6 +395,7 @@ class _ConvTrUp2(torch.autograd.Function):
         out = pairs_gemm(feats, W.contiguous(), rb.out_idx, rb.in_idx, rb.koff, n_fine, n_fine)
         ctx.save_for_backward(feats, W)
         ctx.nbr2, ctx.rb = nbr2, rb
+        ctx.w_param = W
         return out
 
     @staticmethod
@@ -385,7 +408,10 @@ class _ConvTrUp2(torch.autograd.Function):
             Wt = weight_transpose(W.contiguous(), mirror=False)
             dfeats = gather_gemm(dout, Wt, ctx.nbr2, feats.shape[0])
         if ctx.needs_input_grad[1]:
-            dW = wgrad(feats, dout, W.shape[0], rb.out_idx, rb.in_idx, rb.koff)
+            tgt = _grad_target(ctx.w_param)
+            dW = wgrad(feats, dout, W.shape[0], rb.out_idx, rb.in_idx, rb.koff, into=tgt)
+            if tgt is not None:
+                dW = None
         return dfeats, dW, None, None, None
 
 
@@ -453,6 +479,7 @@ class _BatchNormAct(torch.autograd.Function):
         y = bn_apply(x, scale, shift, res, relu)
         ctx.save_for_backward(x, gamma, mean, invstd, y if relu else None)
         ctx.relu, ctx.has_res, ctx.training = relu, residual is not None, training
+        ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
 
     @staticmethod
@@ -463,14 +490,17 @@ class _BatchNormAct(torch.autograd.Function):
         dev = x.device
         red = torch.empty((4, c), dtype=torch.float32, device=dev)   # dgamma | dbeta | mean_g | mean_gx
         ws = _ws(lib.usc_colstats_ws_bytes(n, c), dev)
+        tg, tb = _grad_target(ctx.gamma_param), _grad_target(ctx.beta_param)
+        in_place = tg is not None and tb is not None
+        dg, db = (tg, tb) if in_place else (red[0], red[1])
         check(lib.usc_bn_backward_reduce(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), n, c,
-                                         int(ctx.training), _ptr(red[0]), _ptr(red[1]), _ptr(red[2]), _ptr(red[3]),
+                                         int(ctx.training), int(in_place), _ptr(dg), _ptr(db), _ptr(red[2]), _ptr(red[3]),
                                          _ptr(ws), ws.numel(), _stream()), "usc_bn_backward_reduce")
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         check(lib.usc_bn_backward_dx(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(red[2]),
                                      _ptr(red[3]), _ptr(dx), _ptr(dres), n, c, _stream()), "usc_bn_backward_dx")
-        return dx, red[0], red[1], dres, None, None, None, None, None, None
+        return dx, (None if in_place else red[0]), (None if in_place else red[1]), dres, None, None, None, None, None, None
 
 
 def batch_norm_act(x, gamma, beta, residual=None, relu=False, eps=1e-5, running_mean=None, running_var=None,
