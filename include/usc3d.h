@@ -310,7 +310,8 @@ int usc_segment_mean_nonzero(const float* feats, int32_t d,
 /* Linear layer on a handful of rows (the 100 decoder queries):
  *   y[M,N] = x[M,K] W[N,K]^T + b[N]   (b may be NULL);  N, K multiples of 32.
  * usc_linear_bwd: dx[M,K] = dy W, dW[N,K] = dy^T x, db[N] = column sums of dy; each
- * of dx / dW may be NULL to skip it (db is produced with dW).  One wave per 32x32
+ * of dx / dW may be NULL to skip it (db is produced with dW); accumulate=1 adds
+ * dW / db into the given buffers (parameter gradients).  One workgroup per 32x32
  * output tile on the f32 matrix cores, one launch per product.
  * Replaces nn.Linear / the nn.MultiheadAttention projections of the mask decoder
  * (models/mask3d.py:491-651 attention layers and FFN, :70-72 mask_embed_head). */
@@ -318,12 +319,13 @@ int usc_linear_fwd(const float* x, const float* W, const float* b, int32_t M,
                    int32_t N, int32_t K, float* y, usc_stream_t s);
 int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M,
                    int32_t N, int32_t K, float* dx, float* dW, float* db,
-                   usc_stream_t s);
+                   int32_t accumulate, usc_stream_t s);
 
 /* LayerNorm over the last dimension of x f32[rows, d] (d in 64*{1,2,3,4,6,8}):
  *   y = (x - mean) * rstd * gamma + beta,  rstd = 1/sqrt(var + eps)  (biased var);
  * mean/rstd f32[rows] are saved for the backward, which is ONE launch for
- * rows <= 1024 (dx, dgamma, dbeta; column sums reduced in a fixed wave order).
+ * rows <= 1024 (dx, dgamma, dbeta; column sums reduced in a fixed wave order;
+ * accumulate=1 adds dgamma / dbeta into the given buffers).
  * Replaces nn.LayerNorm of the mask decoder (models/mask3d.py:174 decoder_norm,
  * :515/:572/:627 post-norms of SelfAttentionLayer / CrossAttentionLayer / FFNLayer). */
 int usc_layernorm_fwd(const float* x, const float* gamma, const float* beta,
@@ -333,7 +335,8 @@ int64_t usc_layernorm_bwd_ws_bytes(int64_t rows, int32_t d);
 int usc_layernorm_bwd(const float* dy, const float* x, const float* mean,
                       const float* rstd, const float* gamma, int64_t rows,
                       int32_t d, float* dx, float* dgamma, float* dbeta,
-                      void* ws, int64_t ws_bytes, usc_stream_t s);
+                      int32_t accumulate, void* ws, int64_t ws_bytes,
+                      usc_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Q1  furthest point sampling — replaces pointnet2._ext.furthest_point_sampling

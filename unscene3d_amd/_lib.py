@@ -73,10 +73,10 @@ SIGNATURES = {
     "usc_project_planes_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32] + [_p] * 10),
     "usc_project_planes_bwd": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "usc_linear_fwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),
-    "usc_linear_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "usc_linear_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     "usc_layernorm_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _p, _p, _p, _p]),
     "usc_layernorm_bwd_ws_bytes": (_i64, [_i64, _i32]),
-    "usc_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i64, _p]),
+    "usc_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
     "usc_furthest_point_sampling": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "usc_fourier_posenc": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p, _p]),
 }

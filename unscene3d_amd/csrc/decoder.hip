@@ -41,7 +41,8 @@ template <int PER>
 __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int64_t rows, int d,
-                                                            int64_t rows_per_block, float* __restrict__ dx,
+                                                            int64_t rows_per_block, int accumulate,
+                                                            float* __restrict__ dx,
                                                             float* __restrict__ part /* [G][2][d] or dgamma/dbeta */,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[16][2][64 * PER];
@@ -79,19 +80,25 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(const float* __rest
     float s = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) s += red[w][which][col];
-    if (gridDim.x == 1) (which == 0 ? dgamma : dbeta)[col] = s;
-    else part[((int64_t)blockIdx.x * 2 + which) * d + col] = s;
+    if (gridDim.x == 1) {
+      float* dst = (which == 0 ? dgamma : dbeta) + col;
+      *dst = accumulate ? *dst + s : s;
+    } else {
+      part[((int64_t)blockIdx.x * 2 + which) * d + col] = s;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void layernorm_bwd_final_kernel(const float* __restrict__ part, int G, int d,
-                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                                 int accumulate, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= 2 * d) return;
   const int which = c / d, col = c - which * d;
   float s = 0.f;
   for (int b = 0; b < G; ++b) s += part[((int64_t)b * 2 + which) * d + col];
-  (which == 0 ? dgamma : dbeta)[col] = s;
+  float* dst = (which == 0 ? dgamma : dbeta) + col;
+  *dst = accumulate ? *dst + s : s;
 }
 
 constexpr int64_t kLnRowsPerBlock = 1024;
@@ -127,14 +134,14 @@ int64_t usc_layernorm_bwd_ws_bytes(int64_t rows, int32_t d) {
 }
 
 int usc_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                      int64_t rows, int32_t d, float* dx, float* dgamma, float* dbeta, void* ws, int64_t ws_bytes,
-                      usc_stream_t s) {
+                      int64_t rows, int32_t d, float* dx, float* dgamma, float* dbeta, int32_t accumulate, void* ws,
+                      int64_t ws_bytes, usc_stream_t s) {
   USC_REQUIRE(rows >= 1 && d >= 64 && d % 64 == 0 && d <= 64 * kLnMaxPerLane, "usc_layernorm_bwd: bad sizes");
   USC_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "usc_layernorm_bwd: null pointer");
   const int64_t G = ceil_div(rows, kLnRowsPerBlock);
   USC_REQUIRE(G == 1 || (ws && ws_bytes >= G * 2 * d * 4), "usc_layernorm_bwd: workspace too small");
   hipStream_t st = as_stream(s);
-#define USC_LN_B(P) hipLaunchKernelGGL((layernorm_bwd_kernel<P>), dim3((unsigned)G), dim3(1024), 0, st, dy, x, mean, rstd, gamma, rows, (int)d, kLnRowsPerBlock, dx, (float*)ws, dgamma, dbeta)
+#define USC_LN_B(P) hipLaunchKernelGGL((layernorm_bwd_kernel<P>), dim3((unsigned)G), dim3(1024), 0, st, dy, x, mean, rstd, gamma, rows, (int)d, kLnRowsPerBlock, (int)accumulate, dx, (float*)ws, dgamma, dbeta)
   switch (d / 64) {
     case 1: USC_LN_B(1); break;  case 2: USC_LN_B(2); break;  case 3: USC_LN_B(3); break;  case 4: USC_LN_B(4); break;
     case 6: USC_LN_B(6); break;  case 8: USC_LN_B(8); break;
@@ -143,7 +150,7 @@ int usc_layernorm_bwd(const float* dy, const float* x, const float* mean, const 
 #undef USC_LN_B
   if (G > 1)
     hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3((unsigned)ceil_div(2 * d, 256)), dim3(256), 0, st,
-                       (const float*)ws, (int)G, (int)d, dgamma, dbeta);
+                       (const float*)ws, (int)G, (int)d, (int)accumulate, dgamma, dbeta);
   USC_CHECK_LAUNCH("usc_layernorm_bwd");
   return USC_OK;
 }
@@ -167,7 +174,8 @@ __device__ inline int acc_row16(int reg, int half) { return (reg & 3) + 8 * (reg
 // (one wave per tile was latency bound: 32 dependent load->MFMA rounds for the 1024-wide FFN), partial tiles are
 // summed through LDS in wave order (deterministic), each wave finalising four of the sixteen accumulator rows.
 __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int wave, int lane, float* __restrict__ out,
-                                         int64_t ld, int row0, int col0, int max_row, const float* __restrict__ bias) {
+                                         int64_t ld, int row0, int col0, int max_row, const float* __restrict__ bias,
+                                         int accumulate = 0) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
@@ -177,7 +185,10 @@ __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int w
     const int r = 4 * wave + q;
     const float v = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
     const int row = row0 + acc_row16(r, h);
-    if (row < max_row) out[(int64_t)row * ld + col0 + i] = v + (bias ? bias[col0 + i] : 0.f);
+    if (row < max_row) {
+      float* dst = out + (int64_t)row * ld + col0 + i;
+      *dst = v + (bias ? bias[col0 + i] : 0.f) + (accumulate ? *dst : 0.f);
+    }
   }
 }
 
@@ -248,7 +259,8 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
 
 // dW[N,K] = dy[M,N]^T x[M,K],  db[N] = sum_m dy[m][N]       grid (K/32, N/32)
 __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M,
-                                                       int N, int K, float* __restrict__ dW, float* __restrict__ db) {
+                                                       int N, int K, int accumulate, float* __restrict__ dW,
+                                                       float* __restrict__ db) {
   __shared__ float red[4][16][64];
   __shared__ float bred[4][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -275,9 +287,11 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
     bsum += __shfl_xor(bsum, 32, 64);
     if (h == 0) bred[wave][i] = bsum;
   }
-  tile_reduce_store(acc, red, wave, lane, dW, K, n0, c0, N, nullptr);   // contains the __syncthreads
-  if (db && blockIdx.x == 0 && threadIdx.x < 32)
-    db[n0 + threadIdx.x] = bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x];
+  tile_reduce_store(acc, red, wave, lane, dW, K, n0, c0, N, nullptr, accumulate);   // contains the __syncthreads
+  if (db && blockIdx.x == 0 && threadIdx.x < 32) {
+    const float v = bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x];
+    db[n0 + threadIdx.x] = accumulate ? db[n0 + threadIdx.x] + v : v;
+  }
 }
 
 }  // namespace
@@ -296,12 +310,12 @@ int usc_linear_fwd(const float* x, const float* W, const float* b, int32_t M, in
 }
 
 int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M, int32_t N, int32_t K, float* dx, float* dW,
-                   float* db, usc_stream_t s) {
+                   float* db, int32_t accumulate, usc_stream_t s) {
   USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_bwd: N, K must be multiples of 32");
   USC_REQUIRE(dy && x && W, "usc_linear_bwd: null pointer");
   hipStream_t st = usc::as_stream(s);
   if (dx) hipLaunchKernelGGL(usc::linear_dx_kernel, dim3(K / 32, (M + 31) / 32), dim3(256), 0, st, dy, W, (int)M, (int)N, (int)K, dx);
-  if (dW) hipLaunchKernelGGL(usc::linear_dw_kernel, dim3(K / 32, N / 32), dim3(256), 0, st, dy, x, (int)M, (int)N, (int)K, dW, db);
+  if (dW) hipLaunchKernelGGL(usc::linear_dw_kernel, dim3(K / 32, N / 32), dim3(256), 0, st, dy, x, (int)M, (int)N, (int)K, (int)accumulate, dW, db);
   USC_CHECK_LAUNCH("usc_linear_bwd");
   return USC_OK;
 }

@@ -708,6 +708,7 @@ class _LayerNorm(torch.autograd.Function):
                                     _ptr(rstd), _stream()), "usc_layernorm_fwd")
         ctx.save_for_backward(x2, weight, mean, rstd)
         ctx.shape = x.shape
+        ctx.w_param, ctx.b_param = weight, bias
         return y.view(x.shape)
 
     @staticmethod
@@ -716,12 +717,17 @@ class _LayerNorm(torch.autograd.Function):
         rows, d = x2.shape
         dy2 = dy.contiguous().view(rows, d)
         dx = torch.empty_like(x2)
-        dgamma = torch.empty_like(weight)
-        dbeta = torch.empty_like(weight)
+        tg, tb = _grad_target(ctx.w_param), _grad_target(ctx.b_param)
+        in_place = tg is not None and tb is not None
+        dgamma = tg if in_place else torch.empty_like(weight)
+        dbeta = tb if in_place else torch.empty_like(weight)
         wsb = lib.usc_layernorm_bwd_ws_bytes(rows, d)
         ws = _ws(wsb, x2.device) if wsb > 0 else None
         check(lib.usc_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(mean), _ptr(rstd), _ptr(weight), rows, d, _ptr(dx),
-                                    _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb, _stream()), "usc_layernorm_bwd")
+                                    _ptr(dgamma), _ptr(dbeta), int(in_place), _ptr(ws), wsb, _stream()),
+              "usc_layernorm_bwd")
+        if in_place:
+            dgamma = dbeta = None
         return dx.view(ctx.shape), dgamma, dbeta, None
 
 
@@ -752,18 +758,23 @@ def _lin_fwd(x2, W, b):
     return torch.addmm(b, x2, W.t()) if b is not None else x2 @ W.t()
 
 
-def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True):
-    """-> dx (or None); writes dW_out [N,K] and db_out [N] (views of larger gradient tensors are fine)."""
+def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False):
+    """-> dx (or None); writes (accumulate: adds) dW_out [N,K] and db_out [N] (row-block views are fine)."""
     M, N = dy2.shape
     K = x2.shape[1]
     if _small_linear_ok(M, K, N):
         dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device) if need_dx else None
-        check(lib.usc_linear_bwd(_ptr(dy2), _ptr(x2), _ptr(W), M, N, K, _ptr(dx), _ptr(dW_out), _ptr(db_out), _stream()),
-              "usc_linear_bwd")
+        check(lib.usc_linear_bwd(_ptr(dy2), _ptr(x2), _ptr(W), M, N, K, _ptr(dx), _ptr(dW_out), _ptr(db_out),
+                                 int(accumulate), _stream()), "usc_linear_bwd")
         return dx
-    torch.mm(dy2.t(), x2, out=dW_out)
-    if db_out is not None:
-        torch.sum(dy2, 0, out=db_out)
+    if accumulate:
+        dW_out.addmm_(dy2.t(), x2)
+        if db_out is not None:
+            db_out.add_(dy2.sum(0))
+    else:
+        torch.mm(dy2.t(), x2, out=dW_out)
+        if db_out is not None:
+            torch.sum(dy2, 0, out=db_out)
     return dy2 @ W if need_dx else None
 
 
@@ -773,15 +784,24 @@ class _LinearRows(torch.autograd.Function):
         x2 = x.contiguous().view(-1, x.shape[-1])
         ctx.save_for_backward(x2, W)
         ctx.has_bias, ctx.shape = b is not None, x.shape
+        ctx.w_param, ctx.b_param = W, b
         return _lin_fwd(x2, W, b).view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, W = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
-        dW = torch.empty_like(W)
-        db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_bias else None
-        dx = _lin_bwd(dy2, x2, W, dW, db, need_dx=ctx.needs_input_grad[0])
+        tw = _grad_target(ctx.w_param)
+        tb = _grad_target(ctx.b_param) if ctx.has_bias else None
+        in_place = tw is not None and (tb is not None or not ctx.has_bias)
+        if in_place:
+            dW, db = tw, tb
+        else:
+            dW = torch.empty_like(W)
+            db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_bias else None
+        dx = _lin_bwd(dy2, x2, W, dW, db, need_dx=ctx.needs_input_grad[0], accumulate=in_place)
+        if in_place:
+            dW = db = None
         return (None if dx is None else dx.view(ctx.shape)), dW, db
 
 
@@ -803,6 +823,7 @@ class _InProj(torch.autograd.Function):
         outs = [_lin_fwd(xs[j], W[j * E:(j + 1) * E], b[j * E:(j + 1) * E]) for j in range(3)]
         ctx.save_for_backward(xs[0], xs[1], xs[2], W)
         ctx.shapes = (xq.shape, xk.shape, xv.shape)
+        ctx.w_param, ctx.b_param = W, b
         ctx.same_qk = xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape
         return tuple(o.view(*shp[:-1], E) for o, shp in zip(outs, ctx.shapes))
 
@@ -810,13 +831,20 @@ class _InProj(torch.autograd.Function):
     def backward(ctx, dq, dk, dv):
         x0, x1, x2, W = ctx.saved_tensors
         E = W.shape[1]
-        dW = torch.empty_like(W)
-        db = torch.empty(3 * E, dtype=torch.float32, device=W.device)
+        tw, tb = _grad_target(ctx.w_param), _grad_target(ctx.b_param)
+        in_place = tw is not None and tb is not None
+        if in_place:
+            dW, db = tw, tb
+        else:
+            dW = torch.empty_like(W)
+            db = torch.empty(3 * E, dtype=torch.float32, device=W.device)
         dxs = []
         for j, (dyj, xj) in enumerate(zip((dq, dk, dv), (x0, x1, x2))):
             dy2 = dyj.contiguous().view(-1, E)
             dxs.append(_lin_bwd(dy2, xj, W[j * E:(j + 1) * E], dW[j * E:(j + 1) * E], db[j * E:(j + 1) * E],
-                                need_dx=ctx.needs_input_grad[j]))
+                                need_dx=ctx.needs_input_grad[j], accumulate=in_place))
+        if in_place:
+            dW = db = None
         return tuple(None if d is None else d.view(shp) for d, shp in zip(dxs, ctx.shapes)) + (dW, db)
 
 
