@@ -747,6 +747,105 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
   }
 }
 
+// wgrad, all of Cin (or half of it) per workgroup: a wave keeps CT x NB accumulator tiles (CT input-channel tiles
+// x NB output-column tiles) and walks a contiguous chunk of the offset's pair list; per pair-step it issues TWO
+// vector loads (A: a[in][ci0 + CT*i ..+CT), B: b[out][co0 + NB*i ..+NB)) for CT*NB MFMAs.  The older kernel gave every
+// 32-channel input tile its own workgroup: each pair's 384-byte b row was gathered Cin/32 times, with 12-byte
+// stride-12 loads.  Cross-wave reduction through one LDS tile in three ordered rounds (deterministic).
+template <int CT, int NB>
+__global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
+  extern __shared__ float red[];  // [CT*NB*16 regs][64 lanes]
+  constexpr int NA = CT * NB;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int k = blockIdx.x / p.S, s = blockIdx.x % p.S;
+  const int ci0 = blockIdx.y * (32 * CT), co0 = blockIdx.z * (NB * 32);
+  const int cin = p.cin, cout = p.cout;
+  int64_t pb, pe;
+  if (p.a_idx) { pb = p.koff[k]; pe = p.koff[k + 1]; } else { pb = 0; pe = p.n_rows; }
+  const int64_t nchunks = (int64_t)p.S * 4;
+  int64_t L = (pe - pb + nchunks - 1) / nchunks;
+  L = (L + 7) & ~7ll;                                  // whole batches of 8 pairs per wave
+  const int64_t cb = pb + ((int64_t)s * 4 + wave) * L;
+  int64_t ce = cb + L;
+  if (ce > pe) ce = pe;
+
+  f32x16 acc[NA];
+#pragma unroll
+  for (int t = 0; t < NA; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // a batch = 8 pairs = 4 pair-steps (lane half h takes pairs 2u + h); lanes 0-7 fetch a-row ids, 8-15 b-row ids
+  auto load_idx = [&](int64_t q) __attribute__((always_inline)) -> int {
+    int v = -1;
+    const int64_t pp = q + (lane & 7);
+    if (lane < 16 && pp < ce) v = p.a_idx ? ((lane < 8) ? p.a_idx[pp] : p.b_idx[pp]) : (int)pp;
+    return v;
+  };
+  auto load_rows = [&](int idxreg, float (&av)[4][CT], float (&bv)[4][NB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ia = __shfl(idxreg, 2 * u + h, 64);
+      const int ib = __shfl(idxreg, 8 + 2 * u + h, 64);
+      // MFMA row i of accumulator (ct, .) is input channel ci0 + CT*i + ct, MFMA column i of accumulator (., nb) is
+      // output channel co0 + NB*i + nb: a lane's CT A operands and NB B operands are each ONE vector load
+      const float* ap = p.a + (int64_t)(ia >= 0 ? ia : 0) * cin + ci0 + CT * i;
+      const float* bp = p.b + (int64_t)(ib >= 0 ? ib : 0) * cout + co0 + NB * i;
+      const float keep = ia >= 0 ? 1.f : 0.f;          // padding pairs: zero the A operand
+      load_b<CT>(ap, av[u]);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) av[u][ct] *= keep;
+      load_b<NB>(bp, bv[u]);
+    }
+  };
+  auto run = [&](float (&av)[4][CT], float (&bv)[4][NB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[ct * NB + nb] = MFMA32(av[u][ct], bv[u][nb], acc[ct * NB + nb]);
+  };
+  float aX[4][CT], aY[4][CT], bX[4][NB], bY[4][NB];
+  int id1 = load_idx(cb), id2 = load_idx(cb + 8);
+  load_rows(id1, aX, bX);
+  for (int64_t q = cb; q < ce; q += 16) {
+    const int id3 = load_idx(q + 16);
+    load_rows(id2, aY, bY);
+    run(aX, bX);
+    id2 = load_idx(q + 24);
+    load_rows(id3, aX, bX);
+    if (q + 8 < ce) run(aY, bY);
+  }
+
+  // ordered reduction: wave 3 -> LDS, wave 2 adds, wave 1 adds, wave 0 adds and writes the partial slice
+  for (int w = 3; w >= 1; --w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NA; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* slot = red + (t * 16 + r) * 64 + lane;
+          *slot = (w == 3 ? 0.f : *slot) + acc[t][r];
+        }
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    float* dst = p.partial + ((int64_t)s * p.K + k) * cin * cout;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ci = ci0 + CT * acc_row(r, h) + ct;
+          dst[(int64_t)ci * cout + co0 + NB * i + nb] = acc[ct * NB + nb][r] + red[((ct * NB + nb) * 16 + r) * 64 + lane];
+        }
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t numel, int accumulate,
                                     float* __restrict__ dW) {
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < numel; j += (int64_t)gridDim.x * blockDim.x) {
@@ -996,17 +1095,48 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
   USC_REQUIRE(cin >= 1 && cout >= 1 && K >= 1 && n_rows >= 0, "usc_spconv_wgrad: bad sizes");
   USC_REQUIRE(a && b && dW && ws, "usc_spconv_wgrad: null pointer");
   USC_REQUIRE((a_idx && b_idx && koff) || (!a_idx && K == 1), "usc_spconv_wgrad: pair lists required for K>1");
+  const int64_t numel = (int64_t)K * cin * cout;
+  hipStream_t st = as_stream(s);
+  WgradParams p{};
+  p.a = a; p.b = b; p.a_idx = a_idx; p.b_idx = b_idx; p.koff = koff; p.n_rows = n_rows;
+  p.partial = (float*)ws; p.cin = cin; p.cout = cout; p.K = K;
+#ifndef USC_WGRAD_LEGACY
+  const int ctiles = cin / 32, cb = cout / 32;
+  const int NBf = (cb % 3 == 0) ? 3 : (cb % 4 == 0 ? 4 : (cb % 2 == 0 ? 2 : 1));
+  // (128 -> 96 channels would need 4x3 tiles = 256 VGPRs + scratch, or 2x3 twice: both measured slower than the
+  //  per-input-tile kernel below, 0.78 / 0.82 vs 0.73 ms)
+  if (cin % 32 == 0 && cout % 32 == 0 && !(NBf == 3 && ctiles % 3 != 0)) {
+    // CT input tiles x NB column tiles per wave, CT*NB <= 9 accumulator tiles
+    const int CT = (ctiles % 3 == 0 && NBf * 3 <= 9) ? 3 : ((ctiles % 4 == 0 && NBf * 4 <= 9) ? 4 : ((ctiles % 2 == 0 && NBf * 2 <= 9) ? 2 : 1));
+    const int64_t blocks_per_split = (int64_t)K * (ctiles / CT) * (cb / NBf);
+    int64_t S = 512 / blocks_per_split;                         // one round of 2 workgroups per CU
+    const int64_t by_rows = n_rows / 4096 + 1;
+    if (S > by_rows) S = by_rows;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    USC_REQUIRE(ws_bytes >= S * numel * 4, "usc_spconv_wgrad: workspace too small");
+    p.S = (int)S;
+    dim3 grid((unsigned)(K * S), (unsigned)(ctiles / CT), (unsigned)(cb / NBf));
+    const size_t lds = (size_t)CT * NBf * 16 * 64 * sizeof(float);
+#define USC_WF(C, N) if (CT == C && NBf == N) { \
+      static bool attr_set = false; auto kfn = wgrad_full_kernel<C, N>; \
+      if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; } \
+      hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p); }
+    USC_WF(3, 3) USC_WF(2, 3) USC_WF(1, 3) USC_WF(2, 4) USC_WF(1, 4) USC_WF(4, 2) USC_WF(3, 2) USC_WF(2, 2) USC_WF(1, 2) USC_WF(4, 1) USC_WF(3, 1) USC_WF(2, 1) USC_WF(1, 1)
+#undef USC_WF
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, (int)S, numel,
+                       (int)accumulate, dW);
+    USC_CHECK_LAUNCH("usc_spconv_wgrad");
+    return USC_OK;
+  }
+#endif
   const int NB = pick_nb(cout);
   const bool aligned = (cin % 32 == 0) && (cout % (NB * 32) == 0);
   const int S = wgrad_splits(K, cin, cout, NB, n_rows);
-  const int64_t numel = (int64_t)K * cin * cout;
   USC_REQUIRE(ws_bytes >= (int64_t)S * numel * 4, "usc_spconv_wgrad: workspace too small");
-  WgradParams p{};
-  p.a = a; p.b = b; p.a_idx = a_idx; p.b_idx = b_idx; p.koff = koff; p.n_rows = n_rows;
-  p.partial = (float*)ws; p.cin = cin; p.cout = cout; p.K = K; p.S = S;
+  p.S = S;
   dim3 grid((unsigned)(K * S), (unsigned)ceil_div(cin, 32), (unsigned)ceil_div(cout, NB * 32));
   const size_t lds = (size_t)3 * NB * 16 * 64 * sizeof(float);
-  hipStream_t st = as_stream(s);
 #define USC_WG(NBv)                                                                          \
   if (aligned) hipLaunchKernelGGL((wgrad_kernel<NBv, true>), grid, dim3(256), lds, st, p);  \
   else hipLaunchKernelGGL((wgrad_kernel<NBv, false>), grid, dim3(256), lds, st, p);
