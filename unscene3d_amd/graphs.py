@@ -15,6 +15,10 @@ from __future__ import annotations
 
 import torch
 
+# "thread_local": other threads of the process (the RCCL watchdog polls events while a multi-GPU job captures) may
+# keep issuing HIP calls during capture without invalidating it
+_CAPTURE_MODE = "thread_local"
+
 
 class _Runner:
     def __init__(self, module, sample_inputs, params):
@@ -98,12 +102,12 @@ def capture_passes(modules, sample_inputs, warmup_iters: int = 3):
     # all forward graphs first, then the backward graphs in reverse order: the pool's liveness during capture
     # then mirrors the liveness during a training step (fwd 0..n-1, bwd n-1..0)
     for r in runners:
-        with torch.cuda.graph(r.fwd_graph, pool=pool):
+        with torch.cuda.graph(r.fwd_graph, pool=pool, capture_error_mode=_CAPTURE_MODE):
             r.static_out = r.module(*r.static_in)
     for r in reversed(runners):
         r.static_grad_out = torch.zeros_like(r.static_out)
         targets = [r.static_in[j] for j in r.grad_in_idx] + r.params
-        with torch.cuda.graph(r.bwd_graph, pool=pool):
+        with torch.cuda.graph(r.bwd_graph, pool=pool, capture_error_mode=_CAPTURE_MODE):
             grads = torch.autograd.grad((r.static_out,), targets, (r.static_grad_out,), allow_unused=True)
             n_in = len(r.grad_in_idx)
             dst = [p.grad for p, g in zip(r.params, grads[n_in:]) if g is not None]
