@@ -307,6 +307,25 @@ int usc_segment_mean_nonzero(const float* feats, int32_t d,
                              int64_t S, float* out, int64_t* nonzero_cnt,
                              usc_stream_t s);
 
+/* Masked cross attention of the mask decoder, all heads at once:
+ *   o = softmax(q k^T / sqrt(16) + mask) v   per (batch, head), head dim 16, L <= 128 queries,
+ * q, o f32[L,B,E], k, v f32[S,B,E] (sequence-first, E = 16*H), mask u8[B,S,L] (non-zero =
+ * masked, shared by the heads).  No [heads, L, S] tensor is materialised: the forward is split
+ * over keys (partial (o, max, sum) per split + a combine pass) and saves lse f32[B*H,128]; the
+ * backward recomputes the probabilities and reduces dq partials in a fixed order.
+ * Replaces nn.MultiheadAttention's attention core in CrossAttentionLayer
+ * (models/mask3d.py:547-605; memory_mask built at :341-348). */
+int64_t usc_attn_ws_bytes(int32_t L, int32_t S, int32_t B, int32_t H);
+int usc_attn_fwd(const float* q, const float* k, const float* v,
+                 const uint8_t* mask, int32_t L, int32_t S, int32_t B, int32_t H,
+                 int32_t E, float* o, float* lse, void* ws, int64_t ws_bytes,
+                 usc_stream_t s);
+int usc_attn_bwd(const float* q, const float* k, const float* v,
+                 const uint8_t* mask, const float* o, const float* lse,
+                 const float* dO, int32_t L, int32_t S, int32_t B, int32_t H,
+                 int32_t E, float* dq, float* dk, float* dv, void* ws,
+                 int64_t ws_bytes, usc_stream_t s);
+
 /* Linear layer on a handful of rows (the 100 decoder queries):
  *   y[M,N] = x[M,K] W[N,K]^T + b[N]   (b may be NULL);  N, K multiples of 32.
  * usc_linear_bwd: dx[M,K] = dy W, dW[N,K] = dy^T x, db[N] = column sums of dy; each

@@ -712,6 +712,35 @@ def test_multihead_attention_matches_nn_module(device, S):
         assert rel_err(b, a) < 1e-4
 
 
+@pytest.mark.parametrize("L,S,B", [(100, 3200, 1), (100, 200, 2), (37, 1000, 1), (128, 12800, 1)])
+def test_fused_masked_cross_attention(device, L, S, B):
+    """usc_attn_fwd/bwd vs softmax(q k^T / sqrt(hd) + mask) v in float64 (forward and dq, dk, dv), incl. ragged
+    key counts, several batches, and keys masked for every query."""
+    from unscene3d_amd import ops
+
+    H, hd = 8, 16
+    E = H * hd
+    g = torch.Generator().manual_seed(L + S)
+    q, k, v = torch.randn(L, B, E, generator=g), torch.randn(S, B, E, generator=g), torch.randn(S, B, E, generator=g)
+    mask = torch.rand(B, S, L, generator=g) > 0.5
+    mask[:, 0, :] = False                                  # every query keeps at least one key
+    mask[:, 5, :] = True                                   # a key nobody attends to
+    do = torch.randn(L, B, E, generator=g)
+    qr, kr, vr = (t.double().requires_grad_() for t in (q, k, v))
+    qh = qr.reshape(L, B * H, hd).transpose(0, 1)
+    kh = kr.reshape(S, B * H, hd).transpose(0, 1)
+    vh = vr.reshape(S, B * H, hd).transpose(0, 1)
+    bias = torch.zeros(B, H, L, S, dtype=torch.float64).masked_fill_(mask.permute(0, 2, 1)[:, None], float("-inf"))
+    sc = qh @ kh.transpose(1, 2) / 4.0 + bias.reshape(B * H, L, S)
+    ref = (torch.softmax(sc, -1) @ vh).transpose(0, 1).reshape(L, B, E)
+    ref.backward(do.double())
+    qd, kd, vd = (_dev(t, device).requires_grad_() for t in (q, k, v))
+    out = ops.masked_cross_attention(qd, kd, vd, _dev(mask, device), H)
+    out.backward(_dev(do, device))
+    assert rel_err(out.detach(), ref.detach()) < 1e-5
+    assert rel_err(qd.grad, qr.grad) < 1e-5 and rel_err(kd.grad, kr.grad) < 1e-5 and rel_err(vd.grad, vr.grad) < 1e-5
+
+
 def test_knn1_matches_kdtree(device):
     from scipy.spatial import KDTree
     from unscene3d_amd import ops

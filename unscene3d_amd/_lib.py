@@ -72,6 +72,9 @@ SIGNATURES = {
     "usc_cc_eps_finish": (C.c_int, [_p, _i64, _p, _p, _p]),
     "usc_project_planes_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32] + [_p] * 10),
     "usc_project_planes_bwd": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
+    "usc_attn_ws_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "usc_attn_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p]),
+    "usc_attn_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
     "usc_linear_fwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),
     "usc_linear_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     "usc_layernorm_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _p, _p, _p, _p]),

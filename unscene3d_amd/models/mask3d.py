@@ -317,7 +317,7 @@ class Linear(nn.Linear):
         return super().forward(x)
 
 
-def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None):
+def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None, mask_bsl=None):
     """nn.MultiheadAttention.forward(query, key, value, attn_mask=…, need_weights=False)[0] for the
     sequence-first layout, dropout 0 and a boolean mask (True = masked), with the input / output projections
     through ops.in_proj / ops.linear (same parameters, same state_dict)."""
@@ -326,6 +326,12 @@ def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask
     H = mha.num_heads
     hd = E // H
     q, k, v = ops.in_proj(query, key, value, mha.in_proj_weight, mha.in_proj_bias)
+    if mask_bsl is not None and hd == 16 and L <= 128:
+        # `mask_bsl` = the decoder's bool[B, S, L] mask (same for every head): fused HIP kernels, no score tensor
+        out = ops.masked_cross_attention(q, k, v, mask_bsl, H)
+        return ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    if mask_bsl is not None:
+        attn_mask = mask_bsl.repeat_interleave(H, dim=0).permute(0, 2, 1)
     q = q.reshape(L, B * H, hd).transpose(0, 1).reshape(B, H, L, hd)
     k = k.reshape(S, B * H, hd).transpose(0, 1).reshape(B, H, S, hd)
     v = v.reshape(S, B * H, hd).transpose(0, 1).reshape(B, H, S, hd)
@@ -371,8 +377,7 @@ class _DecoderPass(nn.Module):
         src = self.squeeze(batched_aux.permute(1, 0, 2))
         if self.level_embed is not None:
             src = src + self.level_embed
-        out = self.cross(queries.permute(1, 0, 2), src,
-                         memory_mask=batched_attn.repeat_interleave(self.num_heads, dim=0).permute(0, 2, 1),
+        out = self.cross(queries.permute(1, 0, 2), src, memory_mask=None, memory_mask_bsl=batched_attn,
                          memory_key_padding_mask=None, pos=batched_pos_enc.permute(1, 0, 2), query_pos=query_pos)
         out = self.self_attn(out, tgt_mask=None, tgt_key_padding_mask=None, query_pos=query_pos)
         return self.ffn(out).permute(1, 0, 2)
@@ -426,11 +431,16 @@ class CrossAttentionLayer(nn.Module):
         self.normalize_before = normalize_before
         _xavier(self)
 
-    def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None):
+    def forward(self, tgt, memory, memory_mask=None, memory_key_padding_mask=None, pos=None, query_pos=None,
+                memory_mask_bsl=None):
+        """`memory_mask_bsl`: the same mask as `memory_mask` in the decoder's own bool[B, S, L] layout (not repeated
+        per head); when given on a HIP device the fused attention kernels are used."""
         src = self.norm(tgt) if self.normalize_before else tgt
+        if memory_mask is None and memory_mask_bsl is not None and not src.is_cuda:
+            memory_mask = memory_mask_bsl.repeat_interleave(self.multihead_attn.num_heads, dim=0).permute(0, 2, 1)
         if memory_key_padding_mask is None and self.multihead_attn.dropout == 0.0 and src.is_cuda:
             upd = multihead_attention(self.multihead_attn, _with_pos(src, query_pos), _with_pos(memory, pos), memory,
-                                      attn_mask=memory_mask)
+                                      attn_mask=memory_mask, mask_bsl=memory_mask_bsl)
         else:
             upd = self.multihead_attn(query=_with_pos(src, query_pos), key=_with_pos(memory, pos), value=memory,
                                       attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask,

@@ -852,3 +852,43 @@ def in_proj(xq, xk, xv, W, b):
     _chk(W, torch.float32, "in_proj_weight")
     _chk(b, torch.float32, "in_proj_bias")
     return _InProj.apply(xq, xk, xv, W, b)
+
+
+class _MaskedCrossAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, mask, num_heads):
+        L, B, E = q.shape
+        S = k.shape[0]
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        m8 = mask.contiguous().view(torch.uint8)
+        o = torch.empty_like(q)
+        lse = torch.empty((B * num_heads, 128), dtype=torch.float32, device=q.device)
+        wsb = lib.usc_attn_ws_bytes(L, S, B, num_heads)
+        ws = _ws(wsb, q.device)
+        check(lib.usc_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(m8), L, S, B, num_heads, E, _ptr(o), _ptr(lse), _ptr(ws),
+                               wsb, _stream()), "usc_attn_fwd")
+        ctx.save_for_backward(q, k, v, m8, o, lse)
+        ctx.num_heads = num_heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, m8, o, lse = ctx.saved_tensors
+        L, B, E = q.shape
+        S = k.shape[0]
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        wsb = lib.usc_attn_ws_bytes(L, S, B, ctx.num_heads)
+        ws = _ws(wsb, q.device)
+        check(lib.usc_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(m8), _ptr(o), _ptr(lse), _ptr(do), L, S, B, ctx.num_heads,
+                               E, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), wsb, _stream()), "usc_attn_bwd")
+        return dq, dk, dv, None, None
+
+
+def masked_cross_attention(q, k, v, mask_bsl, num_heads):
+    """softmax(q k^T / 4 + mask) v per head for head dim 16: q [L,B,E], k/v [S,B,E] (f32, sequence-first),
+    mask_bsl bool[B,S,L] with True = masked (the decoder's `batched_attn`, shared by all heads) -> [L,B,E]."""
+    L, B, E = q.shape
+    if E != 16 * num_heads or L > 128 or mask_bsl.dtype != torch.bool or tuple(mask_bsl.shape) != (B, k.shape[0], L):
+        raise RuntimeError("masked_cross_attention: needs head dim 16, <= 128 queries and a bool[B,S,L] mask")
+    return _MaskedCrossAttention.apply(q, k, v, mask_bsl, num_heads)
