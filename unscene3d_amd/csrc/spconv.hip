@@ -1110,7 +1110,7 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
     const int CT = (ctiles % 3 == 0 && NBf * 3 <= 9) ? 3 : ((ctiles % 4 == 0 && NBf * 4 <= 9) ? 4 : ((ctiles % 2 == 0 && NBf * 2 <= 9) ? 2 : 1));
     const int64_t blocks_per_split = (int64_t)K * (ctiles / CT) * (cb / NBf);
     int64_t S = 512 / blocks_per_split;                         // one round of 2 workgroups per CU
-    const int64_t by_rows = n_rows / 4096 + 1;
+    const int64_t by_rows = n_rows / (K > 1 ? 4096 : 256) + 1;   // identity pairs (dense layers): 64 rows per wave suffice
     if (S > by_rows) S = by_rows;
     if (S > 64) S = 64;
     if (S < 1) S = 1;
