@@ -37,17 +37,33 @@ __device__ inline int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >
 // row masks, bucket sort, tile masks
 struct KeySel { int bit[kKeyBits]; int n; };
 
+// Row masks + bucket histogram.  Surface voxels put most rows into a few dozen of the 4096 buckets, so global atomics
+// per row serialise (45 us for 148 k rows); each workgroup (1024 rows) first counts in an LDS histogram and then
+// adds only its non-empty buckets to the global one.
 __global__ __launch_bounds__(256) void rowmask_hist_kernel(const int32_t* __restrict__ nbr, int K, int64_t n,
                                                           KeySel sel, uint32_t* __restrict__ mask,
                                                           uint32_t* __restrict__ bins) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  uint32_t m = 0;
-  for (int k = 0; k < K; ++k) m |= (nbr[(int64_t)k * n + r] >= 0 ? 1u : 0u) << k;
-  mask[r] = m;
-  uint32_t key = 0;
-  for (int b = 0; b < sel.n; ++b) key |= ((m >> sel.bit[b]) & 1u) << b;
-  atomicAdd(&bins[key], 1u);
+  __shared__ uint32_t lh[kBins];
+  for (int e = threadIdx.x; e < kBins; e += 256) lh[e] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t r = base + u * 256 + threadIdx.x;
+    if (r < n) {
+      uint32_t m = 0;
+      for (int k = 0; k < K; ++k) m |= (nbr[(int64_t)k * n + r] >= 0 ? 1u : 0u) << k;
+      mask[r] = m;
+      uint32_t key = 0;
+      for (int b = 0; b < sel.n; ++b) key |= ((m >> sel.bit[b]) & 1u) << b;
+      atomicAdd(&lh[key], 1u);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kBins; e += 256) {
+    const uint32_t c = lh[e];
+    if (c) atomicAdd(&bins[e], c);
+  }
 }
 
 // exclusive scan of the kBins bucket counts -> cursors (one workgroup)
@@ -70,15 +86,36 @@ __global__ __launch_bounds__(1024) void bins_scan_kernel(const uint32_t* __restr
   for (int j = 0; j < per; ++j) { cursor[threadIdx.x * per + j] = base; base += v[j]; }
 }
 
+// Placement: per workgroup (1024 rows) an LDS count per bucket gives every row its rank inside the workgroup's
+// share of the bucket; one global atomic per (workgroup, non-empty bucket) reserves the share.
 __global__ __launch_bounds__(256) void bucket_place_kernel(const uint32_t* __restrict__ mask, int64_t n, KeySel sel,
                                                           uint32_t* __restrict__ cursor, int32_t* __restrict__ perm) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n) return;
-  const uint32_t m = mask[r];
-  uint32_t key = 0;
-  for (int b = 0; b < sel.n; ++b) key |= ((m >> sel.bit[b]) & 1u) << b;
-  const uint32_t pos = atomicAdd(&cursor[key], 1u);
-  perm[pos] = (int32_t)r;
+  __shared__ uint32_t lh[kBins];
+  for (int e = threadIdx.x; e < kBins; e += 256) lh[e] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * 1024;
+  uint32_t key[4], rank[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t r = base + u * 256 + threadIdx.x;
+    key[u] = 0; rank[u] = 0;
+    if (r < n) {
+      const uint32_t m = mask[r];
+      for (int b = 0; b < sel.n; ++b) key[u] |= ((m >> sel.bit[b]) & 1u) << b;
+      rank[u] = atomicAdd(&lh[key[u]], 1u);
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kBins; e += 256) {
+    const uint32_t c = lh[e];
+    if (c) lh[e] = atomicAdd(&cursor[e], c);     // count -> start of this workgroup's share
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t r = base + u * 256 + threadIdx.x;
+    if (r < n) perm[lh[key[u]] + rank[u]] = (int32_t)r;
+  }
 }
 
 __global__ __launch_bounds__(256) void tile_mask_kernel(const uint32_t* __restrict__ mask, const int32_t* __restrict__ perm,
@@ -353,9 +390,10 @@ int usc_rowsort_build(const int32_t* nbr, int32_t K, int64_t n_out, int32_t* per
   const KeySel sel = key_selection(K);
   (void)hipMemsetAsync(bins, 0, kBins * 4, st);
   const unsigned nb = (unsigned)ceil_div(n_out, 256);
-  hipLaunchKernelGGL(rowmask_hist_kernel, dim3(nb), dim3(256), 0, st, nbr, (int)K, n_out, sel, mask, bins);
+  const unsigned nb4 = (unsigned)ceil_div(n_out, 1024);
+  hipLaunchKernelGGL(rowmask_hist_kernel, dim3(nb4), dim3(256), 0, st, nbr, (int)K, n_out, sel, mask, bins);
   hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)bins, cursor);
-  hipLaunchKernelGGL(bucket_place_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t*)mask, n_out, sel, cursor, perm);
+  hipLaunchKernelGGL(bucket_place_kernel, dim3(nb4), dim3(256), 0, st, (const uint32_t*)mask, n_out, sel, cursor, perm);
   hipLaunchKernelGGL(tile_mask_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t*)mask, (const int32_t*)perm, n_out,
                      tile_mask);
   USC_CHECK_LAUNCH("usc_rowsort_build");
