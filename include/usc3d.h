@@ -153,7 +153,7 @@ int usc_weight_transpose(const float* W, int32_t K, int32_t cin, int32_t cout,
 /* Launch plan chosen for a shape (for profiling labels): returns
  * NB | aligned<<8 | G<<16 where NB = 32-column blocks per wave, aligned = fast
  * path, G = offset groups.  kind 0: gather_gemm (n = n_out), 1: pairs_gemm
- * (n = P_capacity), 2: wgrad. */
+ * (n = P_capacity), 2: wgrad (bit 13 set: the all-input-tiles kernel, CT = code>>16). */
 int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout,
                     int32_t K);
 /* Mask-sorted form of the same convolution (all map sizes, cin and cout multiples

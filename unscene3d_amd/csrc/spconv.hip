@@ -1007,7 +1007,17 @@ int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout, int32_t 
   GemmPlan pl;
   if (kind == 0) pl = plan_table(n, cin, cout, K);
   else if (kind == 1) pl = plan_list(ceil_div(n, 32) + K, cin, cout);
-  else { const int NB = pick_nb(cout); pl = GemmPlan{NB, 1, (cin % 32 == 0) && (cout % (NB * 32) == 0), 0}; }
+  else {
+    // wgrad: mirror usc_spconv_wgrad's choice (full kernel: NB | 1<<8 | 1<<13 | CT<<16)
+    const int ctiles = cin / 32, cb = cout / 32;
+    const int NBf = (cb % 3 == 0) ? 3 : (cb % 4 == 0 ? 4 : (cb % 2 == 0 ? 2 : 1));
+    if (cin % 32 == 0 && cout % 32 == 0 && !(NBf == 3 && ctiles % 3 != 0)) {
+      const int CT = (ctiles % 3 == 0 && NBf * 3 <= 9) ? 3 : ((ctiles % 4 == 0 && NBf * 4 <= 9) ? 4 : ((ctiles % 2 == 0 && NBf * 2 <= 9) ? 2 : 1));
+      return NBf | (1 << 8) | (1 << 13) | (CT << 16);
+    }
+    const int NB = pick_nb(cout);
+    pl = GemmPlan{NB, 1, (cin % 32 == 0) && (cout % (NB * 32) == 0), 0};
+  }
   return pl.NB | ((pl.aligned ? 1 : 0) << 8) | ((pl.TM > 0 ? 1 : 0) << 12) | (pl.G << 16);
 }
 

@@ -187,6 +187,8 @@ def _kernel_symbol(kind, n, cin, cout, K):
     if kind == 0 and compact:
         return f"usc::gather_gemm_compact_kernel<{nb}>" + tag
     if kind == 2:
+        if (code >> 13) & 1:
+            return f"usc::wgrad_full_kernel<{code >> 16}, {nb}>" + tag
         return f"usc::wgrad_kernel<{nb}, {'true' if aligned else 'false'}>" + tag
     base = "usc::gather_gemm_aligned_kernel" if aligned else "usc::gather_gemm_kernel"
     return f"{base}<{nb}, {'true' if kind == 1 else 'false'}>" + tag
@@ -310,8 +312,10 @@ def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None, into=None):
     dW = torch.empty((K, cin, cout), dtype=torch.float32, device=a.device) if into is None else into
     ws = _ws(lib.usc_spconv_wgrad_ws_bytes(K, cin, cout), a.device)
     n_rows = a.shape[0] if a_idx is None else int(a_idx.shape[0])
+    # (profiling only) real pair count = koff[K]; n_rows is the capacity of the pair lists
     with _prof.maybe(lambda: _kernel_symbol(2, n_rows, cin, cout, K),
-                     lambda: _conv_cost(n_rows, a.shape[0], b.shape[0], K, cin, cout)):
+                     lambda: _conv_cost(n_rows if koff is None else int(koff[-1].item()), a.shape[0], b.shape[0], K,
+                                        cin, cout)):
         check(lib.usc_spconv_wgrad(_ptr(a), cin, _ptr(b), cout, K, _ptr(a_idx), _ptr(b_idx), _ptr(koff), n_rows,
                                    _ptr(dW), int(into is not None), _ptr(ws), ws.numel(), _stream()), "usc_spconv_wgrad")
     return dW
