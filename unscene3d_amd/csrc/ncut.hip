@@ -209,16 +209,64 @@ __global__ __launch_bounds__(1024) void tri_reflector_kernel(TriState t, int64_t
   }
 }
 
-// p[r] = sum_c C[r][c] v[c] over the trailing block (r, c > i); one wave per row
-__global__ __launch_bounds__(256) void tri_symv_kernel(TriState t, int64_t i) {
+// Steps (1) + (2) in one launch: every workgroup recomputes the reflector of column i — bit for bit the reduction of
+// tri_reflector_kernel's single 1024-thread workgroup (each of the 256 threads plays four of its threads, the sixteen
+// wave sums are added in the same order) — keeps v in LDS and then forms its rows of p = C22 v, one wave per row.
+// Workgroup 0 also stores d, e, tau and v (for the update kernel and the back-transform).  Two launches per
+// Householder step instead of three: the solver is bound by the ~5 us kernel-to-kernel latency of its dependent
+// chain (1 875 launches for 625 segments), not by work.
+__global__ __launch_bounds__(256) void tri_reflect_symv_kernel(TriState t, int64_t i) {
+  extern __shared__ double vsh[];   // [n]
+  __shared__ double red[16];
+  __shared__ double s_scale;
   const int64_t n = t.n;
-  const int lane = threadIdx.x & 63;
-  const int64_t r = i + 1 + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const double* col = t.C;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    double ss = 0.0;
+    for (int64_t r = i + 2 + tid + 256 * v; r < n; r += 1024) { const double x = col[r * n + i]; ss += x * x; }
+    ss = wave_reduce_addd(ss);
+    if (lane == 0) red[(tid >> 6) + 4 * v] = ss;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    const double alpha = col[(i + 1) * n + i];
+    const double xnorm = sqrt(tot);
+    double beta, tau, scale;
+    if (xnorm == 0.0) {
+      beta = alpha; tau = 0.0; scale = 0.0;
+    } else {
+      const double nrm = hypot(alpha, xnorm);
+      beta = alpha >= 0.0 ? -nrm : nrm;     // -sign(alpha) * ||(alpha, x)||
+      tau = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    s_scale = scale;
+    if (blockIdx.x == 0) {
+      t.d[i] = col[i * n + i];
+      t.e[i] = beta;
+      t.tau[i] = tau;
+      if (i == n - 2) t.d[n - 1] = 0.0;  // set by the final step
+    }
+  }
+  __syncthreads();
+  const double scale = s_scale;
+  for (int64_t r = tid; r < n; r += 256) {
+    double val = 0.0;
+    if (r == i + 1) val = 1.0;
+    else if (r > i + 1) val = col[r * n + i] * scale;
+    vsh[r] = val;
+    if (blockIdx.x == 0) t.Vt[i * n + r] = val;
+  }
+  __syncthreads();
+  const int64_t r = i + 1 + (int64_t)blockIdx.x * 4 + (tid >> 6);
   if (r >= n) return;
-  const double* v = t.Vt + i * n;
   const double* row = t.C + r * n;
   double s = 0.0;
-  for (int64_t c = i + 1 + lane; c < n; c += 64) s += row[c] * v[c];
+  for (int64_t c = i + 1 + lane; c < n; c += 64) s += row[c] * vsh[c];
   s = wave_reduce_addd(s);
   if (lane == 0) t.p[r] = s;
 }
@@ -264,11 +312,28 @@ __device__ inline int sturm_count(const double* d, const double* e, int64_t n, d
   return cnt;
 }
 
-__global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ d, const double* __restrict__ e, int64_t n,
+// LDS = 1: the tridiagonal (d, e), the LU work arrays and the iterate live in LDS (n <= kEigLdsMax) — the bisection and
+// above all the single-lane inverse iteration are chains of dependent loads, ~10 k of them per call: 4.3 ms of a
+// 12 ms solve from global memory.
+constexpr int64_t kEigLdsMax = 1000;
+template <int LDS>
+__global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ d_g, const double* __restrict__ e_g, int64_t n,
                                                     int k, double* __restrict__ eval_out /*[2]*/,
-                                                    double* __restrict__ z /*[n]*/, double* __restrict__ work /*[5n]*/) {
+                                                    double* __restrict__ z_g /*[n]*/, double* __restrict__ work_g /*[5n]*/) {
+  extern __shared__ double eig_sh[];   // LDS: d[n] e[n] z[n] work[5n]
   const int lane = threadIdx.x;
   __shared__ double s_lam[2];
+  const double* d = d_g;
+  const double* e = e_g;
+  double* z = z_g;
+  double* work = work_g;
+  if (LDS) {
+    double* dl_ = eig_sh;
+    double* el_ = eig_sh + n;
+    for (int64_t j = lane; j < n; j += 64) { dl_[j] = d_g[j]; el_[j] = j < n - 1 ? e_g[j] : 0.0; }
+    __syncthreads();
+    d = dl_; e = el_; z = eig_sh + 2 * n; work = eig_sh + 3 * n;
+  }
   // Gershgorin interval
   double lo = 1e300, hi = -1e300;
   for (int64_t j = lane; j < n; j += 64) {
@@ -350,6 +415,7 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
   int64_t jmax = 0;
   for (int64_t j = 1; j < n; ++j) if (fabs(z[j]) > fabs(z[jmax])) jmax = j;
   if (z[jmax] < 0.0) for (int64_t j = 0; j < n; ++j) z[j] = -z[j];
+  if (LDS) for (int64_t j = 0; j < n; ++j) z_g[j] = z[j];
 }
 
 // y = H(0) H(1) ... H(n-2) z, then x = y / sqrt(deg)
@@ -424,7 +490,7 @@ int64_t usc_ncut_fiedler_ws_bytes(int64_t S) { return (2 * S * S + 12 * S + 16) 
 
 int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double eps, double* evec, double* eval,
                      void* ws, int64_t ws_bytes, usc_stream_t s) {
-  USC_REQUIRE(S >= 3 && Abin && deg && evec && eval && ws, "usc_ncut_fiedler: bad argument");
+  USC_REQUIRE(S >= 3 && S <= 8000 && Abin && deg && evec && eval && ws, "usc_ncut_fiedler: bad argument (3 <= S <= 8000)");
   USC_REQUIRE(ws_bytes >= usc_ncut_fiedler_ws_bytes(S), "usc_ncut_fiedler: workspace too small");
   hipStream_t st = as_stream(s);
   double* w = (double*)ws;
@@ -440,13 +506,16 @@ int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double e
   double* work = z + S;   // 5 S
   hipLaunchKernelGGL(ncut_laplacian_kernel, dim3(stream_grid(S * S, 256)), dim3(256), 0, st, Abin, deg, S, eps, t.C);
   for (int64_t i = 0; i + 1 < S; ++i) {
-    hipLaunchKernelGGL(tri_reflector_kernel, dim3(1), dim3(1024), 0, st, t, i);
     const int64_t m = S - i - 1;
-    hipLaunchKernelGGL(tri_symv_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(256), 0, st, t, i);
+    hipLaunchKernelGGL(tri_reflect_symv_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(256), (size_t)S * sizeof(double), st, t, i);
     hipLaunchKernelGGL(tri_update_kernel, dim3(stream_grid(m * m, 256)), dim3(256), 0, st, t, i);
   }
   hipLaunchKernelGGL(tri_last_diag_kernel, dim3(1), dim3(64), 0, st, t);
-  hipLaunchKernelGGL(tri_eig_kernel, dim3(1), dim3(64), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
+  if (S <= kEigLdsMax)
+    hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(64), (size_t)S * 8 * sizeof(double), st, (const double*)t.d,
+                       (const double*)t.e, S, 1, eval, z, work);
+  else
+    hipLaunchKernelGGL(tri_eig_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
   hipLaunchKernelGGL(tri_backtransform_kernel, dim3(1), dim3(1024), 0, st, t, deg, z, evec);
   USC_CHECK_LAUNCH("usc_ncut_fiedler");
   return USC_OK;
