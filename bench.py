@@ -320,11 +320,13 @@ def main():
 
     # roofline of the dominant kernel: one extra instrumented step (HIP events around every conv launch on
     # the launch stream; not part of the timed region so that event overhead does not pollute `value`)
+    # Every rank runs it (the criterion's num_masks all-reduce and the gradient all-reduce are collectives); rank 0
+    # reports.
     roof = None
+    with profiler.capture() as prof:
+        step(world)
+        torch.cuda.synchronize()
     if rank == 0:
-        with profiler.capture() as prof:
-            step(1)
-            torch.cuda.synchronize()
         roof = prof.roofline(MFMA_F32_PEAK_TFLOPS)
         if roof is not None:
             # PMC counters cannot be read from inside the process; `traffic` is the per-launch HBM byte count
