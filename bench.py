@@ -40,6 +40,9 @@ def parse():
                          "ncut: configs[4] masked-NCut pseudo-mask loop on a 625-segment scene (secondary metric)")
     ap.add_argument("--no-graphs", action="store_true", help="do not capture the decoder passes as HIP graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, the measured configuration); gloo only to smoke-test the N>1 code path on a box "
+                         "with fewer GPUs than ranks (ranks then share devices)")
     ap.add_argument("--cpu-sample-voxels", type=int, default=15_000)
     return ap.parse_args()
 
@@ -279,7 +282,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    if args.dist_backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -1,0 +1,27 @@
+"""The N>1 code path of bench.py end to end on whatever GPUs the box has: two ranks (sharing device 0 when there is
+only one), gloo collectives — the criterion's num_masks all-reduce, the flat gradient all-reduce, graph capture with a
+process group alive, the instrumented roofline step on every rank.  (RCCL itself needs one GPU per rank; the driver's
+scaling bench covers that.)"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_gloo():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--voxels", "40000", "--dist-backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                 # rank 0 prints exactly one JSON line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["roofline"] is not None and rec["cpu_baseline"] is None
