@@ -741,6 +741,38 @@ def test_fused_masked_cross_attention(device, L, S, B):
     assert rel_err(qd.grad, qr.grad) < 1e-5 and rel_err(kd.grad, kr.grad) < 1e-5 and rel_err(vd.grad, vr.grad) < 1e-5
 
 
+def test_edge_sizes_of_the_decoder_and_sorted_kernels(device):
+    """Empty and tiny inputs: zero output rows, a map smaller than one tile, fewer keys than one chunk, a single
+    query, LayerNorm / linear on one row."""
+    from unscene3d_amd import ops
+
+    # sorted conv on an empty map and on 5 rows
+    W = torch.randn(27, 32, 32, device=device)
+    nbr0 = torch.empty((27, 0), dtype=torch.int32, device=device)
+    assert ops.gather_gemm(torch.empty(0, 32, device=device), W, nbr0, 0).shape == (0, 32)
+    c, cmap = _maps(device, seed=2, n=5, extent=1)
+    nbr = ops.kernel_map_cube(cmap, 3)
+    x = torch.randn(len(c), 32, device=device)
+    y = ops.gather_gemm(x, W, nbr, len(c))
+    yr = R.conv_gather(x.cpu(), W.cpu(), R.kernel_map_cube(c, 1), len(c))
+    assert rel_err(y, yr) < 1e-5
+    # attention: 1 query, 3 keys, one of them masked
+    q, k, v = torch.randn(1, 1, 128, device=device), torch.randn(3, 1, 128, device=device), torch.randn(3, 1, 128, device=device)
+    mask = torch.tensor([[[False], [True], [False]]], device=device)
+    o = ops.masked_cross_attention(q, k, v, mask, 8)
+    qh, kh, vh = q.reshape(1, 8, 16).transpose(0, 1), k.reshape(3, 8, 16).transpose(0, 1), v.reshape(3, 8, 16).transpose(0, 1)
+    sc = (qh @ kh.transpose(1, 2)) / 4.0
+    sc[:, :, 1] = float("-inf")
+    ref = (torch.softmax(sc, -1) @ vh).transpose(0, 1).reshape(1, 1, 128)
+    assert rel_err(o, ref) < 1e-5
+    # one-row LayerNorm / linear
+    w, b = torch.randn(128, device=device), torch.randn(128, device=device)
+    x1 = torch.randn(1, 128, device=device)
+    assert rel_err(ops.layer_norm(x1, w, b), torch.nn.functional.layer_norm(x1, (128,), w, b)) < 1e-5
+    Wl = torch.randn(64, 128, device=device)
+    assert rel_err(ops.linear(x1, Wl, None), x1 @ Wl.t()) < 1e-5
+
+
 def test_knn1_matches_kdtree(device):
     from scipy.spatial import KDTree
     from unscene3d_amd import ops

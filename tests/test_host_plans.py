@@ -25,6 +25,13 @@ def test_conv_plan_dispatch_rules():
     assert _plan(0, 148564, 96, 128, 1)["hi"] == 1
 
 
+def test_empty_maps_plan_without_faulting():
+    for kind in (0, 1, 2):
+        lib.usc_spconv_plan(kind, 0, 32, 32, 27)
+    assert lib.usc_spconv_gather_gemm_ws_bytes(0, 32, 32, 27) == 0
+    assert lib.usc_spconv_sorted_ws_bytes(0, 32, 32, 27) == 0
+
+
 def test_wgrad_plan_matches_design():
     p = _plan(2, 4011228, 96, 96, 27)
     assert p["full"] == 1 and p["NB"] == 3 and p["hi"] == 3            # 3 x 3 accumulator tiles per wave

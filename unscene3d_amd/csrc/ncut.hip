@@ -168,47 +168,6 @@ struct TriState {
   int64_t n;
 };
 
-__global__ __launch_bounds__(1024) void tri_reflector_kernel(TriState t, int64_t i) {
-  __shared__ double red[16];
-  __shared__ double s_beta, s_tau, s_scale;
-  const int64_t n = t.n;
-  const int tid = threadIdx.x;
-  double* col = t.C;  // column i entries C[r][i], r > i
-  double ss = 0.0;
-  for (int64_t r = i + 2 + tid; r < n; r += 1024) { const double x = col[r * n + i]; ss += x * x; }
-  ss = wave_reduce_addd(ss);
-  if ((tid & 63) == 0) red[tid >> 6] = ss;
-  __syncthreads();
-  if (tid == 0) {
-    double tot = 0.0;
-    for (int k = 0; k < 16; ++k) tot += red[k];
-    const double alpha = col[(i + 1) * n + i];
-    const double xnorm = sqrt(tot);
-    if (xnorm == 0.0) {
-      s_beta = alpha; s_tau = 0.0; s_scale = 0.0;
-    } else {
-      const double nrm = hypot(alpha, xnorm);
-      const double beta = alpha >= 0.0 ? -nrm : nrm;     // -sign(alpha) * ||(alpha, x)||
-      s_beta = beta;
-      s_tau = (beta - alpha) / beta;
-      s_scale = 1.0 / (alpha - beta);
-    }
-    t.d[i] = col[i * n + i];
-    t.e[i] = s_beta;
-    t.tau[i] = s_tau;
-    if (i == n - 2) t.d[n - 1] = 0.0;  // set by the final step below
-  }
-  __syncthreads();
-  const double scale = s_scale;
-  double* v = t.Vt + i * n;
-  for (int64_t r = tid; r < n; r += 1024) {
-    double val = 0.0;
-    if (r == i + 1) val = 1.0;
-    else if (r > i + 1) val = col[r * n + i] * scale;
-    v[r] = val;
-  }
-}
-
 // Steps (1) + (2) in one launch: every workgroup recomputes the reflector of column i — bit for bit the reduction of
 // tri_reflector_kernel's single 1024-thread workgroup (each of the 256 threads plays four of its threads, the sixteen
 // wave sums are added in the same order) — keeps v in LDS and then forms its rows of p = C22 v, one wave per row.

@@ -946,7 +946,7 @@ static GemmPlan plan_table(int64_t n_out, int cin, int cout, int K) {
   }
   pl.NB = chosen;
   const int64_t waves = row_tiles * (cb / chosen);
-  if (waves < kTargetWaves && K > 1) {
+  if (waves > 0 && waves < kTargetWaves && K > 1) {   // (an empty map plans to nothing)
     int64_t G = ceil_div(kTargetWaves, waves);
     if (G > K) G = K;
     pl.G = (int)G;

@@ -342,7 +342,7 @@ SortedPlan plan_sorted(int64_t n_out, int cin, int cout, int K) {
   const int64_t ntiles = ceil_div(n_out, 32);
   const int64_t waves = ntiles * (cb / nb);
   constexpr int64_t kTarget = 2048;   // two waves per SIMD
-  if (waves < kTarget) {
+  if (waves > 0 && waves < kTarget) {   // (an empty map plans to nothing)
     int64_t G = ceil_div(kTarget, waves);
     if (G > K) G = K;
     pl.G = (int)G;
