@@ -148,7 +148,9 @@ int usc_weight_transpose(const float* W, int32_t K, int32_t cin, int32_t cout,
  * Small maps (coarse U-Net levels) split the K offsets over extra workgroups and
  * reduce the partial sums in a fixed order through `ws`
  * (usc_spconv_gather_gemm_ws_bytes; 0 bytes when no split is planned).
- * Covers: k3/s1 conv fwd and dgrad (W = usc_weight_transpose(mirror=1)),
+ * w_transposed=1 (tile-compacted plan only, usc_spconv_plan bit 12): W is the forward
+ * conv's f32[K,cout,cin] and W'[k][c][n] = W[K-1-k][n][c] is used (stride-1 dgrad).
+ * Covers: k3/s1 conv fwd and dgrad (W = usc_weight_transpose(mirror=1), or w_transposed),
  * k2/s2 conv fwd (nbr = child table), conv-transpose dgrad. */
 /* Launch plan chosen for a shape (for profiling labels): returns
  * NB | aligned<<8 | G<<16 where NB = 32-column blocks per wave, aligned = fast
@@ -165,7 +167,9 @@ int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout,
  * usc_spconv_sorted_gemm computes usc_spconv_gather_gemm's result; its output
  * bits do not depend on perm (each output element is reduced by one lane over
  * k ascending, channel ascending); weights are staged through LDS per workgroup.
- * One perm serves the forward conv and, for a stride-1 map, its input gradient.
+ * One perm serves the forward conv and, for a stride-1 map, its input gradient:
+ * w_transposed=1 takes the FORWARD weights f32[K, cout, cin] and uses
+ * W'[k][c][n] = W[K-1-k][n][c] while staging them (no usc_weight_transpose pass).
  * Replaces the same MinkowskiEngine calls as usc_spconv_gather_gemm
  * (models/res16unet.py:224-297; ME 0.5.4 src/convolution_kernel.cu, un-vendored). */
 int64_t usc_rowsort_ws_bytes(int32_t K, int64_t n_out);
@@ -179,14 +183,15 @@ int usc_spconv_sorted_gemm(const float* in, int64_t n_in, int32_t cin,
                            const int32_t* nbr, const int32_t* perm,
                            const uint32_t* tile_mask, int64_t n_out,
                            const float* bias, float* out, int32_t accumulate,
-                           void* ws, int64_t ws_bytes, usc_stream_t s);
+                           int32_t w_transposed, void* ws, int64_t ws_bytes,
+                           usc_stream_t s);
 
 int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin,
                                         int32_t cout, int32_t K);
 int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin,
                            const float* W, int32_t K, int32_t cout,
                            const int32_t* nbr, int64_t n_out,
-                           const float* bias, float* out, int32_t accumulate,
+                           const float* bias, float* out, int32_t accumulate, int32_t w_transposed,
                            void* ws, int64_t ws_bytes, usc_stream_t s);
 
 /* One-parent form (transposed-conv forward, strided-conv dgrad):

@@ -37,11 +37,11 @@ SIGNATURES = {
     "usc_weight_transpose": (C.c_int, [_p, _i32, _i32, _i32, _i32, _p, _p]),
     "usc_spconv_plan": (C.c_int, [_i32, _i64, _i32, _i32, _i32]),
     "usc_spconv_gather_gemm_ws_bytes": (_i64, [_i64, _i32, _i32, _i32]),
-    "usc_spconv_gather_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p, _p, _i32, _p, _i64, _p]),
+    "usc_spconv_gather_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "usc_rowsort_ws_bytes": (_i64, [_i32, _i64]),
     "usc_rowsort_build": (C.c_int, [_p, _i32, _i64, _p, _p, _p, _i64, _p]),
     "usc_spconv_sorted_ws_bytes": (_i64, [_i64, _i32, _i32, _i32]),
-    "usc_spconv_sorted_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _p, _i64, _p]),
+    "usc_spconv_sorted_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "usc_spconv_pairs_gemm": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p]),
     "usc_spconv_wgrad_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p, _i64, _p]),

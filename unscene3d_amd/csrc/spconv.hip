@@ -875,7 +875,9 @@ __global__ void weight_transpose_kernel(const float* __restrict__ W, int K, int 
 // wave's 64 loads are 1 KiB contiguous.  (The natural [cin][cout] layout made every k-step a 12-byte-per-lane,
 // stride-12 load that the texture path splits into strided dword passes: measured 85 cycles per wave
 // instruction and 0.55 ms of a 0.60 ms kernel bound by it, independent of prefetch depth.)
-__global__ void weight_pack_kernel(const float* __restrict__ W, int K, int cin, int cout, int NB,
+// wt = 1: W is the forward conv's [K, cout, cin] and the packed slices are those of W'[k][c][n] = W[K-1-k][n][c]
+// (input gradient of a stride-1 conv) — the transpose pass is folded into the packing.
+__global__ void weight_pack_kernel(const float* __restrict__ W, int K, int cin, int cout, int NB, int wt,
                                    float* __restrict__ out) {
   const int64_t total = (int64_t)K * cin * cout;
   const int nq = cin >> 3, BN = NB * 32;
@@ -888,7 +890,8 @@ __global__ void weight_pack_kernel(const float* __restrict__ W, int K, int cin, 
     const int k = (int)(r % K);
     const int cb = (int)(r / K);
     const int i = ln & 31, h = ln >> 5;
-    out[e] = W[((int64_t)k * cin + 8 * q + 4 * h + j) * cout + cb * BN + NB * i + nb];
+    const int c = 8 * q + 4 * h + j, n = cb * BN + NB * i + nb;
+    out[e] = wt ? W[((int64_t)(K - 1 - k) * cout + n) * cin + c] : W[((int64_t)k * cin + c) * cout + n];
   }
 }
 
@@ -1029,7 +1032,7 @@ int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin, int32_t cout
 
 int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
                            const int32_t* nbr, int64_t n_out, const float* bias, float* out, int32_t accumulate,
-                           void* ws, int64_t ws_bytes, usc_stream_t s) {
+                           int32_t w_transposed, void* ws, int64_t ws_bytes, usc_stream_t s) {
   USC_REQUIRE(cin >= 1 && cout >= 1 && K >= 1 && n_out >= 0 && n_in >= 0, "usc_spconv_gather_gemm: bad sizes");
   USC_REQUIRE(nbr || K == 1, "usc_spconv_gather_gemm: K>1 needs a neighbour table");
   USC_REQUIRE(nbr || n_in == n_out, "usc_spconv_gather_gemm: identity map needs n_in == n_out");
@@ -1044,11 +1047,14 @@ int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const flo
     p.out = (float*)ws;
   }
   hipStream_t st = as_stream(s);
+  USC_REQUIRE(!w_transposed || pl.TM > 0,
+              "usc_spconv_gather_gemm: w_transposed is only folded into the tile-compacted kernel (usc_spconv_plan bit 12); "
+              "use usc_weight_transpose for other shapes");
   if (pl.TM > 0) {
     p.TM = pl.TM;
     USC_REQUIRE(ws && ws_bytes >= (int64_t)K * cin * cout * 4, "usc_spconv_gather_gemm: workspace too small");
     hipLaunchKernelGGL(weight_pack_kernel, dim3(stream_grid((int64_t)K * cin * cout, 256)), dim3(256), 0, st, W, (int)K,
-                       (int)cin, (int)cout, pl.NB, (float*)ws);
+                       (int)cin, (int)cout, pl.NB, (int)w_transposed, (float*)ws);
     p.W = (const float*)ws;
     dim3 cgrid((unsigned)ceil_div(n_out, pl.TM), (unsigned)(cout / (pl.NB * 32)));
     const size_t lds = compact_lds_bytes(pl.NB, pl.TM);

@@ -138,6 +138,7 @@ struct SortedParams {
   float* out;             // [n_out, cout]  or partial [G, n_out, cout]
   int64_t n_out;
   int cin, cout, K, G, accumulate;
+  int wt;                 // 1: W is the FORWARD conv's [K, cout, cin]; use W'[k][c][n] = W[K-1-k][n][c] (input gradient)
 };
 
 // One wave = one sorted tile of 32 rows x (32*NB) columns, accumulators in registers over the whole reduction.
@@ -211,20 +212,38 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void gather_gemm_so
   // immediate — no per-thread address tables (an operand-order LDS layout needed 16 live address registers
   // for its scattered staging writes and pushed the kernel into scratch).
   float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0, w2 = w0, w3 = w0;
+  // wt = 1 (input gradient of a stride-1 conv): the chunk is read from the forward weights, transposed and with the
+  // offsets mirrored — element (r, n) = W[K-1-k][n0+n][c0+r]; a thread's float4 then runs along r (contiguous in
+  // memory) and lands in four LDS rows.  No separate weight-transpose launch per conv.
 #define USC_STAGE_LD(U, REG)                                                                   \
   if (U < kLd) {   /* unconditional (index wrapped): a predicated load would force vmcnt(0) at the store */ \
     const int e0 = threadIdx.x + U * NT;                                                       \
     const int e = (kF4 % NT == 0 || e0 < kF4) ? e0 : e0 - kF4;                                 \
-    const int r = e / (BN / 4), c4 = e - r * (BN / 4);                                         \
-    REG = *reinterpret_cast<const float4*>(src + (int64_t)r * cout + c4 * 4);                  \
+    if (wt) {                                                                                  \
+      const int nn = e >> 3, r4 = e & 7;                                                       \
+      REG = *reinterpret_cast<const float4*>(src + (int64_t)nn * cin + r4 * 4);                \
+    } else {                                                                                   \
+      const int r = e / (BN / 4), c4 = e - r * (BN / 4);                                       \
+      REG = *reinterpret_cast<const float4*>(src + (int64_t)r * cout + c4 * 4);                \
+    }                                                                                          \
   }
 #define USC_STAGE_ST(U, REG)                                                                   \
   if (U < kLd) {                                                                               \
     const int e = threadIdx.x + U * NT;                                                        \
-    if (kF4 % NT == 0 || e < kF4) reinterpret_cast<float4*>(wbuf[buf])[e] = REG;               \
+    if (kF4 % NT == 0 || e < kF4) {                                                            \
+      if (wt) {                                                                                \
+        const int nn = e >> 3, r4 = e & 7;                                                     \
+        float* dstw = wbuf[buf] + (4 * r4) * BN + nn;                                          \
+        dstw[0] = REG.x; dstw[BN] = REG.y; dstw[2 * BN] = REG.z; dstw[3 * BN] = REG.w;         \
+      } else {                                                                                 \
+        reinterpret_cast<float4*>(wbuf[buf])[e] = REG;                                         \
+      }                                                                                        \
+    }                                                                                          \
   }
+  const bool wt = p.wt != 0;
   auto stage_load = [&](int k, int ch) __attribute__((always_inline)) {
-    const float* src = p.W + ((int64_t)k * cin + ch * 32) * cout + n0;
+    const float* src = wt ? p.W + ((int64_t)(K - 1 - k) * cout + n0) * cin + ch * 32
+                          : p.W + ((int64_t)k * cin + ch * 32) * cout + n0;
     USC_STAGE_LD(0, w0) USC_STAGE_LD(1, w1) USC_STAGE_LD(2, w2) USC_STAGE_LD(3, w3)
   };
   auto stage_store = [&](int buf) __attribute__((always_inline)) {
@@ -408,8 +427,8 @@ int64_t usc_spconv_sorted_ws_bytes(int64_t n_out, int32_t cin, int32_t cout, int
 
 int usc_spconv_sorted_gemm(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
                            const int32_t* nbr, const int32_t* perm, const uint32_t* tile_mask, int64_t n_out,
-                           const float* bias, float* out, int32_t accumulate, void* ws, int64_t ws_bytes,
-                           usc_stream_t s) {
+                           const float* bias, float* out, int32_t accumulate, int32_t w_transposed, void* ws,
+                           int64_t ws_bytes, usc_stream_t s) {
   USC_REQUIRE(n_in >= 0 && n_out >= 0 && K >= 1 && K <= 32, "usc_spconv_sorted_gemm: bad sizes");
   USC_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 32 && cout % 32 == 0 && cin <= kZeroFloats,
               "usc_spconv_sorted_gemm: channels must be multiples of 32 (cin <= 4096)");
@@ -418,7 +437,7 @@ int usc_spconv_sorted_gemm(const float* in, int64_t n_in, int32_t cin, const flo
   const SortedPlan pl = plan_sorted(n_out, cin, cout, K);
   SortedParams p{};
   p.in = in; p.W = W; p.nbr = nbr; p.perm = perm; p.tmask = tile_mask; p.bias = bias; p.out = out;
-  p.n_out = n_out; p.cin = cin; p.cout = cout; p.K = K; p.G = pl.G; p.accumulate = accumulate;
+  p.n_out = n_out; p.cin = cin; p.cout = cout; p.K = K; p.G = pl.G; p.accumulate = accumulate; p.wt = w_transposed;
   if (pl.G > 1) {
     USC_REQUIRE(ws && ws_bytes >= (int64_t)pl.G * n_out * cout * 4, "usc_spconv_sorted_gemm: workspace too small");
     p.out = (float*)ws;

@@ -239,11 +239,20 @@ def _sorted_applies(nbr, K, cin, cout):
     return not compact
 
 
-def gather_gemm(feats, W, nbr, n_out, bias=None, out=None, accumulate=False):
-    """out[o] = sum_k feats[nbr[k,o]] @ W[k] (+bias).  W f32[K,cin,cout]; nbr None -> identity."""
+def gather_gemm(feats, W, nbr, n_out, bias=None, out=None, accumulate=False, w_transposed=False):
+    """out[o] = sum_k feats[nbr[k,o]] @ W[k] (+bias).  W f32[K,cin,cout]; nbr None -> identity.
+    w_transposed: W is the FORWARD conv's [K, cout, cin] and W'[k][c][n] = W[K-1-k][n][c] is meant (input gradient
+    of a stride-1 conv); the sorted and tile-compacted kernels fold that into their weight staging / packing, the
+    row-order kernels get an explicit usc_weight_transpose pass."""
     _chk(feats, torch.float32, "feats")
     _chk(W, torch.float32, "W")
-    K, cin, cout = W.shape
+    if w_transposed:
+        K, cout, cin = W.shape
+        if not (_sorted_applies(nbr, K, cin, cout) or
+                (nbr is not None and (lib.usc_spconv_plan(0, int(n_out), cin, cout, K) >> 12) & 1)):
+            W = weight_transpose(W, mirror=K > 1)
+            w_transposed = False
+    K, cin, cout = (W.shape[0], W.shape[2], W.shape[1]) if w_transposed else W.shape
     if feats.shape[1] != cin:
         raise RuntimeError(f"gather_gemm: feats have {feats.shape[1]} channels, kernel expects {cin}")
     if nbr is not None:
@@ -261,8 +270,8 @@ def gather_gemm(feats, W, nbr, n_out, bias=None, out=None, accumulate=False):
         with _prof.maybe(lambda: f"usc::gather_gemm_sorted_kernel" + (f" [n={n_out} cin={cin} cout={cout} K={K}]" if _prof.SHAPES else ""),
                          lambda: _conv_cost(_prof.table_pairs(nbr), feats.shape[0], n_out, K, cin, cout)):
             check(lib.usc_spconv_sorted_gemm(_ptr(feats), feats.shape[0], cin, _ptr(W), K, cout, _ptr(nbr), _ptr(perm),
-                                             _ptr(tmask), n_out, _ptr(bias), _ptr(out), int(accumulate), _ptr(ws), wsb,
-                                             _stream()), "usc_spconv_sorted_gemm")
+                                             _ptr(tmask), n_out, _ptr(bias), _ptr(out), int(accumulate),
+                                             int(w_transposed), _ptr(ws), wsb, _stream()), "usc_spconv_sorted_gemm")
         return out
     wsb = lib.usc_spconv_gather_gemm_ws_bytes(n_out, cin, cout, K)
     ws = _ws(wsb, feats.device) if wsb > 0 else None
@@ -270,8 +279,8 @@ def gather_gemm(feats, W, nbr, n_out, bias=None, out=None, accumulate=False):
                      lambda: _conv_cost(_prof.table_pairs(nbr) if nbr is not None else n_out, feats.shape[0], n_out,
                                         K, cin, cout)):
         check(lib.usc_spconv_gather_gemm(_ptr(feats), feats.shape[0], cin, _ptr(W), K, cout, _ptr(nbr), n_out,
-                                         _ptr(bias), _ptr(out), int(accumulate), _ptr(ws), wsb, _stream()),
-              "usc_spconv_gather_gemm")
+                                         _ptr(bias), _ptr(out), int(accumulate), int(w_transposed), _ptr(ws), wsb,
+                                         _stream()), "usc_spconv_gather_gemm")
     return out
 
 
@@ -342,8 +351,10 @@ class _ConvSame(torch.autograd.Function):
         K = W3.shape[0]
         dfeats = dW = dbias = None
         if ctx.needs_input_grad[0]:
-            Wt = weight_transpose(W3.contiguous(), mirror=K > 1)
-            dfeats = gather_gemm(dout, Wt, ctx.nbr, feats.shape[0])
+            if K > 1:
+                dfeats = gather_gemm(dout, W3.contiguous(), ctx.nbr, feats.shape[0], w_transposed=True)
+            else:
+                dfeats = gather_gemm(dout, weight_transpose(W3.contiguous(), mirror=False), ctx.nbr, feats.shape[0])
         if ctx.needs_input_grad[1]:
             tgt = _grad_target(ctx.w_param)
             if ctx.nbr is None:
