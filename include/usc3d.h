@@ -232,10 +232,11 @@ int usc_colstats(const float* x, const float* y, int64_t n, int32_t c,
 /* BatchNorm1d training statistics in one pass (f64 accumulation) + finalisation:
  * mean, invstd = 1/sqrt(var_biased+eps), scale = gamma*invstd, shift = beta-mean*scale,
  * and the running-stat update running = (1-m)*running + m*{mean, var_unbiased}
- * (running_* may both be NULL).  ws: usc_colstats_ws_bytes(n, c). */
+ * (running_* may both be NULL).  ws: usc_colstats_ws_bytes(n, c).  num_batches_tracked (i64[1]
+ * or NULL) is incremented by the same launch. */
 int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamma,
                          const float* beta, float eps, float momentum,
-                         float* running_mean, float* running_var, float* mean,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
                          float* invstd, float* scale, float* shift, void* ws,
                          int64_t ws_bytes, usc_stream_t s);
 /* y = [relu]( x*scale[c] + shift[c] (+ residual) ); mask-free (backward uses y>0). */

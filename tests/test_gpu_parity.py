@@ -193,6 +193,7 @@ def test_parameter_gradients_accumulate_in_place(device):
     for p, r, ptr in zip(list(conv.parameters()) + list(bn.parameters()), ref, ptrs):
         assert p.grad.data_ptr() == ptr
         assert rel_err(p.grad, 2 * r) < 1e-6
+    assert int(bn.bn.num_batches_tracked) == 3              # bumped inside the statistics launch, once per forward
 
 
 @pytest.mark.parametrize("cin,cout", [(32, 32), (128, 128), (256, 128), (96, 96)])

@@ -372,11 +372,11 @@ class MinkowskiBatchNorm(nn.Module):
 
     def forward(self, x: SparseTensor, residual: SparseTensor = None, relu: bool = False) -> SparseTensor:
         bn = self.bn
-        if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
         training = bn.training or not bn.track_running_stats
+        # nn.BatchNorm's batch counter is bumped inside the statistics launch (one tiny add kernel per layer otherwise)
+        nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
         out = ops.batch_norm_act(x.F, bn.weight, bn.bias, None if residual is None else residual.F, relu, bn.eps,
-                                 bn.running_mean, bn.running_var, bn.momentum, training)
+                                 bn.running_mean, bn.running_var, bn.momentum, training, nbt)
         return x._like(out)
 
 

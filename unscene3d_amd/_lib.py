@@ -50,7 +50,7 @@ SIGNATURES = {
     "usc_bn_apply": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i64, _i32, _p]),
     "usc_bn_backward_dx": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "usc_bn_backward_reduce": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p]),
-    "usc_bn_forward_stats": (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "usc_bn_forward_stats": (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "usc_relu_fwd": (C.c_int, [_p, _p, _i64, _p]),
     "usc_relu_bwd": (C.c_int, [_p, _p, _p, _i64, _p]),
     "usc_avgpool_down2": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),

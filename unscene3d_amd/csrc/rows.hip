@@ -129,6 +129,7 @@ struct BnFwdOut {
   float* mean; float* invstd; float* scale; float* shift;
   float eps, momentum;
   int64_t n;
+  int64_t* num_batches_tracked;   // incremented once per call when not NULL (nn.BatchNorm's counter)
 };
 __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int c,
                                                             BnFwdOut o) {
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const double* __res
       o.running_mean[ch] = (1.f - o.momentum) * o.running_mean[ch] + o.momentum * mean;
       o.running_var[ch] = (1.f - o.momentum) * o.running_var[ch] + o.momentum * (float)unbiased;
     }
+    if (ch == 0 && o.num_batches_tracked) *o.num_batches_tracked += 1;
   }
 }
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int c,
@@ -542,15 +544,16 @@ int usc_colstats(const float* x, const float* y, int64_t n, int32_t c, double* s
 }
 
 int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamma, const float* beta, float eps,
-                         float momentum, float* running_mean, float* running_var, float* mean, float* invstd,
-                         float* scale, float* shift, void* ws, int64_t ws_bytes, usc_stream_t s) {
+                         float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                         float* mean, float* invstd, float* scale, float* shift, void* ws, int64_t ws_bytes,
+                         usc_stream_t s) {
   USC_REQUIRE(x && gamma && beta && mean && invstd && scale && shift && ws && n >= 1, "usc_bn_forward_stats: bad argument");
   USC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "usc_bn_forward_stats: running stats mismatch");
   StatArgs a{x, nullptr, nullptr, nullptr, nullptr, n, (int)c};
   int nb = 0;
   int rc = launch_colstats_partials<STAT_XY>(a, ws, ws_bytes, as_stream(s), "usc_bn_forward_stats", &nb);
   if (rc) return rc;
-  BnFwdOut o{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n};
+  BnFwdOut o{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n, num_batches_tracked};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c, o);
   USC_CHECK_LAUNCH("usc_bn_forward_stats");
   return USC_OK;

@@ -473,7 +473,8 @@ class _BatchNormAct(torch.autograd.Function):
     fused into one stats pass and one apply pass (reference models/modules/resnet_block.py:48-64)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, relu, eps, running_mean, running_var, momentum, training):
+    def forward(ctx, x, gamma, beta, residual, relu, eps, running_mean, running_var, momentum, training,
+                num_batches_tracked=None):
         x = x.contiguous()
         n, c = x.shape
         dev = x.device
@@ -482,8 +483,9 @@ class _BatchNormAct(torch.autograd.Function):
             mean, invstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
             ws = _ws(lib.usc_colstats_ws_bytes(n, c), dev)
             check(lib.usc_bn_forward_stats(_ptr(x), n, c, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
-                                           _ptr(running_mean), _ptr(running_var), _ptr(mean), _ptr(invstd),
-                                           _ptr(scale), _ptr(shift), _ptr(ws), ws.numel(), _stream()),
+                                           _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
+                                           _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), _ptr(ws), ws.numel(),
+                                           _stream()),
                   "usc_bn_forward_stats")
         else:
             mean = running_mean
@@ -515,12 +517,15 @@ class _BatchNormAct(torch.autograd.Function):
         dres = torch.empty_like(x) if ctx.has_res else None
         check(lib.usc_bn_backward_dx(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(red[2]),
                                      _ptr(red[3]), _ptr(dx), _ptr(dres), n, c, _stream()), "usc_bn_backward_dx")
-        return dx, (None if in_place else red[0]), (None if in_place else red[1]), dres, None, None, None, None, None, None
+        return (dx, (None if in_place else red[0]), (None if in_place else red[1]), dres, None, None, None, None, None,
+                None, None)
 
 
 def batch_norm_act(x, gamma, beta, residual=None, relu=False, eps=1e-5, running_mean=None, running_var=None,
-                   momentum=0.1, training=True):
-    return _BatchNormAct.apply(x, gamma, beta, residual, relu, eps, running_mean, running_var, momentum, training)
+                   momentum=0.1, training=True, num_batches_tracked=None):
+    """`num_batches_tracked` (i64[1], optional) is incremented inside the statistics launch of a training pass."""
+    return _BatchNormAct.apply(x, gamma, beta, residual, relu, eps, running_mean, running_var, momentum, training,
+                               num_batches_tracked)
 
 
 class _ReLU(torch.autograd.Function):
