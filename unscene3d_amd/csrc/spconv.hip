@@ -930,9 +930,12 @@ static GemmPlan plan_table(int64_t n_out, int cin, int cout, int K) {
     const int cb = cout / 32;
     const int nb = (cb % 3 == 0) ? 3 : (cb % 2 == 0 ? 2 : 1);
     const int tm_max = nb == 3 ? 192 : 256;
+#ifndef USC_TILE_SLOTS
+#define USC_TILE_SLOTS 256   /* whole rounds of 256 CUs; 512 (both resident workgroups of a CU) measured 5 % slower on the 40 k-row map: smaller tiles pad more */
+#endif
     int64_t R = 1;
-    int64_t tm = ceil_div(n_out, 256 * R);
-    while (tm > tm_max) { ++R; tm = ceil_div(n_out, 256 * R); }
+    int64_t tm = ceil_div(n_out, (int64_t)USC_TILE_SLOTS * R);
+    while (tm > tm_max) { ++R; tm = ceil_div(n_out, (int64_t)USC_TILE_SLOTS * R); }
     tm = (tm + 3) & ~3ll;
     pl.NB = nb;
     pl.TM = (int)tm;
