@@ -667,9 +667,11 @@ def test_layernorm_matches_torch(device, rows, d):
     assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
 
 
-@pytest.mark.parametrize("rows,n_in,n_out", [(100, 128, 128), (100, 128, 1024), (100, 1024, 128), (1, 32, 64), (333, 96, 160)])
+@pytest.mark.parametrize("rows,n_in,n_out", [(100, 128, 128), (100, 128, 1024), (100, 1024, 128), (1, 32, 64), (333, 96, 160),
+                                              (3200, 128, 128), (12800, 96, 128)])
 def test_small_row_linear_matches_torch(device, rows, n_in, n_out):
-    """usc_linear_fwd/bwd (few-row linear layers of the decoder) vs F.linear in float64."""
+    """ops.linear vs F.linear in float64: usc_linear_fwd/bwd for the few-row layers of the decoder; for thousands of
+    rows (projections of the sampled voxels) the weight gradient goes through usc_spconv_wgrad with identity pairs."""
     from unscene3d_amd import ops
 
     g = torch.Generator().manual_seed(rows + n_in)

@@ -312,18 +312,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
   }
 }
 
+// one wave per (bh, query): lane = (partial group jj = lane >> 4, channel d = lane & 15); every lane sums a quarter of the
+// (split, wave) partials, the four groups are combined by two shuffles — fixed order, a quarter of the dependent loads
 __global__ __launch_bounds__(256) void attn_dq_reduce_kernel(AttnParams p) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int d = (int)(t % HD);
-  const int64_t r = t / HD;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int qi = (int)(r % p.L);
   const int bh = (int)(r / p.L);
   if (bh >= p.B * p.H) return;
-  float s = 0.f;
+  const int d = lane & 15, jj = lane >> 4;
   const int n = p.nsplit * 4;
-  for (int j = 0; j < n; ++j) s += p.dq_part[(((int64_t)bh * n) + j) * kMaxL * HD + qi * HD + d];
-  const int b = bh / p.H, hh = bh % p.H;
-  p.dq[(int64_t)qi * p.B * p.E + (int64_t)b * p.E + hh * HD + d] = s;
+  float s = 0.f;
+  for (int j = jj; j < n; j += 4) s += p.dq_part[(((int64_t)bh * n) + j) * kMaxL * HD + qi * HD + d];
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (jj == 0) {
+    const int b = bh / p.H, hh = bh % p.H;
+    p.dq[(int64_t)qi * p.B * p.E + (int64_t)b * p.E + hh * HD + d] = s;
+  }
 }
 
 static int pick_splits(int BH, int S) {
@@ -403,7 +409,7 @@ int usc_attn_bwd(const float* q, const float* k, const float* v, const uint8_t* 
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)ceil_div((int64_t)B * H * L, 256)), dim3(256), 0, st, dO, o, (int)L,
                      (int)B, (int)H, (int)E, D);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H, p.nsplit), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)ceil_div((int64_t)B * H * L * HD, 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)ceil_div((int64_t)B * H * L, 4)), dim3(256), 0, st, p);
   USC_CHECK_LAUNCH("usc_attn_bwd");
   return USC_OK;
 }
