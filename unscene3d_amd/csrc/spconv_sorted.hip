@@ -27,6 +27,10 @@ void launch_group_reduce(const float* partial, int G, int64_t numel4, int cout, 
 namespace {
 
 constexpr int kKeyBits = 12;
+#ifndef USC_SORT_ROWS
+#define USC_SORT_ROWS 2   /* rows per thread in the bucket-sort kernels (workgroup = 256 * USC_SORT_ROWS rows) */
+#endif
+constexpr int kSortRows = USC_SORT_ROWS;
 constexpr int kBins = 1 << kKeyBits;
 constexpr int kZeroFloats = 4096;
 __device__ float s_zero_row[kZeroFloats + 8];
@@ -46,9 +50,9 @@ __global__ __launch_bounds__(256) void rowmask_hist_kernel(const int32_t* __rest
   __shared__ uint32_t lh[kBins];
   for (int e = threadIdx.x; e < kBins; e += 256) lh[e] = 0u;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * 1024;
+  const int64_t base = (int64_t)blockIdx.x * (256 * kSortRows);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < kSortRows; ++u) {
     const int64_t r = base + u * 256 + threadIdx.x;
     if (r < n) {
       uint32_t m = 0;
@@ -93,10 +97,10 @@ __global__ __launch_bounds__(256) void bucket_place_kernel(const uint32_t* __res
   __shared__ uint32_t lh[kBins];
   for (int e = threadIdx.x; e < kBins; e += 256) lh[e] = 0u;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * 1024;
-  uint32_t key[4], rank[4];
+  const int64_t base = (int64_t)blockIdx.x * (256 * kSortRows);
+  uint32_t key[kSortRows], rank[kSortRows];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < kSortRows; ++u) {
     const int64_t r = base + u * 256 + threadIdx.x;
     key[u] = 0; rank[u] = 0;
     if (r < n) {
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(256) void bucket_place_kernel(const uint32_t* __res
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
+  for (int u = 0; u < kSortRows; ++u) {
     const int64_t r = base + u * 256 + threadIdx.x;
     if (r < n) perm[lh[key[u]] + rank[u]] = (int32_t)r;
   }
@@ -409,7 +413,7 @@ int usc_rowsort_build(const int32_t* nbr, int32_t K, int64_t n_out, int32_t* per
   const KeySel sel = key_selection(K);
   (void)hipMemsetAsync(bins, 0, kBins * 4, st);
   const unsigned nb = (unsigned)ceil_div(n_out, 256);
-  const unsigned nb4 = (unsigned)ceil_div(n_out, 1024);
+  const unsigned nb4 = (unsigned)ceil_div(n_out, 256 * kSortRows);
   hipLaunchKernelGGL(rowmask_hist_kernel, dim3(nb4), dim3(256), 0, st, nbr, (int)K, n_out, sel, mask, bins);
   hipLaunchKernelGGL(bins_scan_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)bins, cursor);
   hipLaunchKernelGGL(bucket_place_kernel, dim3(nb4), dim3(256), 0, st, (const uint32_t*)mask, n_out, sel, cursor, perm);
