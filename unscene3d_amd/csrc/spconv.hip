@@ -318,7 +318,10 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
 #ifndef USC_KRB
 #define USC_KRB 2
 #endif
-  constexpr int kDA = 3, kDB = USC_KDB;  // prefetch distances in quads
+#ifndef USC_KDA
+#define USC_KDA 3
+#endif
+  constexpr int kDA = USC_KDA, kDB = USC_KDB;  // prefetch distances in quads
   constexpr int kRA = 4, kRB = USC_KRB;  // ring sizes (the quad loop is unrolled by 4: static slots)
   float4 ra[kRA];
   float4 rb[kRB][NB];   // [slot][accumulator] -> the 4 k-steps of the quad
@@ -364,7 +367,10 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     // compiler barriers and lgkmcnt waits below.
 #ifndef USC_ABLATE_TICKET
     if (lane == 0) {
-      while (*ticket3 != st.item) __builtin_amdgcn_s_sleep(1);
+#ifndef USC_POLL_SLEEP
+#define USC_POLL_SLEEP 1
+#endif
+      while (*ticket3 != st.item) __builtin_amdgcn_s_sleep(USC_POLL_SLEEP);
     }
     __builtin_amdgcn_wave_barrier();
 #endif
@@ -379,7 +385,10 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     // atomics measured 2x slower for the whole kernel).  The reads of a batch of rows are issued
     // before the first dependent add so the row updates pipeline instead of paying one LDS round
     // trip each — the serialised flush is the critical section of the workgroup.
-    constexpr int kFB = 4;   // rows per batch (register budget: the load rings stay live across the flush)
+#ifndef USC_KFB
+#define USC_KFB 4
+#endif
+    constexpr int kFB = USC_KFB;   // rows per batch (register budget: the load rings stay live across the flush)
 #ifdef USC_ABLATE_RMW
     {
       float sink = 0.f;
