@@ -466,6 +466,56 @@ int usc_project_planes_bwd(const int32_t* coords, int64_t V, int32_t inst,
                            const float* g_yz, float* grad_pred,
                            usc_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * F1  2D -> 3D feature projection — replaces [CUDA ext] project_features_cuda.project_features_cuda
+ * and project_features_cuda.unproject_depth_images (utils/cuda_utils/project_image_cuda.cpp:10-31,
+ * project_image_cuda_kernel.cu:24-146,190-290; wrapper utils/cuda_utils/raycast_image.py:18-77; caller
+ * pseudo_masks/unscene3d_pseudo_main.py:287-330).
+ * views f32[B,V,4,4] row-major camera-to-grid matrices in voxel units (already shifted by the per-batch
+ * minimum like the wrapper does), intrinsics f32[B,4] = fx, fy, mx, my.
+ * Every pixel (b,v,y,x) marches  t = t0, t0+inc, ...  (sequential fp32 accumulation, like the reference)
+ * and reports the row of the first occupied voxel at round-half-away(cam + t*dir):
+ *   hit i32[B,V,H,W]   row, -1 = none.  Row 0 never hits (the reference's grid stores 0 for "empty").
+ *   seg i64[B,V,H,W]   optional: row, or n_rows for a miss — the segment ids usc_segment_csr takes.
+ * _map: the occupancy is the coordinate hash of usc_coordmap_build (tensor stride 1); shift i32[B,3] is
+ *       the per-batch minimum coordinate (grid voxel + shift = map coordinate).
+ * _dense: occupancy i64[B,dim_z,dim_y,dim_x] exactly as the reference builds it (0 = empty).
+ * ---------------------------------------------------------------------- */
+int usc_raycast_first_hit_map(const uint64_t* table_keys, const int32_t* table_vals,
+                              int64_t cap, int64_t n_rows, const int32_t* shift,
+                              const float* views, const float* intrinsics,
+                              int32_t B, int32_t V, int32_t H, int32_t W,
+                              float depth_min, float depth_max, float ray_increment,
+                              int32_t* hit, int64_t* seg, usc_stream_t s);
+int usc_raycast_first_hit_dense(const int64_t* occupancy, int32_t dim_z, int32_t dim_y,
+                                int32_t dim_x, int64_t n_rows, const float* views,
+                                const float* intrinsics, int32_t B, int32_t V,
+                                int32_t H, int32_t W, float depth_min, float depth_max,
+                                float ray_increment, int32_t* hit, int64_t* seg,
+                                usc_stream_t s);
+/* Per-voxel reduction of the hit pixels' features over the CSR (order, seg_off) that
+ * usc_segment_csr built from `seg` with n_rows+1 segments; feats f32[n_pix,c]; sums run in
+ * ascending pixel order (deterministic; the reference's float atomics are unordered).
+ *   mode 0: out f32[n_rows,c] = sum / (count + 10e-5) on every row (0 where nothing hit);
+ *           num i32[n_rows] = count                                  (raycast_image.py:66-68)
+ *   mode 1: out is the scene feature table: out[r] = (out[r] + sum/(count+10e-5)) / 2 on the rows
+ *           that were hit only; num = count     (unscene3d_pseudo_main.py:311-313, :327-328)
+ *   mode 2: out[r] += sum, num[r] += count — the operator's own in-place accumulation
+ *           (project_image_cuda_kernel.cu:49,61-64)
+ *   num may be NULL. */
+int usc_project_reduce(const float* feats, int32_t c, const int64_t* order,
+                       const int64_t* seg_off, int64_t n_rows, int32_t mode,
+                       float* out, int32_t* num, usc_stream_t s);
+/* Prediction mode (project_image_cuda_kernel.cu:68-109): out i32[n_rows,c] (caller-initialised to the
+ * ignore label) = max(out, preds of the pixels that hit the row); preds i32[n_pix,c]. */
+int usc_project_predictions(const int32_t* preds, int32_t c, const int32_t* hit,
+                            int64_t n_pix, int32_t* out, usc_stream_t s);
+/* depth f32[V,H,W], views f32[V,4,4], intrinsics f32[V,4] -> cloud f32[V*H*W,5] = (view, pixel index,
+ * x, y, z) for depth > 0; other rows are left as the caller initialised them
+ * (project_image_cuda_kernel.cu:249-290). */
+int usc_unproject_depth(const float* depth, const float* views, const float* intrinsics,
+                        int32_t V, int32_t H, int32_t W, float* cloud, usc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,3 +193,48 @@ def make_segment_scene(seed: int, side: int = 25, dims=(384, 96), n_objects: int
     und = np.concatenate([right, down])
     conn = np.concatenate([und, und[:, ::-1]]).astype(np.int64)
     return feats, conn, label
+
+
+# ---- 2D -> 3D projection inputs (a voxelised room and camera poses inside it) ----------------------------------
+def room_voxels(seed, dims=(40, 36, 28), n_boxes=4, batch=1, origin=(-7, 11, 3)):
+    """Voxel shell of a room (floor, ceiling, walls) with a few boxes inside, rows shuffled."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(batch):
+        X, Y, Z = dims
+        g = np.zeros((X, Y, Z), bool)
+        g[0], g[-1], g[:, 0], g[:, -1], g[:, :, 0], g[:, :, -1] = True, True, True, True, True, True
+        for _ in range(n_boxes):
+            lo = rng.integers(3, [X - 10, Y - 10, Z - 10])
+            sz = rng.integers(3, 8, 3)
+            g[lo[0]:lo[0] + sz[0], lo[1]:lo[1] + sz[1], lo[2]:lo[2] + sz[2]] = True
+        xyz = np.argwhere(g)
+        xyz = xyz[rng.permutation(len(xyz))] + np.asarray(origin) + b
+        out.append(np.concatenate([np.full((len(xyz), 1), b), xyz], 1))
+    return np.concatenate(out).astype(np.int32)
+
+
+def look_at(eye, target, up=(0, 0, 1)):
+    """Camera-to-world 4x4 (camera z forward, x right, y down)."""
+    eye, target, up = (np.asarray(v, np.float64) for v in (eye, target, up))
+    z = target - eye
+    z /= np.linalg.norm(z)
+    x = np.cross(z, up)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2], m[:3, 3] = x, y, z, eye
+    return m.astype(np.float32)
+
+
+def camera_views(seed, coords, n_views, dims=(40, 36, 28)):
+    rng = np.random.default_rng(seed)
+    B = int(coords[-1, 0]) + 1
+    views = np.zeros((B, n_views, 4, 4), np.float32)
+    for b in range(B):
+        lo = coords[coords[:, 0] == b, 1:].min(0)
+        for v in range(n_views):
+            eye = lo + np.asarray(dims) * rng.uniform(0.35, 0.65, 3)
+            tgt = lo + np.asarray(dims) * rng.uniform(0.1, 0.9, 3)
+            views[b, v] = look_at(eye, tgt)
+    return views
