@@ -7,6 +7,7 @@ not installed: SURVEY.md Appendix A), feeds them seeded inputs and stores inputs
 
     python tests/golden/make_golden.py            # criterion / posenc / decoder_layers fixtures
     python tests/golden/make_golden.py ncut       # NCut fixtures (separate interpreter: different stubs)
+    python tests/golden/make_golden.py export     # eval/export post-processing fixtures (trainer.eval_instance_step)
 """
 import importlib
 import os
@@ -245,10 +246,151 @@ def make_ncut(ref):
     np.savez_compressed(os.path.join(HERE, "ncut.npz"), **out)
 
 
+def import_reference_trainer():
+    stub("imageio", "pyviz3d", "pyviz3d.visualizer", "torch_scatter", "matplotlib", "matplotlib.cm", "hydra",
+         "MinkowskiEngine", "MinkowskiEngine.MinkowskiOps", "MinkowskiEngine.MinkowskiPooling", "custom_cuda_utils",
+         "detectron2", "detectron2.utils", "detectron2.utils.comm", "detectron2.projects",
+         "detectron2.projects.point_rend", "detectron2.projects.point_rend.point_features", "pointnet2",
+         "pointnet2._ext", "torchvision", "pytorch_lightning", "open3d", "benchmark",
+         "benchmark.evaluate_semantic_instance", "utils.votenet_utils", "utils.votenet_utils.eval_det",
+         "albumentations", "volumentations", "plyfile", "natsort", "loguru", "fire")
+
+    class MinkowskiNetwork(nn.Module):
+        def __init__(self, D):
+            super().__init__()
+            self.D = D
+
+    def scatter_mean(src, index, dim=0):
+        # torch_scatter 2.x (not installed, not part of /root/reference): out[i] = sum(src[index == i]) / max(count, 1)
+        assert dim == 0
+        n = int(index.max()) + 1
+        out = torch.zeros((n,) + tuple(src.shape[1:]), dtype=src.dtype)
+        out.index_add_(0, index, src)
+        cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones(index.shape[0], dtype=src.dtype))
+        return out / cnt.clamp(min=1).view(-1, *([1] * (src.dim() - 1)))
+
+    sys.modules["MinkowskiEngine"].MinkowskiNetwork = MinkowskiNetwork
+    sys.modules["pytorch_lightning"].LightningModule = nn.Module
+    sys.modules["pytorch_lightning"].Callback = object
+    sys.modules["torch_scatter"].scatter_mean = scatter_mean
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    return importlib.import_module("trainer.trainer")
+
+
+def export_scene(seed, n_obj=6, q=100):
+    """A small voxel scene of box-shaped objects over a floor, an over-segmentation of it, and decoder outputs
+    that (a) cover objects, (b) duplicate some of them, (c) merge two disconnected objects in one query."""
+    rng = np.random.default_rng(seed)
+    pts, seg, obj = [], [], []
+    sid = 0
+    fx, fy = np.meshgrid(np.arange(40), np.arange(36), indexing="ij")
+    floor = np.stack([fx.ravel(), fy.ravel(), np.zeros(fx.size, int)], 1)
+    pts.append(floor)
+    seg.append(sid + (floor[:, 0] // 10) * 4 + floor[:, 1] // 9)
+    obj.append(np.zeros(len(floor), int))
+    sid += 16
+    for o in range(n_obj):
+        lo = np.array([3 + 6 * o, rng.integers(2, 24), 2 + (o % 2)])
+        sz = rng.integers(3, 6, 3)
+        g = np.stack(np.meshgrid(*[np.arange(l, l + s) for l, s in zip(lo, sz)], indexing="ij"), -1).reshape(-1, 3)
+        pts.append(g)
+        seg.append(sid + (g[:, 2] - lo[2]) // 2)
+        sid += int(((g[:, 2] - lo[2]) // 2).max()) + 1
+        obj.append(np.full(len(g), o + 1))
+    pts, seg, obj = np.concatenate(pts), np.concatenate(seg), np.concatenate(obj)
+    perm = rng.permutation(len(pts))
+    pts, seg, obj = pts[perm], seg[perm], obj[perm]
+    S = sid
+    seg_obj = np.zeros(S, int)
+    seg_obj[seg] = obj
+    masks = rng.normal(-4.0, 1.0, (S, q)).astype(np.float32)
+    for j in range(n_obj):                                   # one query per object
+        masks[:, j] = np.where(seg_obj == j + 1, 4.0, -4.0) + rng.normal(0, 0.5, S)
+    masks[:, n_obj] = np.where(seg_obj == 1, 3.0, -4.0) + rng.normal(0, 0.5, S)        # duplicate of object 1
+    masks[:, n_obj + 1] = np.where((seg_obj == 2) | (seg_obj == 5), 3.5, -4.0)          # two objects, disconnected
+    masks[:, n_obj + 2] = np.where(seg_obj == 0, 2.0, -5.0)                             # the floor
+    logits = rng.normal(0, 1, (q, 3)).astype(np.float32)
+    logits[:n_obj + 3, 1] += 4.0
+    logits[n_obj + 3:, 2] += 3.0
+    n_low = len(pts)
+    inverse = np.concatenate([np.arange(n_low), rng.integers(0, n_low, 2 * n_low)])
+    inverse = inverse[rng.permutation(len(inverse))]
+    seg_full = seg[inverse].copy()
+    flip = rng.random(len(seg_full)) < 0.04
+    seg_full[flip] = rng.integers(0, S, int(flip.sum()))
+    full_coords = (pts[inverse] + rng.uniform(0, 1, (len(inverse), 3))) * 0.02
+    t_masks = np.stack([obj[inverse] == j + 1 for j in range(n_obj)])
+    return dict(raw_coords=pts.astype(np.float64) * 0.3, point2segment=seg.astype(np.int64), pred_masks=masks,
+                pred_logits=logits, inverse_map=inverse.astype(np.int64), point2segment_full=seg_full.astype(np.int64),
+                full_res_coords=full_coords.astype(np.float32), target_masks=t_masks,
+                target_labels=np.ones(n_obj, np.int64))
+
+
+def make_export(tr):
+    import tempfile
+    from types import SimpleNamespace as NS
+
+    out = {}
+    cases = {"freemask": dict(use_dbscan=False, topk_per_image=100, filter_out_instances=True),
+             "dbscan": dict(use_dbscan=True, topk_per_image=-1, filter_out_instances=True),
+             "plain": dict(use_dbscan=False, topk_per_image=-1, filter_out_instances=False)}
+    for name, opt in cases.items():
+        scenes = [export_scene(100 + i) for i in range(2)]
+        save_dir = tempfile.mkdtemp()
+
+        class Cfg(dict):
+            __getattr__ = dict.__getitem__
+
+        general = Cfg(use_dbscan=opt["use_dbscan"], dbscan_eps=0.95, dbscan_min_points=1,
+                      topk_per_image=opt["topk_per_image"], filter_out_instances=opt["filter_out_instances"],
+                      scores_threshold=0.1, iou_threshold=0.66, separate_instances=False, eval_inner_core=-1,
+                      save_visualizations=False, save_for_freemask=True, export=False, save_dir=save_dir)
+        cfg = Cfg(general=general, data=Cfg(test_mode="validation"))
+        me = NS(config=cfg, decoder_id=-1, eval_on_segments=True, device="cpu",
+                model=NS(train_on_segments=True, num_classes=3),
+                validation_dataset=NS(label_offset=2, dataset_name="scannet", _remap_model_output=lambda o: np.asarray(o)),
+                preds={}, bbox_preds={}, bbox_gt={})
+        me.get_mask_and_scores = lambda *a, **k: tr.InstanceSegmentation.get_mask_and_scores(me, *a, **k)
+        me.get_full_res_mask = lambda *a, **k: tr.InstanceSegmentation.get_full_res_mask(me, *a, **k)
+        output = {"aux_outputs": [],
+                  "pred_logits": torch.from_numpy(np.stack([s["pred_logits"] for s in scenes])),
+                  "pred_masks": [torch.from_numpy(s["pred_masks"]) for s in scenes]}
+        target_low = [{"point2segment": torch.from_numpy(s["point2segment"])} for s in scenes]
+        target_full = [{"point2segment": torch.from_numpy(s["point2segment_full"]),
+                        "labels": torch.from_numpy(s["target_labels"].copy()),
+                        "masks": torch.from_numpy(s["target_masks"])} for s in scenes]
+        names = [f"scene{i:04d}_00" for i in range(2)]
+        tr.InstanceSegmentation.eval_instance_step(
+            me, output, target_low, target_full, [s["inverse_map"] for s in scenes], names,
+            [s["full_res_coords"] for s in scenes], [None, None], [None, None],
+            np.concatenate([s["raw_coords"] for s in scenes]), [0, 1])
+        for i, (s, nm) in enumerate(zip(scenes, names)):
+            for k, v in s.items():
+                out[f"{name}/{i}/{k}"] = np.packbits(v, axis=1) if v.dtype == bool else v
+            p = me.preds[nm]
+            pm = np.asarray(p["pred_masks"]).astype(bool)
+            out[f"{name}/{i}/out_masks"] = np.packbits(pm, axis=0)
+            out[f"{name}/{i}/out_n"] = np.array(pm.shape)
+            out[f"{name}/{i}/out_scores"] = np.asarray(p["pred_scores"], np.float32)
+            out[f"{name}/{i}/out_classes"] = np.asarray(p["pred_classes"], np.int64)
+            saved = np.load(f"{save_dir}/freemasks/{nm}_masks.npy")
+            cloud = np.load(f"{save_dir}/freemasks/{nm}_cloud.npy")
+            assert saved.dtype == bool and np.array_equal(saved, pm) and np.array_equal(cloud, s["full_res_coords"])
+            out[f"{name}/{i}/out_boxes"] = np.array([np.concatenate([[c], b, [sc]]) for c, b, sc in me.bbox_preds[nm]],
+                                                    np.float64).reshape(-1, 8)
+            print(name, i, "masks", pm.shape, "scores", out[f"{name}/{i}/out_scores"][:6])
+        for k, v in opt.items():
+            out[f"{name}/{k}"] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "export.npz"), **out)
+
+
 if __name__ == "__main__":
     cwd = os.getcwd()
     if len(sys.argv) > 1 and sys.argv[1] == "ncut":
         make_ncut(import_reference_ncut())
+    elif len(sys.argv) > 1 and sys.argv[1] == "export":
+        make_export(import_reference_trainer())
     else:
         mods = import_reference_models()
         make_criterion(mods)
