@@ -8,6 +8,7 @@ not installed: SURVEY.md Appendix A), feeds them seeded inputs and stores inputs
     python tests/golden/make_golden.py            # criterion / posenc / decoder_layers fixtures
     python tests/golden/make_golden.py ncut       # NCut fixtures (separate interpreter: different stubs)
     python tests/golden/make_golden.py export     # eval/export post-processing fixtures (trainer.eval_instance_step)
+    python tests/golden/make_golden.py dataset    # self-train mask merge + validation-mode scene reader fixtures
 """
 import importlib
 import os
@@ -385,10 +386,95 @@ def make_export(tr):
     np.savez_compressed(os.path.join(HERE, "export.npz"), **out)
 
 
+def import_reference_dataset():
+    stub("open3d", "felzenszwalb_cpp", "albumentations", "volumentations", "imageio", "MinkowskiEngine", "plyfile",
+         "natsort", "loguru", "fire", "torch_scatter", "hydra")
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    return importlib.import_module("datasets.freemask_semseg")
+
+
+def make_dataset(ds):
+    import tempfile
+    from types import SimpleNamespace as NS
+
+    rng = np.random.default_rng(7)
+    out = {}
+    tmp = tempfile.mkdtemp()
+    os.makedirs(f"{tmp}/freemasks")
+    os.makedirs(f"{tmp}/scans/scene0001_00")
+    n = 4000
+    xyz = rng.uniform(0, [6, 5, 2.5], (n, 3))
+    pts = np.concatenate([xyz, rng.integers(0, 256, (n, 3)), rng.normal(0, 1, (n, 3)), rng.integers(0, 60, (n, 1)),
+                          np.zeros((n, 2))], 1).astype(np.float32)
+    obj = (xyz[:, 0] // 1.0).astype(int) + 6 * (xyz[:, 1] // 2.5).astype(int)            # 12 spatial cells
+    free = np.stack([(obj == j) * rng.uniform(0.3, 1.0, n) for j in (0, 3, 7)], 1).astype(np.float32)
+    free = np.concatenate([free, (rng.random((n, 1)) < 0.25) * 0.9], 1).astype(np.float32)   # one scene-sized mask
+    # the previous round's export: a different (denser) cloud with its own masks, most confident first
+    m = 6000
+    cloud = np.concatenate([xyz + rng.normal(0, 0.004, (n, 3)), rng.uniform(0, [6, 5, 2.5], (m - n, 3))]).astype(np.float32)
+    cobj = (cloud[:, 0] // 1.0).astype(int) + 6 * (cloud[:, 1] // 2.5).astype(int)
+    st = np.stack([cobj == 1, (cobj == 0) | (cobj == 2), cobj == 3, cobj == 5, (cobj == 5) | (cobj == 8), cobj == 9,
+                   cobj == 10, cobj == 11], 1)
+    np.save(f"{tmp}/scans/scene0001_00/0001_00.npy", pts)
+    np.save(f"{tmp}/scans/scene0001_00/0001_00_freemasks.npy", free)
+    np.save(f"{tmp}/freemasks/scene0001_00_cloud.npy", cloud)
+    np.save(f"{tmp}/freemasks/scene0001_00_masks.npy", st)
+    out.update(points=pts, freemasks=free, st_cloud=cloud, st_masks=np.packbits(st, axis=1))
+
+    mean, std = (0.47793125906962, 0.4303257521323044, 0.3749598901421883), (0.2834475483823543, 0.27566157565723015, 0.27018971370874995)
+
+    def normalize(image):
+        # albumentations.Normalize(mean, std, max_pixel_value=255) — third-party, not installed, not in /root/reference:
+        # img = (img - mean * 255) * (1 / (std * 255)) in float32
+        mu = np.array(mean, np.float32) * 255.0
+        den = np.reciprocal(np.array(std, np.float32) * 255.0)
+        return {"image": (image.astype(np.float32) - mu) * den}
+
+    me = NS(data=[{"filepath": f"{tmp}/scans/scene0001_00/0001_00.npy",
+                   "raw_filepath": f"{tmp}/raw/scene0001_00/scene0001_00_vh_clean_2.ply"}],
+            self_train_data_dir=tmp, load_self_train_data=True, num_self_train_data=5, cache_data=False, on_crops=False,
+            max_num_gt_instances=-1, resegment_mesh=False, freemask_extent_max_ratio=0.8, freemask_hard_threshold=0.5,
+            add_colors=True, add_normals=True, add_raw_coordinates=True, mode="validation",
+            volume_augmentations=NS(), normalize_color=normalize)
+    me.load_self_train_masks = lambda *a, **k: ds.SemanticSegmentationFreeDataset.load_self_train_masks(me, *a, **k)
+    me.__len__ = lambda: 1
+    cls = ds.SemanticSegmentationFreeDataset
+    # (a) the exported cloud differs from the scene's points: 1-NN transfer.  The reference queries its 3-D tree with
+    # the [N,12] point table, which scipy rejects — the branch only works for a caller that passes xyz, so that is what
+    # the fixture records.
+    for nsd, drop in ((5, False), (2, False), (8, True)):
+        me.num_self_train_data = nsd
+        merged = cls.load_self_train_masks(me, 0, pts[:, :3], free, drop_original=drop)
+        out[f"merge/{nsd}_{int(drop)}"] = merged.astype(np.float32)
+        print("merge", nsd, drop, merged.shape)
+    me.num_self_train_data = 5
+    # (b) the usual case: the export was made on this very cloud (trainer.py:749 saves full_res_coords)
+    same = np.stack([obj == 1, (obj == 0) | (obj == 2), obj == 3, obj == 5, (obj == 5) | (obj == 8), obj == 9], 1)
+    np.save(f"{tmp}/freemasks/scene0001_00_cloud.npy", pts[:, :3])
+    np.save(f"{tmp}/freemasks/scene0001_00_masks.npy", same)
+    out["st_masks_same"] = np.packbits(same, axis=1)
+
+    class Fake(NS):
+        def __len__(self):
+            return 1
+    fake = Fake(**vars(me))
+    item = cls.__getitem__(fake, 0)
+    names = ("coordinates", "features", "freemasks", "scene_name", "raw_color", "raw_normals", "raw_coordinates", "idx")
+    for k, v in zip(names, item):
+        if k not in ("scene_name", "idx"):
+            out[f"item/{k}"] = np.asarray(v)
+    assert item[3] == "scene0001_00" and item[7] == 0 and item[8] == []
+    print("item", [np.asarray(v).shape for v in item[:3]])
+    np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
+
+
 if __name__ == "__main__":
     cwd = os.getcwd()
     if len(sys.argv) > 1 and sys.argv[1] == "ncut":
         make_ncut(import_reference_ncut())
+    elif len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        make_dataset(import_reference_dataset())
     elif len(sys.argv) > 1 and sys.argv[1] == "export":
         make_export(import_reference_trainer())
     else:
