@@ -11,6 +11,8 @@
 // transformations is restated here in fp64 — the result matches LAPACK's vector including its sign
 // (verified against scipy on the golden fixtures).  Everything is S x S (S = 600..3000 segments):
 // latency-bound; the trailing-matrix symv / rank-2 update of every Householder step run chip-wide.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace usc {
@@ -252,6 +254,289 @@ __global__ __launch_bounds__(256) void tri_update_kernel(TriState t, int64_t i) 
     t.C[r * n + c] -= v[r] * wc + wr * v[c];
   }
 }
+// ---------------------------------------------------------------------------
+// The whole tridiagonalisation in ONE launch.  The two-launch-per-step path above spends its time in the ~5 us
+// kernel-to-kernel latency of 2(n-1) dependent launches; here G co-resident workgroups keep the working matrix
+// distributed by rows (row r lives with workgroup r mod G, in LDS when it fits) and meet at one grid barrier per
+// Householder step (the exchange of p below):
+//   before the exchange of step i every workgroup builds reflector i from the pivot column it already holds
+//                                 (redundantly — same reduction order as tri_reflect_symv_kernel), forms its rows of
+//                                 p = C22 v, and the owner of row i+1 publishes that row as it stands;
+//   after the exchange            every workgroup has p, forms w = tau p - (tau^2/2)(p.v) v, applies the rank-2
+//                                 update to its own rows and — to the published row i+1 — redundantly, which is the
+//                                 pivot column of step i+1 (C stays exactly symmetric: v_r w_c + w_r v_c commutes).
+// p and the published row travel as 16-byte {value, step tag} slots, stored write-through and polled by the threads
+// that need them: the data is its own arrival flag, so a step costs one store -> load trip through memory and no
+// counter, drain or fence.  Slots ping-pong between two buffers (nobody can run more than one step ahead).
+// The arithmetic per element is that of the stepwise kernels, so both paths give the same T and reflectors.
+// Waits are bounded: a thread that does not see its slots arrive raises the error word and everybody leaves
+// (d[0] becomes NaN, which the caller sees as a NaN eigenpair) instead of hanging the device.
+struct Slot {          // 16 bytes, written and read as ONE dwordx4 access: a value never shows without its tag
+  double value;
+  uint64_t tag;
+};
+struct TriPersist {
+  TriState t;
+  Slot* pbuf;        // [2][n]  p of step i lives in pbuf[i & 1], tagged i + 1
+  Slot* rowbuf;      // [2][n]  row i+1 as it stood before the update of step i
+  unsigned int* sync;  // [1] error flag   (zeroed before launch, with the slots)
+  int G;
+  int R;             // rows per workgroup
+  int ld;            // LDS row pitch (doubles)
+};
+constexpr unsigned int kSpinLimit = 1u << 20;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// write-through / cache-bypassing 16-byte buffer accesses (aux = sc1): visible across the eight XCD L2s without
+// fences; as compiler intrinsics (not asm) several loads can be in flight before one wait
+constexpr int kSc1 = 16;
+__device__ inline u32x4 slot_pack(double value, uint64_t tag) {
+  u32x4 q;
+  q.x = (unsigned int)__double2loint(value); q.y = (unsigned int)__double2hiint(value);
+  q.z = (unsigned int)tag; q.w = (unsigned int)(tag >> 32);
+  return q;
+}
+__device__ inline double slot_value(const u32x4& q) { return __hiloint2double((int)q.y, (int)q.x); }
+__device__ inline uint64_t slot_tag(const u32x4& q) { return (uint64_t)q.z | ((uint64_t)q.w << 32); }
+
+// Reductions of doubles on the DPP path (row shifts and row broadcasts: VALU latency) instead of ds_bpermute
+// (__shfl_xor: two LDS-crossbar trips per level) — a Householder step is a chain of dependent reductions.
+// The DPP sequence adds neighbours first (lane bit 0, then 1, ... 5); the xor butterfly of wave_reduce_addd adds
+// distance 32 first (bit 5, then 4, ... 0).  Both are balanced trees, so with the summands placed in bit-reversed lane
+// order the DPP tree is the butterfly's tree and the sums are bit-identical to the stepwise kernels'.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over each row of 16 lanes; valid in the row's last lane (15, 31, 47, 63)
+__device__ inline double row16_sum(double x) {
+  x += dpp_f64<0x111, 0xf>(x);   // row_shr:1
+  x += dpp_f64<0x112, 0xf>(x);   // row_shr:2
+  x += dpp_f64<0x114, 0xf>(x);   // row_shr:4
+  x += dpp_f64<0x118, 0xf>(x);   // row_shr:8
+  return x;
+}
+__device__ inline int bitrev6(int l) { return (int)(__brev((unsigned int)l) >> 26); }
+__device__ inline int bitrev4(int l) { return (int)(__brev((unsigned int)l) >> 28); }
+// sum over the wave, broadcast to every lane
+__device__ inline double wave_sum_dpp(double x) {
+  x = row16_sum(x);
+  x += dpp_f64<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+  x += dpp_f64<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+  return __hiloint2double(hi, lo);
+}
+
+template <bool LDS_ROWS>
+__global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
+  extern __shared__ double lds[];
+  __shared__ double red[20];
+  __shared__ int s_abort;
+  const TriState& t = a.t;
+  const int64_t n = t.n;
+  const int G = a.G, R = a.R, g = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int erev = bitrev6(lane), frev = bitrev4(tid & 15);
+  const int64_t ld = a.ld;   // row pitch in LDS: = 16 mod 32 doubles, so two 16-lane row groups hit disjoint banks
+  const __amdgpu_buffer_rsrc_t slots = __builtin_amdgcn_make_buffer_rsrc((void*)a.pbuf, 0, (int)(4 * n * 16), 0x00020000);
+  double* v = lds;            // [n] reflector
+  double* w = v + n;          // [n]
+  double* p = w + n;          // [n]
+  double* piv = p + n;        // [n] pivot column of the current step (entries >= i valid)
+  double* rows_l = piv + n;   // [R][n] when LDS_ROWS
+  auto row_ptr = [&](int q) -> double* {
+    return LDS_ROWS ? rows_l + (int64_t)q * ld : t.C + ((int64_t)g + (int64_t)q * G) * n;
+  };
+  if (LDS_ROWS) {
+    for (int q = 0; q < R; ++q) {
+      const int64_t r = g + (int64_t)q * G;
+      if (r < n) for (int64_t c = tid; c < n; c += 256) rows_l[(int64_t)q * ld + c] = t.C[r * n + c];
+    }
+  }
+  for (int64_t c = tid; c < n; c += 256) piv[c] = t.C[c];   // row 0 == column 0
+  if (tid == 0) s_abort = 0;
+  __syncthreads();
+
+#ifdef USC_TRI_TIMING
+  long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = clock64(), t1;
+#define TRI_MARK(acc) do { t1 = clock64(); acc += t1 - t0; t0 = t1; } while (0)
+#else
+#define TRI_MARK(acc) do {} while (0)
+#endif
+  for (int64_t i = 0; i + 1 < n; ++i) {
+    // ---- reflector i from piv (x = piv[i+2..], alpha = piv[i+1]); every thread ends up with tau and scale ----
+    {
+      // the stepwise kernel's 1024 virtual threads: group wave + 4u, position bitrev6(lane) (see above)
+      double ss[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ss[u] = 0.0;
+        for (int64_t r = i + 2 + 64 * (wave + 4 * u) + erev; r < n; r += 1024) { const double x = piv[r]; ss[u] += x * x; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ss[u] = wave_sum_dpp(ss[u]);
+      if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) red[wave + 4 * u] = ss[u];
+      }
+    }
+    __syncthreads();
+    double tau, scale;
+    {
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += red[k];
+      const double alpha = piv[i + 1];
+      const double xnorm = sqrt(tot);
+      double beta;
+      if (xnorm == 0.0) {
+        beta = alpha; tau = 0.0; scale = 0.0;
+      } else {
+        const double nrm = hypot(alpha, xnorm);
+        beta = alpha >= 0.0 ? -nrm : nrm;
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      if (g == 0 && tid == 0) {
+        t.d[i] = piv[i];
+        t.e[i] = beta;
+        t.tau[i] = tau;
+      }
+    }
+    for (int64_t r = tid; r < n; r += 256) {
+      double val = 0.0;
+      if (r == i + 1) val = 1.0;
+      else if (r > i + 1) val = piv[r] * scale;
+      v[r] = val;
+      if (g == 0) t.Vt[i * n + r] = val;
+    }
+    __syncthreads();
+    TRI_MARK(tA);
+    if (i + 2 >= n) break;   // last step: tau = 0 (empty x), nothing to update
+    // ---- own rows of p = C22 v; the owner of row i+1 publishes it ----
+    // slots of step i: p in [par*n, par*n + n), the published row in [(2 + par)*n, ...), par = i & 1
+    const int pb_off = (int)((i & 1) * n) * 16, rb_off = (int)((2 + (i & 1)) * n) * 16;
+    const uint64_t tag = (uint64_t)i + 1;
+    // 16 lanes per row, 16 rows per pass; a lane carries four of the stepwise kernel's 64 per-lane partial sums
+    // (positions frev + 16 m) and folds them in the butterfly's order before the 16-lane DPP tree
+    for (int q = tid >> 4; q < R; q += 16) {
+      const int64_t r = g + (int64_t)q * G;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (r > i && r < n) {
+        const double* row = row_ptr(q);
+        // the four chains advance together (each keeps its own ascending-c order)
+        for (int64_t c0 = i + 1 + frev; c0 < n; c0 += 64) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int64_t c = c0 + 16 * m;
+            if (c < n) acc[m] += row[c] * v[c];
+          }
+        }
+      }
+      double sum = (acc[0] + acc[2]) + (acc[1] + acc[3]);
+      sum = row16_sum(sum);
+      if ((tid & 15) == 15 && r > i && r < n)
+        __builtin_amdgcn_raw_buffer_store_b128(slot_pack(sum, tag), slots, pb_off + (int)r * 16, 0, kSc1);
+    }
+    if ((i + 1) % G == g) {
+      const double* row = row_ptr((int)((i + 1) / G));
+      for (int64_t c = i + 1 + tid; c < n; c += 256)
+        __builtin_amdgcn_raw_buffer_store_b128(slot_pack(row[c], tag), slots, rb_off + (int)c * 16, 0, kSc1);
+    }
+    // ---- exchange: every thread waits for the tagged slots it needs (this is the grid barrier: nobody gets past
+    // step i without everybody's p of step i).  No counter, no drain, no atomic; a slot is rewritten at step i+2, by
+    // which time every workgroup has produced step i+1 and therefore finished reading step i ----
+    TRI_MARK(tB);
+    constexpr int K = 4;   // slots per thread and buffer in flight together
+    for (int64_t c0 = i + 1 + tid; c0 < n; c0 += 256 * K) {
+      u32x4 qp[K], qr[K];
+      unsigned int spins = 0;
+      for (;;) {
+        asm volatile("" ::: "memory");   // the slots change under us: reload every round
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int64_t c = c0 + 256 * k;
+          if (c < n) {
+            qp[k] = __builtin_amdgcn_raw_buffer_load_b128(slots, pb_off + (int)c * 16, 0, kSc1);
+            qr[k] = __builtin_amdgcn_raw_buffer_load_b128(slots, rb_off + (int)c * 16, 0, kSc1);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (c0 + 256 * k < n) ok = ok && slot_tag(qp[k]) == tag && slot_tag(qr[k]) == tag;
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kSpinLimit || __hip_atomic_load(&a.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          __hip_atomic_store(&a.sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_abort = 1;
+          break;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int64_t c = c0 + 256 * k;
+        if (c < n) { p[c] = slot_value(qp[k]); piv[c] = slot_value(qr[k]); }
+      }
+    }
+    __syncthreads();
+    TRI_MARK(tC);
+    if (s_abort) {
+      if (g == 0 && tid == 0) t.d[0] = __builtin_nan("");
+      return;
+    }
+    double dot = 0.0;
+    for (int64_t c = i + 1 + 64 * wave + erev; c < n; c += 256) dot += p[c] * v[c];
+    dot = wave_sum_dpp(dot);
+    if (lane == 0) red[16 + wave] = dot;
+    __syncthreads();
+    dot = red[16] + red[17] + red[18] + red[19];
+    const double a2 = -0.5 * tau * (tau * dot);
+    for (int64_t c = i + 1 + tid; c < n; c += 256) w[c] = tau * p[c] + a2 * v[c];
+    __syncthreads();
+    if (tau != 0.0) {
+      for (int q = tid >> 4; q < R; q += 16) {
+        const int64_t r = g + (int64_t)q * G;
+        if (r <= i || r >= n) continue;
+        double* row = row_ptr(q);
+        const double vr = v[r], wr = w[r];
+        // four columns per trip, loads first: a load behind a store to `row` would wait for it (same address space)
+        for (int64_t c0 = i + 1 + (tid & 15); c0 < n; c0 += 64) {
+          double x[4], wc[4], vc[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int64_t c = c0 + 16 * m;
+            if (c < n) { x[m] = row[c]; wc[m] = w[c]; vc[m] = v[c]; }
+          }
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int64_t c = c0 + 16 * m;
+            if (c < n) row[c] = x[m] - (vr * wc[m] + wr * vc[m]);
+          }
+        }
+      }
+    }
+    {
+      const double vr = v[i + 1], wr = w[i + 1];
+      for (int64_t c = i + 1 + tid; c < n; c += 256) {
+        double x = piv[c];
+        if (tau != 0.0) x -= vr * w[c] + wr * v[c];
+        piv[c] = x;
+      }
+    }
+    __syncthreads();
+    TRI_MARK(tD);
+  }
+#ifdef USC_TRI_TIMING
+  if ((g == 0 || g == G - 1) && tid == 0)
+    printf("tri timing wg %d: reflector %lld  symv+publish %lld  exchange %lld  update %lld cycles (n=%d)\n", g, tA, tB, tC, tD, (int)n);
+#endif
+  // d[n-1]: bottom-right entry after the last update; its owner holds it
+  if ((n - 1) % G == g && tid == 0) t.d[n - 1] = row_ptr((int)((n - 1) / G))[n - 1];
+}
+
 __global__ void tri_last_diag_kernel(TriState t) {
   if (threadIdx.x == 0 && blockIdx.x == 0) t.d[t.n - 1] = t.C[(t.n - 1) * t.n + (t.n - 1)];
 }
@@ -402,6 +687,43 @@ __global__ __launch_bounds__(1024) void tri_backtransform_kernel(TriState t, con
   for (int64_t r = tid; r < n; r += 1024) x[r] = z[r] / sqrt(deg[r]);
 }
 
+// One-launch tridiagonalisation when the co-resident grid and its LDS fit; false -> caller runs the stepwise path.
+// USC3D_TRI_STEPWISE=1 forces the stepwise path (A/B measurements).
+static bool launch_persistent(const TriState& t, double* tail, hipStream_t st) {
+  static const int mode = [] { const char* e = getenv("USC3D_TRI_STEPWISE"); return (e && e[0] == '1') ? 1 : 0; }();
+  if (mode == 1) return false;
+  const int64_t n = t.n;
+  if (n < 8 || n > 4000) return false;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+    return false;
+  TriPersist a;
+  a.t = t;
+  // few workgroups: every arrival is an atomic on one word, and a step's work is tiny (n = 625: 2.4 kFLOP per row)
+  static const int g_env = [] { const char* e = getenv("USC3D_TRI_G"); return e ? atoi(e) : 0; }();
+  a.G = g_env > 0 ? g_env : 64;
+  if (a.G > cus) a.G = cus;
+  if ((int64_t)a.G > n / 2) a.G = (int)(n / 2);
+  a.R = (int)ceil_div(n, a.G);
+  a.pbuf = reinterpret_cast<Slot*>(tail);
+  a.rowbuf = a.pbuf + 2 * n;
+  a.sync = reinterpret_cast<unsigned int*>(a.rowbuf + 2 * n);
+  a.ld = (int)(((n + 15) / 32) * 32 + 16);   // >= n, = 16 mod 32
+  const size_t vec_bytes = (size_t)4 * n * sizeof(double);
+  const size_t row_bytes = (size_t)a.R * a.ld * sizeof(double);
+  const bool lds_rows = vec_bytes + row_bytes <= 150 * 1024;
+  const size_t lds = lds_rows ? vec_bytes + row_bytes : vec_bytes;
+  if (lds > 150 * 1024) return false;
+  auto kern = lds_rows ? tri_persistent_kernel<true> : tri_persistent_kernel<false>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return false;
+  (void)hipMemsetAsync(tail, 0, (size_t)(8 * n + 2) * sizeof(double), st);   // tags 0 = "nothing published yet"
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.G), dim3(256), lds, st, a);
+  return true;
+}
+
 }  // namespace usc
 
 using namespace usc;
@@ -445,7 +767,7 @@ int usc_ncut_binarize(const float* simA, const float* simB, int64_t S, float tau
   return USC_OK;
 }
 
-int64_t usc_ncut_fiedler_ws_bytes(int64_t S) { return (2 * S * S + 12 * S + 16) * 8; }
+int64_t usc_ncut_fiedler_ws_bytes(int64_t S) { return (2 * S * S + 20 * S + 32) * 8; }
 
 int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double eps, double* evec, double* eval,
                      void* ws, int64_t ws_bytes, usc_stream_t s) {
@@ -463,13 +785,16 @@ int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double e
   t.p = t.tau + S;
   double* z = t.p + S;
   double* work = z + S;   // 5 S
+  double* work_tail = work + 5 * S;   // offset 2S^2 + 10S doubles: 16-byte aligned; 8S + 2 doubles: tagged p / row slots + error word
   hipLaunchKernelGGL(ncut_laplacian_kernel, dim3(stream_grid(S * S, 256)), dim3(256), 0, st, Abin, deg, S, eps, t.C);
-  for (int64_t i = 0; i + 1 < S; ++i) {
-    const int64_t m = S - i - 1;
-    hipLaunchKernelGGL(tri_reflect_symv_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(256), (size_t)S * sizeof(double), st, t, i);
-    hipLaunchKernelGGL(tri_update_kernel, dim3(stream_grid(m * m, 256)), dim3(256), 0, st, t, i);
+  if (!launch_persistent(t, work_tail, st)) {
+    for (int64_t i = 0; i + 1 < S; ++i) {
+      const int64_t m = S - i - 1;
+      hipLaunchKernelGGL(tri_reflect_symv_kernel, dim3((unsigned)ceil_div(m, 4)), dim3(256), (size_t)S * sizeof(double), st, t, i);
+      hipLaunchKernelGGL(tri_update_kernel, dim3(stream_grid(m * m, 256)), dim3(256), 0, st, t, i);
+    }
+    hipLaunchKernelGGL(tri_last_diag_kernel, dim3(1), dim3(64), 0, st, t);
   }
-  hipLaunchKernelGGL(tri_last_diag_kernel, dim3(1), dim3(64), 0, st, t);
   if (S <= kEigLdsMax)
     hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(64), (size_t)S * 8 * sizeof(double), st, (const double*)t.d,
                        (const double*)t.e, S, 1, eval, z, work);
