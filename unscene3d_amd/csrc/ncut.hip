@@ -561,12 +561,13 @@ __device__ inline int sturm_count(const double* d, const double* e, int64_t n, d
 // 12 ms solve from global memory.
 constexpr int64_t kEigLdsMax = 1000;
 template <int LDS>
-__global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ d_g, const double* __restrict__ e_g, int64_t n,
+__global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__ d_g, const double* __restrict__ e_g, int64_t n,
                                                     int k, double* __restrict__ eval_out /*[2]*/,
                                                     double* __restrict__ z_g /*[n]*/, double* __restrict__ work_g /*[5n]*/) {
   extern __shared__ double eig_sh[];   // LDS: d[n] e[n] z[n] work[5n]
-  const int lane = threadIdx.x;
-  __shared__ double s_lam[2];
+  // two waves: wave 0 bisects eigenvalue #k and goes straight on to its eigenvector, wave 1 bisects #k+1 (only
+  // reported) at the same time — the two bisections are independent chains of 14 x n dependent divisions
+  const int lane = threadIdx.x & 63, which = threadIdx.x >> 6;
   const double* d = d_g;
   const double* e = e_g;
   double* z = z_g;
@@ -574,7 +575,7 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
   if (LDS) {
     double* dl_ = eig_sh;
     double* el_ = eig_sh + n;
-    for (int64_t j = lane; j < n; j += 64) { dl_[j] = d_g[j]; el_[j] = j < n - 1 ? e_g[j] : 0.0; }
+    for (int64_t j = threadIdx.x; j < n; j += 128) { dl_[j] = d_g[j]; el_[j] = j < n - 1 ? e_g[j] : 0.0; }
     __syncthreads();
     d = dl_; e = el_; z = eig_sh + 2 * n; work = eig_sh + 3 * n;
   }
@@ -586,7 +587,8 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
     hi = fmax(hi, d[j] + r);
   }
   for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o, 64)); hi = fmax(hi, __shfl_xor(hi, o, 64)); }
-  for (int which = 0; which < 2; ++which) {
+  double lam;
+  {
     double a = lo - 1e-12 - 1e-12 * fabs(lo), b = hi + 1e-12 + 1e-12 * fabs(hi);
     const int target = k + which;   // eigenvalue index (0-based): smallest x with count(x) > target
     for (int round = 0; round < 14; ++round) {
@@ -598,16 +600,19 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
       const double nb = first == 64 ? b : a + (b - a) * (double)(first + 1) / 65.0;
       a = na; b = nb;
     }
-    if (lane == 0) s_lam[which] = 0.5 * (a + b);
-    __syncthreads();
+    lam = 0.5 * (a + b);
   }
-  if (lane != 0) return;
-  eval_out[0] = s_lam[0];
-  eval_out[1] = s_lam[1];
-  // ---- inverse iteration (single lane; n is a few thousand at most)
-  const double lam = s_lam[0];
+  if (lane == 0) eval_out[which] = lam;
+  if (which != 0) return;
+  // ---- inverse iteration on wave 0.  The LU sweep, the two substitutions and the norm are recurrences (lane 0);
+  // everything element-wise (set-up, the 1/norm scaling with its n divisions per iteration, sign, copy-out) is spread
+  // over the 64 lanes with the same per-element arithmetic.  Lane 0's LDS/global writes are ordered against the other
+  // lanes' later reads by program order within the wave plus the waits below.
+#define USC_WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
   double tnorm = 0.0;
-  for (int64_t j = 0; j < n; ++j) tnorm = fmax(tnorm, fabs(d[j]) + (j > 0 ? fabs(e[j - 1]) : 0.0) + (j < n - 1 ? fabs(e[j]) : 0.0));
+  for (int64_t j = lane; j < n; j += 64)
+    tnorm = fmax(tnorm, fabs(d[j]) + (j > 0 ? fabs(e[j - 1]) : 0.0) + (j < n - 1 ? fabs(e[j]) : 0.0));
+  for (int o = 32; o > 0; o >>= 1) tnorm = fmax(tnorm, __shfl_xor(tnorm, o, 64));
   const double shift = lam;
   double* dl = work;            // sub-diagonal multipliers
   double* dd = work + n;        // U diagonal
@@ -616,50 +621,66 @@ __global__ __launch_bounds__(64) void tri_eig_kernel(const double* __restrict__ 
   double* piv = work + 4 * n;   // 1.0 if rows were swapped
   // LU with partial pivoting of T - shift*I
   const double tiny = 2.3e-16 * fmax(tnorm, 1e-300);
-  for (int64_t j = 0; j < n; ++j) { dd[j] = d[j] - shift; du[j] = (j < n - 1) ? e[j] : 0.0; du2[j] = 0.0; }
-  for (int64_t j = 0; j < n - 1; ++j) {
-    const double sub = e[j];
-    if (fabs(dd[j]) >= fabs(sub)) {
-      if (fabs(dd[j]) < tiny) dd[j] = tiny;
-      const double mlt = sub / dd[j];
-      dl[j] = mlt; piv[j] = 0.0;
-      dd[j + 1] -= mlt * du[j];
-    } else {
-      const double mlt = dd[j] / sub;
-      dl[j] = mlt; piv[j] = 1.0;
-      const double t1 = dd[j + 1];
-      dd[j] = sub;
-      dd[j + 1] = du[j] - mlt * t1;
-      du[j] = t1;
-      if (j < n - 2) { du2[j] = du[j + 1]; du[j + 1] = -mlt * du2[j]; }
+  for (int64_t j = lane; j < n; j += 64) { dd[j] = d[j] - shift; du[j] = (j < n - 1) ? e[j] : 0.0; du2[j] = 0.0; }
+  USC_WAVE_SYNC();
+  if (lane == 0) {
+    for (int64_t j = 0; j < n - 1; ++j) {
+      const double sub = e[j];
+      if (fabs(dd[j]) >= fabs(sub)) {
+        if (fabs(dd[j]) < tiny) dd[j] = tiny;
+        const double mlt = sub / dd[j];
+        dl[j] = mlt; piv[j] = 0.0;
+        dd[j + 1] -= mlt * du[j];
+      } else {
+        const double mlt = dd[j] / sub;
+        dl[j] = mlt; piv[j] = 1.0;
+        const double t1 = dd[j + 1];
+        dd[j] = sub;
+        dd[j + 1] = du[j] - mlt * t1;
+        du[j] = t1;
+        if (j < n - 2) { du2[j] = du[j + 1]; du[j + 1] = -mlt * du2[j]; }
+      }
     }
-  }
-  if (fabs(dd[n - 1]) < tiny) dd[n - 1] = tiny;
-  // start vector: fixed pseudo-random in (-1,1)
-  unsigned long long st = 0x9E3779B97F4A7C15ull;
-  for (int64_t j = 0; j < n; ++j) {
-    st = st * 6364136223846793005ull + 1442695040888963407ull;
-    z[j] = ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+    if (fabs(dd[n - 1]) < tiny) dd[n - 1] = tiny;
+    // start vector: fixed pseudo-random in (-1,1)
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    for (int64_t j = 0; j < n; ++j) {
+      st = st * 6364136223846793005ull + 1442695040888963407ull;
+      z[j] = ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+    }
   }
   for (int it = 0; it < 6; ++it) {
-    // forward: apply L^-1 with the recorded row swaps
-    for (int64_t j = 0; j < n - 1; ++j) {
-      if (piv[j] != 0.0) { const double tmp = z[j]; z[j] = z[j + 1]; z[j + 1] = tmp - dl[j] * z[j]; }
-      else z[j + 1] -= dl[j] * z[j];
+    double nrm = 0.0;
+    if (lane == 0) {
+      // forward: apply L^-1 with the recorded row swaps
+      for (int64_t j = 0; j < n - 1; ++j) {
+        if (piv[j] != 0.0) { const double tmp = z[j]; z[j] = z[j + 1]; z[j + 1] = tmp - dl[j] * z[j]; }
+        else z[j + 1] -= dl[j] * z[j];
+      }
+      // backward: U x = z
+      z[n - 1] /= dd[n - 1];
+      if (n > 1) z[n - 2] = (z[n - 2] - du[n - 2] * z[n - 1]) / dd[n - 2];
+      for (int64_t j = n - 3; j >= 0; --j) z[j] = (z[j] - du[j] * z[j + 1] - du2[j] * z[j + 2]) / dd[j];
+      for (int64_t j = 0; j < n; ++j) nrm += z[j] * z[j];
+      nrm = sqrt(nrm);
     }
-    // backward: U x = z
-    z[n - 1] /= dd[n - 1];
-    if (n > 1) z[n - 2] = (z[n - 2] - du[n - 2] * z[n - 1]) / dd[n - 2];
-    for (int64_t j = n - 3; j >= 0; --j) z[j] = (z[j] - du[j] * z[j + 1] - du2[j] * z[j + 2]) / dd[j];
-    double nrm = 0.0, big = 0.0;
-    for (int64_t j = 0; j < n; ++j) { nrm += z[j] * z[j]; big = fmax(big, fabs(z[j])); }
-    nrm = sqrt(nrm);
-    for (int64_t j = 0; j < n; ++j) z[j] /= nrm;
+    nrm = __shfl(nrm, 0, 64);
+    USC_WAVE_SYNC();
+    for (int64_t j = lane; j < n; j += 64) z[j] /= nrm;
+    USC_WAVE_SYNC();
   }
-  int64_t jmax = 0;
-  for (int64_t j = 1; j < n; ++j) if (fabs(z[j]) > fabs(z[jmax])) jmax = j;
-  if (z[jmax] < 0.0) for (int64_t j = 0; j < n; ++j) z[j] = -z[j];
-  if (LDS) for (int64_t j = 0; j < n; ++j) z_g[j] = z[j];
+  int flip = 0;
+  if (lane == 0) {
+    int64_t jmax = 0;
+    for (int64_t j = 1; j < n; ++j) if (fabs(z[j]) > fabs(z[jmax])) jmax = j;
+    flip = z[jmax] < 0.0;
+  }
+  flip = __shfl(flip, 0, 64);
+  for (int64_t j = lane; j < n; j += 64) {
+    const double zj = flip ? -z[j] : z[j];
+    if (LDS) z_g[j] = zj; else z[j] = zj;
+  }
+#undef USC_WAVE_SYNC
 }
 
 // y = H(0) H(1) ... H(n-2) z, then x = y / sqrt(deg)
@@ -796,10 +817,10 @@ int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double e
     hipLaunchKernelGGL(tri_last_diag_kernel, dim3(1), dim3(64), 0, st, t);
   }
   if (S <= kEigLdsMax)
-    hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(64), (size_t)S * 8 * sizeof(double), st, (const double*)t.d,
+    hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(128), (size_t)S * 8 * sizeof(double), st, (const double*)t.d,
                        (const double*)t.e, S, 1, eval, z, work);
   else
-    hipLaunchKernelGGL(tri_eig_kernel<0>, dim3(1), dim3(64), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
+    hipLaunchKernelGGL(tri_eig_kernel<0>, dim3(1), dim3(128), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
   hipLaunchKernelGGL(tri_backtransform_kernel, dim3(1), dim3(1024), 0, st, t, deg, z, evec);
   USC_CHECK_LAUNCH("usc_ncut_fiedler");
   return USC_OK;
