@@ -647,6 +647,36 @@ def test_config5_ncut_irregular_scene_product_path(device):
         assert (m & r).sum() / max((m | r).sum(), 1) >= 0.99
 
 
+@pytest.mark.parametrize("side", [9, 26, 46])
+def test_tridiagonalisation_one_launch_equals_stepwise(device, side, tmp_path):
+    """S = 81 (workgroup count capped by n), 676 (rows in LDS) and 2116 (rows in global memory): the persistent
+    tridiagonalisation and the stepwise one (USC3D_TRI_STEPWISE=1, also the path for n > 4000) must give the
+    same eigenpair bit for bit — same summation trees — and it must be the generalized eigenvector #2 scipy finds."""
+    import os
+    import subprocess
+    import sys
+
+    import scipy.linalg
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for mode in ("0", "1"):
+        out = str(tmp_path / f"fiedler_{mode}.npz")
+        env = dict(os.environ, USC3D_TRI_STEPWISE=mode)
+        subprocess.run([sys.executable, os.path.join(root, "tools", "fiedler_dump.py"), str(side), out], check=True,
+                       env=env, timeout=300)
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.isfinite(a["vec"]).all()
+    assert np.array_equal(a["vec"], b["vec"])
+    A = np.where(a["A"] > 0, 1.0, 1e-5)
+    L, Dm = np.diag(a["D"]) - A, np.diag(a["D"])
+    w, v = scipy.linalg.eigh(L, Dm, subset_by_index=[1, 1])
+    x = a["vec"]
+    np.testing.assert_allclose((x @ L @ x) / (x @ Dm @ x), w[0], rtol=1e-8)
+    assert abs(float(x @ (a["D"] * v[:, 0]))) / np.sqrt(float(x @ (a["D"] * x))) > 1 - 1e-6
+
+
 @pytest.mark.parametrize("rows,d", [(100, 128), (1, 64), (2500, 256), (37, 384)])
 def test_layernorm_matches_torch(device, rows, d):
     """usc_layernorm_fwd/bwd vs F.layer_norm in float64 on the CPU (the reference's nn.LayerNorm)."""

@@ -160,6 +160,20 @@ __global__ __launch_bounds__(256) void ncut_laplacian_kernel(const uint8_t* __re
 // ---------------------------------------------------------------------------
 // Householder tridiagonalisation, LAPACK dsytd2 uplo='L' conventions.
 // step i:  (1) reflector from column i  (2) p = C22 v  (3) C22 -= v w^T + w v^T, w = tau p - (tau^2/2)(p.v) v
+// The two tridiagonalisation paths must round alike, and C must stay exactly symmetric (the stepwise path reads
+// column i where the one-launch path reads row i): the rank-2 update is written once, both products rounded before
+// they are added — v_r w_c + w_r v_c then commutes bit for bit, which a fused multiply-add would break.
+__device__ __forceinline__ double tri_w(double tau, double p, double a2, double v) {
+  const double t = a2 * v;
+  return __builtin_fma(tau, p, t);
+}
+__device__ __forceinline__ double tri_update(double x, double vr, double wc, double wr, double vc) {
+  const double t1 = vr * wc;
+  const double t2 = wr * vc;
+  const double u = t1 + t2;
+  return x - u;
+}
+
 struct TriState {
   double* C;      // [n][n] symmetric working matrix
   double* Vt;     // [n][n] row i = reflector i (v[i+1] = 1, zeros above)
@@ -250,8 +264,8 @@ __global__ __launch_bounds__(256) void tri_update_kernel(TriState t, int64_t i) 
   const int64_t total = m * m;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
     const int64_t r = i + 1 + q / m, c = i + 1 + q % m;
-    const double wr = tau * t.p[r] + a2 * v[r], wc = tau * t.p[c] + a2 * v[c];
-    t.C[r * n + c] -= v[r] * wc + wr * v[c];
+    const double wr = tri_w(tau, t.p[r], a2, v[r]), wc = tri_w(tau, t.p[c], a2, v[c]);
+    t.C[r * n + c] = tri_update(t.C[r * n + c], v[r], wc, wr, v[c]);
   }
 }
 // ---------------------------------------------------------------------------
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
     __syncthreads();
     dot = red[16] + red[17] + red[18] + red[19];
     const double a2 = -0.5 * tau * (tau * dot);
-    for (int64_t c = i + 1 + tid; c < n; c += 256) w[c] = tau * p[c] + a2 * v[c];
+    for (int64_t c = i + 1 + tid; c < n; c += 256) w[c] = tri_w(tau, p[c], a2, v[c]);
     __syncthreads();
     if (tau != 0.0) {
       for (int q = tid >> 4; q < R; q += 16) {
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) {
             const int64_t c = c0 + 16 * m;
-            if (c < n) row[c] = x[m] - (vr * wc[m] + wr * vc[m]);
+            if (c < n) row[c] = tri_update(x[m], vr, wc[m], wr, vc[m]);
           }
         }
       }
@@ -522,7 +536,7 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
       const double vr = v[i + 1], wr = w[i + 1];
       for (int64_t c = i + 1 + tid; c < n; c += 256) {
         double x = piv[c];
-        if (tau != 0.0) x -= vr * w[c] + wr * v[c];
+        if (tau != 0.0) x = tri_update(x, vr, w[c], wr, v[c]);
         piv[c] = x;
       }
     }
