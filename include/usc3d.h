@@ -481,8 +481,16 @@ int usc_project_planes_bwd(const int32_t* coords, int64_t V, int32_t inst,
  *       the per-batch minimum coordinate (grid voxel + shift = map coordinate).
  * _dense: occupancy i64[B,dim_z,dim_y,dim_x] exactly as the reference builds it (0 = empty).
  * ---------------------------------------------------------------------- */
+/* Optional free-space filter of the _map ray cast: one bit per 8x8x8-voxel brick of the (shifted) grid,
+ * set where a voxel row > 0 lives; mask u32[B, ceil(bricks_x*bricks_y*bricks_z / 32)] (zeroed here),
+ * brick index = (gz*bricks_y + gy)*bricks_x + gx.  coords i32[n,4] are the map's coordinates. */
+int usc_brick_mask_build(const int32_t* coords, int64_t n, const int32_t* shift, int32_t B,
+                         int32_t bricks_x, int32_t bricks_y, int32_t bricks_z,
+                         uint32_t* mask, usc_stream_t s);
 int usc_raycast_first_hit_map(const uint64_t* table_keys, const int32_t* table_vals,
                               int64_t cap, int64_t n_rows, const int32_t* shift,
+                              const uint32_t* brick_mask /* may be NULL */, int32_t bricks_x,
+                              int32_t bricks_y, int32_t bricks_z,
                               const float* views, const float* intrinsics,
                               int32_t B, int32_t V, int32_t H, int32_t W,
                               float depth_min, float depth_max, float ray_increment,

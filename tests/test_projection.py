@@ -129,6 +129,10 @@ def test_first_hit_hash_and_dense_match_oracle(device, batch, n_views, W, H):
     hit_h, seg_h = P.raycast_first_hit_map(cmap, _dev(shifts.astype(np.int32), device), _dev(views, device),
                                            _dev(intr, device), H, W, DMIN, DMAX, INC)
     assert np.array_equal(hit_h.cpu().numpy(), ref)
+    sh_d = _dev(shifts.astype(np.int32), device)
+    hit_b, _ = P.raycast_first_hit_map(cmap, sh_d, _dev(views, device), _dev(intr, device), H, W, DMIN, DMAX, INC,
+                                       bricks=P.brick_mask(cmap, sh_d))       # free-space filter: same hits
+    assert np.array_equal(hit_b.cpu().numpy(), ref)
     exp_seg = np.where(ref.reshape(-1) >= 0, ref.reshape(-1), n).astype(np.int64)
     assert np.array_equal(seg_d.cpu().numpy(), exp_seg) and np.array_equal(seg_h.cpu().numpy(), exp_seg)
 
@@ -238,6 +242,10 @@ def test_full_size_frame_properties(device):
     hit_d, _ = P.raycast_first_hit_dense(_dev(occ, device), _dev(views, device), _dev(intr, device), H, W, dmin, dmax,
                                          INC, n)
     assert torch.equal(hit_h, hit_d)
+    sh_d = _dev(shifts.astype(np.int32), device)
+    hit_b, _ = P.raycast_first_hit_map(cmap, sh_d, _dev(views, device), _dev(intr, device), H, W, dmin, dmax, INC,
+                                       bricks=P.brick_mask(cmap, sh_d))
+    assert torch.equal(hit_b, hit_d)
     hit = hit_h.cpu().numpy()[0, 0]
     assert (hit >= 0).mean() > 0.9
 

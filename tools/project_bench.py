@@ -51,7 +51,7 @@ def main():
     feats = torch.randn((1, 1, H, W, C), device=dev)
     scene = torch.zeros((n, C), device=dev)
 
-    cmap, shift = proj._scene_state(c_d)
+    cmap, shift, bricks = proj._scene_state(c_d)
     lv = v_d.clone()
     lv[:, :, :3, 3] -= shift.float()[:, None, :]
     out = {"voxels": n, "rays": H * W, "channels": C}
@@ -61,8 +61,11 @@ def main():
         i = fr[0] % a.frames
         fr[0] += 1
         return P.raycast_first_hit_map(cmap, shift, lv[:, i:i + 1], k_d, H, W, proj.depth_min, proj.depth_max,
-                                       proj.ray_increment)
+                                       proj.ray_increment, bricks=use_bricks[0])
 
+    use_bricks = [None]
+    out["raycast_no_brick_mask_ms"] = _time(cast, a.frames)
+    use_bricks[0] = bricks
     out["raycast_ms"] = _time(cast, a.frames)
     hit, seg = cast()
     out["hit_fraction"] = float((hit >= 0).float().mean())

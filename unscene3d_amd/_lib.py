@@ -72,8 +72,9 @@ SIGNATURES = {
     "usc_cc_eps_finish": (C.c_int, [_p, _i64, _p, _p, _p]),
     "usc_project_planes_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _i32] + [_p] * 10),
     "usc_project_planes_bwd": (C.c_int, [_p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
-    "usc_raycast_first_hit_map": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _p,
-                                            _p, _p]),
+    "usc_brick_mask_build": (C.c_int, [_p, _i64, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "usc_raycast_first_hit_map": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _i32, _i32, _i32, _i32,
+                                            _f32, _f32, _f32, _p, _p, _p]),
     "usc_raycast_first_hit_dense": (C.c_int, [_p, _i32, _i32, _i32, _i64, _p, _p, _i32, _i32, _i32, _i32, _f32, _f32,
                                               _f32, _p, _p, _p]),
     "usc_project_reduce": (C.c_int, [_p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),

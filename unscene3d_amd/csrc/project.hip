@@ -68,13 +68,36 @@ struct HashOcc {
   const int32_t* vals;
   int64_t cap;
   const int32_t* shift;   // i32[B,3]: local voxel (0-based) + shift = map coordinate
+  // optional occupancy of 8^3-voxel bricks (one bit each, rows 1.. only): a ray spends most of its voxels in free
+  // space, where one bit from a KB-sized, cache-resident mask replaces a probe into the MB-sized hash table
+  const uint32_t* bricks;
+  int bx, by, bz, brick_words;
   __device__ int operator()(int b, const Vox& v) const {
+    if (v.x < 0 || v.y < 0 || v.z < 0) return 0;
+    if (bricks) {
+      const int gx = v.x >> 3, gy = v.y >> 3, gz = v.z >> 3;
+      if (gx >= bx || gy >= by || gz >= bz) return 0;
+      const int idx = (gz * by + gy) * bx + gx;
+      if (!((bricks[(int64_t)b * brick_words + (idx >> 5)] >> (idx & 31)) & 1u)) return 0;
+    }
     const int x = v.x + shift[b * 3 + 0], y = v.y + shift[b * 3 + 1], z = v.z + shift[b * 3 + 2];
-    if (v.x < 0 || v.y < 0 || v.z < 0 || !coord_in_range(b, x, y, z)) return 0;
+    if (!coord_in_range(b, x, y, z)) return 0;
     const int row = table_lookup(keys, vals, cap, pack_key(b, x, y, z));
     return row > 0 ? row : 0;   // row 0 reads as "empty" in the reference's occupancy grid
   }
 };
+__global__ __launch_bounds__(256) void brick_mask_kernel(const int32_t* __restrict__ coords, int64_t n,
+                                                        const int32_t* __restrict__ shift, int bx, int by, int bz,
+                                                        int brick_words, uint32_t* __restrict__ mask) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || i == 0) return;   // row 0 never hits
+  const int b = coords[i * 4];
+  const int gx = (coords[i * 4 + 1] - shift[b * 3 + 0]) >> 3, gy = (coords[i * 4 + 2] - shift[b * 3 + 1]) >> 3,
+            gz = (coords[i * 4 + 3] - shift[b * 3 + 2]) >> 3;
+  if (gx < 0 || gy < 0 || gz < 0 || gx >= bx || gy >= by || gz >= bz) return;
+  const int idx = (gz * by + gy) * bx + gx;
+  atomicOr(&mask[(int64_t)b * brick_words + (idx >> 5)], 1u << (idx & 31));
+}
 struct DenseOcc {
   const int64_t* occ;
   int dz, dy, dx;
@@ -131,6 +154,17 @@ __global__ __launch_bounds__(64) void raycast_first_hit_kernel(Occ occ, const fl
   const int64_t p = ((int64_t)bv * H + y) * W + x;
   hit[p] = found != 0 ? found : -1;
   if (seg) seg[p] = found != 0 ? (int64_t)found : n_rows;   // misses go to the extra segment n_rows
+}
+
+template <class Occ>
+static int launch_raycast(const char* name, Occ occ, const float* views, const float* intrinsics, int B, int V, int H,
+                          int W, float dmin, float dmax, float inc, int32_t* hit, int64_t* seg, int64_t n_rows,
+                          hipStream_t st) {
+  dim3 grid((W + 7) / 8, (H + 7) / 8, B * V);
+  hipLaunchKernelGGL(raycast_first_hit_kernel<Occ>, grid, dim3(64), 0, st, occ, views, intrinsics, V, H, W, dmin, dmax,
+                     inc, hit, seg, n_rows);
+  USC_CHECK_LAUNCH(name);
+  return 0;
 }
 
 // One wave per voxel row; lanes stride over the channels, pixels of the row are added in CSR order.
@@ -230,18 +264,31 @@ using namespace usc;
 
 extern "C" {
 
+int usc_brick_mask_build(const int32_t* coords, int64_t n, const int32_t* shift, int32_t B, int32_t bricks_x,
+                         int32_t bricks_y, int32_t bricks_z, uint32_t* mask, usc_stream_t s) {
+  USC_REQUIRE(B > 0 && bricks_x > 0 && bricks_y > 0 && bricks_z > 0, "usc_brick_mask_build: empty brick grid");
+  const int64_t words = ceil_div((int64_t)bricks_x * bricks_y * bricks_z, 32);
+  USC_REQUIRE(words < (1 << 26), "usc_brick_mask_build: brick grid too large");
+  (void)hipMemsetAsync(mask, 0, (size_t)B * words * 4, as_stream(s));
+  if (n > 0)
+    hipLaunchKernelGGL(brick_mask_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), coords, n, shift,
+                       bricks_x, bricks_y, bricks_z, (int)words, mask);
+  USC_CHECK_LAUNCH("usc_brick_mask_build");
+  return 0;
+}
+
 int usc_raycast_first_hit_map(const uint64_t* table_keys, const int32_t* table_vals, int64_t cap, int64_t n_rows,
-                              const int32_t* shift, const float* views, const float* intrinsics, int32_t B, int32_t V,
+                              const int32_t* shift, const uint32_t* brick_mask, int32_t bricks_x, int32_t bricks_y,
+                              int32_t bricks_z, const float* views, const float* intrinsics, int32_t B, int32_t V,
                               int32_t H, int32_t W, float depth_min, float depth_max, float ray_increment,
                               int32_t* hit, int64_t* seg, usc_stream_t s) {
   if (int rc = check_rays("usc_raycast_first_hit_map", B, V, H, W, depth_min, depth_max, ray_increment)) return rc;
   USC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "usc_raycast_first_hit_map: capacity must be a power of two");
-  HashOcc occ{table_keys, table_vals, cap, shift};
-  dim3 grid((W + 7) / 8, (H + 7) / 8, B * V);
-  hipLaunchKernelGGL(raycast_first_hit_kernel<HashOcc>, grid, dim3(64), 0, as_stream(s), occ, views, intrinsics, V, H, W,
-                     depth_min, depth_max, ray_increment, hit, seg, n_rows);
-  USC_CHECK_LAUNCH("usc_raycast_first_hit_map");
-  return 0;
+  USC_REQUIRE(!brick_mask || (bricks_x > 0 && bricks_y > 0 && bricks_z > 0), "usc_raycast_first_hit_map: brick grid");
+  HashOcc occ{table_keys, table_vals, cap, shift, brick_mask, bricks_x, bricks_y, bricks_z,
+              brick_mask ? (int)ceil_div((int64_t)bricks_x * bricks_y * bricks_z, 32) : 0};
+  return launch_raycast("usc_raycast_first_hit_map", occ, views, intrinsics, B, V, H, W, depth_min, depth_max,
+                        ray_increment, hit, seg, n_rows, as_stream(s));
 }
 
 int usc_raycast_first_hit_dense(const int64_t* occupancy, int32_t dim_z, int32_t dim_y, int32_t dim_x, int64_t n_rows,
@@ -251,11 +298,8 @@ int usc_raycast_first_hit_dense(const int64_t* occupancy, int32_t dim_z, int32_t
   if (int rc = check_rays("usc_raycast_first_hit_dense", B, V, H, W, depth_min, depth_max, ray_increment)) return rc;
   USC_REQUIRE(dim_z > 0 && dim_y > 0 && dim_x > 0, "usc_raycast_first_hit_dense: empty occupancy grid");
   DenseOcc occ{occupancy, dim_z, dim_y, dim_x};
-  dim3 grid((W + 7) / 8, (H + 7) / 8, B * V);
-  hipLaunchKernelGGL(raycast_first_hit_kernel<DenseOcc>, grid, dim3(64), 0, as_stream(s), occ, views, intrinsics, V, H,
-                     W, depth_min, depth_max, ray_increment, hit, seg, n_rows);
-  USC_CHECK_LAUNCH("usc_raycast_first_hit_dense");
-  return 0;
+  return launch_raycast("usc_raycast_first_hit_dense", occ, views, intrinsics, B, V, H, W, depth_min, depth_max,
+                        ray_increment, hit, seg, n_rows, as_stream(s));
 }
 
 int usc_project_reduce(const float* feats, int32_t c, const int64_t* order, const int64_t* seg_off, int64_t n_rows,

@@ -44,9 +44,23 @@ def raycast_first_hit_dense(occupancy_3d, views, intrinsics, height, width, dept
     return hit, seg
 
 
+def brick_mask(cmap: ops.CoordMap, shift):
+    """Free-space filter for the ray cast: (mask u32[B, words], (bricks_x, bricks_y, bricks_z)) — one bit per
+    8^3-voxel brick of the shifted grid that holds a voxel.  Build once per scene."""
+    B = shift.shape[0]
+    ext = (cmap.coords[:, 1:].amax(0) - shift.amin(0) + 1).tolist()
+    bricks = tuple((int(e) + 7) // 8 for e in ext)
+    words = (bricks[0] * bricks[1] * bricks[2] + 31) // 32
+    mask = torch.empty((B, words), dtype=torch.int32, device=cmap.coords.device)
+    check(lib.usc_brick_mask_build(_ptr(cmap.coords), cmap.n, _ptr(shift), B, *bricks, _ptr(mask), _stream()),
+          "usc_brick_mask_build")
+    return mask, bricks
+
+
 def raycast_first_hit_map(cmap: ops.CoordMap, shift, views, intrinsics, height, width, depth_min, depth_max,
-                          ray_increment, want_seg=True):
-    """cmap: stride-1 coordinate map; shift i32[B,3] per-batch minimum coordinate; views already shifted."""
+                          ray_increment, want_seg=True, bricks=None):
+    """cmap: stride-1 coordinate map; shift i32[B,3] per-batch minimum coordinate; views already shifted;
+    bricks: optional result of `brick_mask` (same hits, fewer hash probes)."""
     ops.require_device()
     _chk(shift, torch.int32, "shift")
     B, V = views.shape[0], views.shape[1]
@@ -56,7 +70,9 @@ def raycast_first_hit_map(cmap: ops.CoordMap, shift, views, intrinsics, height, 
     dev = cmap.coords.device
     hit = torch.empty((B, V, height, width), dtype=torch.int32, device=dev)
     seg = torch.empty(B * V * height * width, dtype=torch.int64, device=dev) if want_seg else None
+    bm, bd = bricks if bricks is not None else (None, (0, 0, 0))
     check(lib.usc_raycast_first_hit_map(_ptr(cmap.table_keys), _ptr(cmap.table_vals), cmap.cap, cmap.n, _ptr(shift),
+                                        _ptr(bm) if bm is not None else None, bd[0], bd[1], bd[2],
                                         _ptr(views), _ptr(intrinsics), B, V, height, width, depth_min, depth_max,
                                         ray_increment, _ptr(hit), _ptr(seg) if want_seg else None, _stream()),
           "usc_raycast_first_hit_map")
@@ -142,15 +158,16 @@ class Project2DFeaturesCUDA(nn.Module):
         (the caller projects 100-300 frames onto one scene)."""
         key = (coords.data_ptr(), tuple(coords.shape), coords._version)
         if self._scene is not None and self._scene[0] == key:
-            return self._scene[1:]
+            return self._scene[1:4]
         c32 = coords.to(torch.int32).contiguous()
         batch_size = int(c32[-1, 0].item()) + 1
         shift = torch.stack([c32[c32[:, 0] == b, 1:].amin(0) for b in range(batch_size)]).contiguous()
         cmap, _, _ = ops.coordmap_build(c32)
         if cmap.n != c32.shape[0]:
             raise RuntimeError("Project2DFeaturesCUDA: duplicate voxel coordinates")
-        self._scene = (key, cmap, shift)
-        return cmap, shift
+        bricks = brick_mask(cmap, shift)
+        self._scene = (key, cmap, shift, bricks, coords)   # holding `coords` keeps its address from being reused
+        return cmap, shift, bricks
 
     def _cast(self, encoded_2d_features, coords, view_matrix, intrinsic_params, want_seg):
         if not coords.is_cuda:
@@ -159,11 +176,11 @@ class Project2DFeaturesCUDA(nn.Module):
         if (H, W) != (self.image_height, self.image_width):
             raise RuntimeError(f"features are {H}x{W}, the projecter was built for "
                                f"{self.image_height}x{self.image_width}")
-        cmap, shift = self._scene_state(coords)
+        cmap, shift, bricks = self._scene_state(coords)
         local_views = view_matrix.detach().to(torch.float32).clone()
         local_views[:, :, :3, 3] -= shift.to(torch.float32)[:, None, :]
         hit, seg = raycast_first_hit_map(cmap, shift, local_views, intrinsic_params, H, W, self.depth_min,
-                                         self.depth_max, self.ray_increment, want_seg=want_seg)
+                                         self.depth_max, self.ray_increment, want_seg=want_seg, bricks=bricks)
         return cmap.n, hit, seg
 
     def forward(self, encoded_2d_features, coords, view_matrix, intrinsic_params, pred_mode=False):
