@@ -89,6 +89,24 @@ def test_export_host_logic_matches_reference(name, monkeypatch):
     _check(results, scenes)
 
 
+@pytest.mark.parametrize("use_dbscan", [False, True])
+def test_export_with_no_instances(use_dbscan, monkeypatch):
+    """Every query mask empty: an empty result, not an exception (the reference's torch.stack raises)."""
+    from unscene3d_amd.trainer import postprocess as PP
+
+    _cpu_row_ops(monkeypatch)
+    rng = np.random.default_rng(0)
+    S, Q, N, NF = 20, 10, 200, 300
+    general = NS(use_dbscan=use_dbscan, dbscan_eps=0.95, topk_per_image=100, filter_out_instances=True,
+                 scores_threshold=0.1, iou_threshold=0.66)
+    output = {"aux_outputs": [], "pred_logits": torch.randn(1, Q, 3), "pred_masks": [torch.full((S, Q), -5.0)]}
+    low = [{"point2segment": torch.from_numpy(rng.integers(0, S, N))}]
+    full = [{"point2segment": torch.from_numpy(rng.integers(0, S, NF))}]
+    res = PP.export_instances(output, low, full, [rng.integers(0, N, NF)], rng.random((N, 3)), general, num_classes=3,
+                              full_res_coords=[rng.random((NF, 3)).astype(np.float32)])[0]
+    assert res["pred_masks"].shape == (NF, 0) and res["pred_scores"].shape == (0,) and res["pred_boxes"].shape == (0, 8)
+
+
 def test_save_for_freemask_format(tmp_path):
     from unscene3d_amd.trainer import postprocess as PP
 

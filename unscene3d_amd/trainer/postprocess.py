@@ -23,6 +23,8 @@ def dbscan_split(masks: torch.Tensor, logits: torch.Tensor, coords: torch.Tensor
         for cid in range(int(labels.max()) + 1):
             new_masks.append(masks[:, q] * (full == cid + 1))
             new_logits.append(logits[q])
+    if not new_masks:   # every query mask empty (the reference's torch.stack raises here): no instances
+        return masks.new_zeros((masks.shape[0], 0)), logits.new_zeros((0, logits.shape[1]))
     return torch.stack(new_masks).T, torch.stack(new_logits)
 
 
@@ -33,9 +35,11 @@ def dbscan_split(masks: torch.Tensor, logits: torch.Tensor, coords: torch.Tensor
 # overlap filter) run on the host exactly like the reference's CPU code, so ties break the same way.
 def get_mask_and_scores(mask_cls, mask_pred, num_queries=100, num_classes=18, topk_per_image=-1):
     """mask_cls [Q,C] class probabilities, mask_pred [N,Q] mask logits (device)
-    -> (score [k], result_pred_mask f32[N,k], classes i64[k], heatmap f32[N,k]); trainer.py:456-477."""
+    -> (score [k], result_pred_mask f32[N,k], classes i64[k], heatmap f32[N,k]); trainer.py:456-477.
+    k is clamped to the number of (query, class) candidates; the reference's topk raises when asked for more."""
     dev = mask_pred.device
     k = topk_per_image if topk_per_image != -1 else num_queries
+    k = min(k, mask_cls.shape[0] * mask_cls.shape[1])   # fewer candidates than asked for (e.g. after a DBSCAN split)
     labels = torch.arange(num_classes).unsqueeze(0).repeat(num_queries, 1).flatten(0, 1)
     scores_per_query, topk_indices = mask_cls.detach().cpu().flatten(0, 1).topk(k, sorted=True)
     classes = labels[topk_indices]
@@ -62,6 +66,8 @@ def get_full_res_mask(mask, inverse_map, segments_full=None, is_heatmap=False):
 def filter_instances(sorted_masks, sorted_scores, scores_threshold, iou_threshold):
     """Greedy overlap filter of trainer.py:586-607 on score-sorted binary masks f32[N,k] -> kept column indices.
     The k x k overlap counts are exact in fp32 (integers < 2^24) and the normalisation repeats numpy's fp32 ops."""
+    if sorted_masks.shape[1] == 0:
+        return []
     overlap = sorted_masks.T @ sorted_masks
     norm = overlap / (overlap.max(dim=0).values + 10e-8)
     over = (norm > iou_threshold).cpu().numpy()
