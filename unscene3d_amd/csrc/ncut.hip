@@ -343,8 +343,16 @@ __device__ inline double wave_sum_dpp(double x) {
   return __hiloint2double(hi, lo);
 }
 
-template <bool LDS_ROWS>
+// ROWS: where a workgroup keeps its rows of the working matrix.
+//   kRowsReg    registers: wave w holds the workgroup's rows q = w, w+4, ... (RW of them), lane e the columns e + 64 j
+//               (J of them) — symv and the rank-2 update then run on registers.  The stepwise kernel's lane e' sums the
+//               columns i+1+e' (mod 64), so lane e's partial sum belongs at tree position e - (i+1) mod 64: one
+//               ds_bpermute rotates it there (bit-reversed, see wave_sum_dpp) and the sums stay bit-identical.
+//   kRowsLds    LDS, 16 lanes per row (n too large for registers);  kRowsGlobal  global memory (too large for LDS).
+enum { kRowsReg = 0, kRowsLds = 1, kRowsGlobal = 2 };
+template <int ROWS, int J, int RW>
 __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
+  constexpr bool LDS_ROWS = ROWS == kRowsLds;
   extern __shared__ double lds[];
   __shared__ double red[20];
   __shared__ int s_abort;
@@ -367,6 +375,18 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
     for (int q = 0; q < R; ++q) {
       const int64_t r = g + (int64_t)q * G;
       if (r < n) for (int64_t c = tid; c < n; c += 256) rows_l[(int64_t)q * ld + c] = t.C[r * n + c];
+    }
+  }
+  double rowreg[RW][J];
+  if (ROWS == kRowsReg) {
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const int64_t r = g + (int64_t)(wave + 4 * k) * G;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int64_t c = lane + 64 * j;
+        rowreg[k][j] = (wave + 4 * k < R && r < n && c < n) ? t.C[r * n + c] : 0.0;
+      }
     }
   }
   for (int64_t c = tid; c < n; c += 256) piv[c] = t.C[c];   // row 0 == column 0
@@ -433,31 +453,72 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
     // slots of step i: p in [par*n, par*n + n), the published row in [(2 + par)*n, ...), par = i & 1
     const int pb_off = (int)((i & 1) * n) * 16, rb_off = (int)((2 + (i & 1)) * n) * 16;
     const uint64_t tag = (uint64_t)i + 1;
-    // 16 lanes per row, 16 rows per pass; a lane carries four of the stepwise kernel's 64 per-lane partial sums
-    // (positions frev + 16 m) and folds them in the butterfly's order before the 16-lane DPP tree
-    for (int q = tid >> 4; q < R; q += 16) {
-      const int64_t r = g + (int64_t)q * G;
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-      if (r > i && r < n) {
-        const double* row = row_ptr(q);
-        // the four chains advance together (each keeps its own ascending-c order)
-        for (int64_t c0 = i + 1 + frev; c0 < n; c0 += 64) {
+    if (ROWS == kRowsReg) {
+      double vreg[J], part[RW];
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const int64_t c = c0 + 16 * m;
-            if (c < n) acc[m] += row[c] * v[c];
-          }
+      for (int j = 0; j < J; ++j) { const int64_t c = lane + 64 * j; vreg[j] = (c > i && c < n) ? v[c] : 0.0; }
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        part[k] = 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          if (lane + 64 * j > i && lane + 64 * j < n) part[k] += rowreg[k][j] * vreg[j];
+      }
+      const int src = ((erev + (int)((i + 1) & 63)) & 63) * 4;   // lane that holds tree position bitrev6(lane)
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(part[k]));
+        const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(part[k]));
+        part[k] = wave_sum_dpp(__hiloint2double(hi, lo));
+      }
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        const int64_t r = g + (int64_t)(wave + 4 * k) * G;
+        if (lane == 0 && wave + 4 * k < R && r > i && r < n)
+          __builtin_amdgcn_raw_buffer_store_b128(slot_pack(part[k], tag), slots, pb_off + (int)r * 16, 0, kSc1);
+      }
+      if ((i + 1) % G == g) {
+        const int qo = (int)((i + 1) / G);
+        if ((qo & 3) == wave) {
+#pragma unroll
+          for (int k = 0; k < RW; ++k)
+            if (k == (qo >> 2)) {
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                const int64_t c = lane + 64 * j;
+                if (c > i && c < n)
+                  __builtin_amdgcn_raw_buffer_store_b128(slot_pack(rowreg[k][j], tag), slots, rb_off + (int)c * 16, 0, kSc1);
+              }
+            }
         }
       }
-      double sum = (acc[0] + acc[2]) + (acc[1] + acc[3]);
-      sum = row16_sum(sum);
-      if ((tid & 15) == 15 && r > i && r < n)
-        __builtin_amdgcn_raw_buffer_store_b128(slot_pack(sum, tag), slots, pb_off + (int)r * 16, 0, kSc1);
-    }
-    if ((i + 1) % G == g) {
-      const double* row = row_ptr((int)((i + 1) / G));
-      for (int64_t c = i + 1 + tid; c < n; c += 256)
-        __builtin_amdgcn_raw_buffer_store_b128(slot_pack(row[c], tag), slots, rb_off + (int)c * 16, 0, kSc1);
+    } else {
+      // 16 lanes per row, 16 rows per pass; a lane carries four of the stepwise kernel's 64 per-lane partial sums
+      // (positions frev + 16 m) and folds them in the butterfly's order before the 16-lane DPP tree
+      for (int q = tid >> 4; q < R; q += 16) {
+        const int64_t r = g + (int64_t)q * G;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        if (r > i && r < n) {
+          const double* row = row_ptr(q);
+          // the four chains advance together (each keeps its own ascending-c order)
+          for (int64_t c0 = i + 1 + frev; c0 < n; c0 += 64) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const int64_t c = c0 + 16 * m;
+              if (c < n) acc[m] += row[c] * v[c];
+            }
+          }
+        }
+        double sum = (acc[0] + acc[2]) + (acc[1] + acc[3]);
+        sum = row16_sum(sum);
+        if ((tid & 15) == 15 && r > i && r < n)
+          __builtin_amdgcn_raw_buffer_store_b128(slot_pack(sum, tag), slots, pb_off + (int)r * 16, 0, kSc1);
+      }
+      if ((i + 1) % G == g) {
+        const double* row = row_ptr((int)((i + 1) / G));
+        for (int64_t c = i + 1 + tid; c < n; c += 256)
+          __builtin_amdgcn_raw_buffer_store_b128(slot_pack(row[c], tag), slots, rb_off + (int)c * 16, 0, kSc1);
+      }
     }
     // ---- exchange: every thread waits for the tagged slots it needs (this is the grid barrier: nobody gets past
     // step i without everybody's p of step i).  No counter, no drain, no atomic; a slot is rewritten at step i+2, by
@@ -510,7 +571,25 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
     const double a2 = -0.5 * tau * (tau * dot);
     for (int64_t c = i + 1 + tid; c < n; c += 256) w[c] = tri_w(tau, p[c], a2, v[c]);
     __syncthreads();
-    if (tau != 0.0) {
+    if (tau != 0.0 && ROWS == kRowsReg) {
+      double vreg[J], wreg[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int64_t c = lane + 64 * j;
+        vreg[j] = (c > i && c < n) ? v[c] : 0.0;
+        wreg[j] = (c > i && c < n) ? w[c] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < RW; ++k) {
+        const int64_t r = g + (int64_t)(wave + 4 * k) * G;
+        if (wave + 4 * k < R && r > i && r < n) {
+          const double vr = v[r], wr = w[r];
+#pragma unroll
+          for (int j = 0; j < J; ++j)
+            if (lane + 64 * j > i && lane + 64 * j < n) rowreg[k][j] = tri_update(rowreg[k][j], vr, wreg[j], wr, vreg[j]);
+        }
+      }
+    } else if (tau != 0.0) {
       for (int q = tid >> 4; q < R; q += 16) {
         const int64_t r = g + (int64_t)q * G;
         if (r <= i || r >= n) continue;
@@ -548,7 +627,20 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
     printf("tri timing wg %d: reflector %lld  symv+publish %lld  exchange %lld  update %lld cycles (n=%d)\n", g, tA, tB, tC, tD, (int)n);
 #endif
   // d[n-1]: bottom-right entry after the last update; its owner holds it
-  if ((n - 1) % G == g && tid == 0) t.d[n - 1] = row_ptr((int)((n - 1) / G))[n - 1];
+  if ((n - 1) % G == g) {
+    const int qo = (int)((n - 1) / G);
+    if (ROWS == kRowsReg) {
+      if ((qo & 3) == wave && lane == (int)((n - 1) & 63)) {
+#pragma unroll
+        for (int k = 0; k < RW; ++k)
+#pragma unroll
+          for (int j = 0; j < J; ++j)
+            if (k == (qo >> 2) && j == (int)((n - 1) >> 6)) t.d[n - 1] = rowreg[k][j];
+      }
+    } else if (tid == 0) {
+      t.d[n - 1] = row_ptr(qo)[n - 1];
+    }
+  }
 }
 
 __global__ void tri_last_diag_kernel(TriState t) {
@@ -747,10 +839,19 @@ static bool launch_persistent(const TriState& t, double* tail, hipStream_t st) {
   a.ld = (int)(((n + 15) / 32) * 32 + 16);   // >= n, = 16 mod 32
   const size_t vec_bytes = (size_t)4 * n * sizeof(double);
   const size_t row_bytes = (size_t)a.R * a.ld * sizeof(double);
-  const bool lds_rows = vec_bytes + row_bytes <= 150 * 1024;
-  const size_t lds = lds_rows ? vec_bytes + row_bytes : vec_bytes;
+  void (*kern)(TriPersist) = nullptr;
+  size_t lds = vec_bytes;
+  if (n <= 640 && a.R <= 12) {
+    kern = tri_persistent_kernel<kRowsReg, 10, 3>;
+  } else if (n <= 1024 && a.R <= 16) {
+    kern = tri_persistent_kernel<kRowsReg, 16, 4>;
+  } else if (vec_bytes + row_bytes <= 150 * 1024) {
+    kern = tri_persistent_kernel<kRowsLds, 1, 1>;
+    lds = vec_bytes + row_bytes;
+  } else {
+    kern = tri_persistent_kernel<kRowsGlobal, 1, 1>;
+  }
   if (lds > 150 * 1024) return false;
-  auto kern = lds_rows ? tri_persistent_kernel<true> : tri_persistent_kernel<false>;
   if (lds > 64 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return false;
