@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
   if (tid == 0) s_abort = 0;
   __syncthreads();
 
-#ifdef USC_TRI_TIMING
+#ifdef USC_TRI_TIMING   // developer build (-DUSC_TRI_TIMING): cycles per phase of workgroups 0 and G-1, printed at the end
   long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = clock64(), t1;
 #define TRI_MARK(acc) do { t1 = clock64(); acc += t1 - t0; t0 = t1; } while (0)
 #else
@@ -626,6 +626,7 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
   if ((g == 0 || g == G - 1) && tid == 0)
     printf("tri timing wg %d: reflector %lld  symv+publish %lld  exchange %lld  update %lld cycles (n=%d)\n", g, tA, tB, tC, tD, (int)n);
 #endif
+#undef TRI_MARK
   // d[n-1]: bottom-right entry after the last update; its owner holds it
   if ((n - 1) % G == g) {
     const int qo = (int)((n - 1) / G);
