@@ -4,6 +4,9 @@ sklearn DBSCAN(eps=0.95, min_samples=1) once per query; here the components come
 (`ops.cc_eps`, identical labels)."""
 from __future__ import annotations
 
+import os
+
+import numpy as np
 import torch
 
 from .. import ops
@@ -138,13 +141,12 @@ def mask_boxes(masks, coords, classes, scores):
     cnt = m.sum(0)
     centre = (m.T @ coords.float()) / cnt.clamp(min=1)[:, None]
     big = torch.finfo(torch.float32).max
-    c = coords.float()[:, None, :]
-    on = masks[:, :, None]
-    hi = torch.where(on, c, torch.full_like(c, -big)).amax(0)
-    lo = torch.where(on, c, torch.full_like(c, big)).amin(0)
-    rows = torch.cat([centre, hi - lo], 1).double().cpu().numpy()
+    ext = []
+    for a in range(3):                                      # one [N,K] temporary per axis, not [N,K,3]
+        ca = coords[:, a:a + 1].float()
+        ext.append(torch.where(masks, ca, -big).amax(0) - torch.where(masks, ca, big).amin(0))
+    rows = torch.cat([centre, torch.stack(ext, 1)], 1).double().cpu().numpy()
     ok = (cnt > 0).cpu().numpy()
-    import numpy as np
     out = np.concatenate([np.asarray(classes, np.float64)[:, None], rows, np.asarray(scores, np.float64)[:, None]], 1)
     return out[ok]
 
@@ -152,9 +154,6 @@ def mask_boxes(masks, coords, classes, scores):
 def save_for_freemask(save_dir, file_name, full_res_coords, pred_masks):
     """`{save_dir}/freemasks/{name}_cloud.npy` (coordinates) and `{name}_masks.npy` (bool [N_full,K]) — the files
     the next self-training round's preprocessing reads (trainer.py:743-760)."""
-    import os
-
-    import numpy as np
     d = os.path.join(save_dir, "freemasks")
     os.makedirs(d, exist_ok=True)
     np.save(os.path.join(d, f"{file_name}_cloud.npy"), np.asarray(full_res_coords))
