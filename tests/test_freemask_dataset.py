@@ -88,3 +88,21 @@ def test_scene_reader_device_feeds_the_collate(device, tmp_path):
     n_vox = data.coordinates.shape[0]
     assert 0 < n_vox <= 4000 and data.features.shape == (n_vox, 6)
     assert target[0]["point2segment"].shape[0] == n_vox and target[0]["segment_mask"].shape[0] >= 1
+
+
+def test_reader_without_export_files_keeps_the_scene_masks(monkeypatch, tmp_path, capsys):
+    """No `freemasks/scene…` files for a scene: the reference prints a notice and carries on with the scene's own
+    pseudo masks (freemask_semseg.py:233-235)."""
+    from unscene3d_amd.datasets.freemask import FreeMaskSceneReader
+
+    _kdtree_knn1(monkeypatch)
+    z = np.load(GOLD)
+    d = tmp_path / "scans" / "scene0001_00"
+    d.mkdir(parents=True)
+    np.save(d / "0001_00.npy", z["points"])
+    np.save(d / "0001_00_freemasks.npy", z["freemasks"])
+    entry = {"filepath": str(d / "0001_00.npy"), "raw_filepath": "raw/scene0001_00/scene0001_00_vh_clean_2.ply"}
+    plain = FreeMaskSceneReader([entry], device="cpu")[0]
+    missing = FreeMaskSceneReader([entry], load_self_train_data=True, self_train_data_dir=str(tmp_path), device="cpu")[0]
+    assert "Could not load self training data" in capsys.readouterr().out
+    assert np.array_equal(plain[2], missing[2])

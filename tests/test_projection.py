@@ -277,3 +277,26 @@ def test_full_size_frame_properties(device):
             if (q >= 0).all() and (q < np.array(dims)).all():
                 v = occ[0, q[2], q[1], q[0]]
                 assert v == 0 or v == hit[ys[k], xs[k]]
+
+
+@pytest.mark.gpu
+def test_frame_that_sees_nothing(device):
+    """Depth range in front of every wall: no pixel hits, features and counts stay zero, the fused update leaves the
+    scene untouched."""
+    from unscene3d_amd import project_features_cuda as P
+
+    coords = room(3)
+    n = coords.shape[0]
+    W, H, C = 12, 9, 5
+    proj = P.Project2DFeaturesCUDA(W, H, 0.02, depth_min=0.02, depth_max=0.05)     # 1 .. 2.5 voxels
+    c_d = _dev(coords, device)
+    lo = coords[:, 1:].min(0)
+    eye = lo + np.array([20.0, 18.0, 14.0])
+    views = look_at(eye, eye + np.array([1.0, 0.2, 0.1]))[None, None]
+    feats = torch.randn((1, 1, H, W, C), device=device)
+    out, num = proj(feats, c_d, _dev(views, device), _dev(intrinsics(1, W, H), device))
+    assert int(num.sum()) == 0 and not bool(out.any())
+    scene = torch.randn((n, C), device=device)
+    before = scene.clone()
+    num2, _ = proj.fuse_frame(scene, feats, c_d, _dev(views, device), _dev(intrinsics(1, W, H), device))
+    assert int(num2.sum()) == 0 and torch.equal(scene, before)
