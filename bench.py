@@ -113,20 +113,40 @@ def make_mask3d_step(args, dev, rank, world):
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(dev),
                                       spatial_sort=False)
 
+    reducer = None
+    if world > 1 and os.environ.get("USC3D_OVERLAP_ALLREDUCE", "1") == "1":
+        from unscene3d_amd.ddp import BucketedGradReducer
+        reducer = BucketedGradReducer(params, flat, world).install()     # ~24 MB buckets, started during backward
+
     def step(w):
         batch = collate([sample])
         out = module.training_step(batch)
         total, _ = out
         opt.zero_grad(set_to_none=False)
+        if reducer is not None:
+            reducer.begin_step()
         total.backward()
-        if w > 1:
-            dist.all_reduce(flat)      # RCCL over xGMI: one flat ~158 MB gradient buffer
+        if reducer is not None:
+            reducer.finish()           # RCCL over xGMI: what backward has not already started, then wait + average
+        elif w > 1:
+            dist.all_reduce(flat)      # one flat ~158 MB gradient buffer
             flat.div_(w)
         opt.step()
         sched.step()
         return total.detach(), batch[0].coordinates.shape[0]
 
+    step.reducer = reducer
     return step
+
+
+def _allreduce_note(step, world):
+    if world == 1:
+        return None
+    red = getattr(step, "reducer", None)
+    if red is None:
+        return "one flat buffer after backward"
+    return (f"{len(red.bounds)} buckets of the flat buffer, {red.started_during_backward} started during backward "
+            f"(last step)")
 
 
 def cpu_baseline(sample_voxels, mode="mask3d"):
@@ -352,7 +372,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.mode].format(nvox=nvox),
                        "voxels_per_scene": int(nvox), "global_batch": world, "parallelism": f"dp{world}",
-                       "loss": float(loss)},
+                       "loss": float(loss), "grad_allreduce": _allreduce_note(step, world)},
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),
         }

@@ -41,6 +41,34 @@ def _worker(rank, world, port, out):
         assert torch.allclose(flat, sum(gathered) / world)
         assert torch.allclose(params[0].grad.reshape(-1), flat[:params[0].numel()])
 
+        # 1b. bucketed reducer: learns the per-parameter report counts on the first step, then starts buckets during
+        #     backward (here through autograd's post-accumulate hooks); result == mean of the local gradients
+        from unscene3d_amd.ddp import BucketedGradReducer
+        torch.manual_seed(1)
+        deep = torch.nn.Sequential(*[torch.nn.Linear(12, 12) for _ in range(6)])
+        import copy
+        twin = copy.deepcopy(deep)                   # same weights, no reducer: the local gradients to compare with
+        tflat = flatten_grads(list(twin.parameters()))
+        dparams = list(deep.parameters())
+        dflat = flatten_grads(dparams)
+        red = BucketedGradReducer(dparams, dflat, world, bucket_bytes=1200)
+        assert len(red.bounds) >= 3
+        for it in range(3):
+            deep.zero_grad(set_to_none=False)
+            red.begin_step()
+            xin = torch.full((4, 12), float(rank + 1 + it))
+            twin.zero_grad(set_to_none=False)
+            twin(xin).square().sum().backward()
+            local = tflat.clone()
+            deep(xin).square().sum().backward()
+            early = sum(red.launched)
+            red.finish()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            assert torch.equal(dflat, (gathered[0] + gathered[1]) / world), it
+            assert (early == 0) if it == 0 else (early >= len(red.bounds) - 1), (it, early)
+            assert all(p.grad.data_ptr() >= dflat.data_ptr() for p in dparams)
+
         # 2. criterion: num_masks is summed over ranks and divided by the world size
         g = torch.Generator().manual_seed(3)
         T = 2 + 3 * rank                      # 2 targets on rank 0, 5 on rank 1 -> global mean 3.5

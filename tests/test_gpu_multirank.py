@@ -13,6 +13,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(overlap, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", USC3D_OVERLAP_ALLREDUCE=overlap)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--voxels", "40000", "--dist-backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_overlapped_gradient_allreduce_equals_the_single_one():
+    """Buckets started during backward vs one all-reduce after it: the same sums, so the same weights and the same
+    loss after four steps, to the last bit — and the buckets of the backbone really do start early."""
+    a, b = _run("1", 29561), _run("0", 29563)
+    assert a["config"]["loss"] == b["config"]["loss"], (a["config"]["loss"], b["config"]["loss"])
+    note = a["config"]["grad_allreduce"]
+    assert "buckets" in note and int(note.split(", ")[1].split()[0]) >= 1, note
+    assert b["config"]["grad_allreduce"] == "one flat buffer after backward"
+
+
 def test_bench_two_ranks_gloo():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -1,8 +1,10 @@
 """Data-parallel gradient exchange: one process per GPU, one scene per
 rank, gradients all-reduced over RCCL/xGMI.  The reference gets this implicitly from
 PyTorch-Lightning DDP (main_instance_segmentation.py:86-92); here every parameter's
-`.grad` is a view into ONE flat fp32 buffer so the exchange is a single large
-all-reduce (xGMI rings are per-link bound: few, large collectives)."""
+`.grad` is a view into ONE flat fp32 buffer (`flatten_grads`), exchanged either as a single
+large all-reduce after backward (`all_reduce_mean_`) or in a few large buckets that start
+while the backbone's backward is still running (`BucketedGradReducer`).  xGMI rings are
+per-link bound: few, large collectives."""
 from __future__ import annotations
 
 import torch
@@ -28,3 +30,97 @@ def all_reduce_mean_(flat, world_size: int):
         dist.all_reduce(flat)
         flat.div_(world_size)
     return flat
+
+
+class BucketedGradReducer:
+    """Overlaps the gradient all-reduce with backward.
+
+    The flat buffer is cut into contiguous buckets of ~`bucket_bytes` (24 MB: large enough for the xGMI rings, small
+    enough that the bucket mixing backbone and decoder parameters — reduced after backward — stays small) in parameter
+    order.  The backward kernels of this
+    package write parameter gradients straight into `p.grad` (ops.GRAD_IN_PLACE) and report each write through
+    `ops.GRAD_WRITTEN_HOOK`; parameters that still go through autograd report through a post-accumulate hook.  The
+    first step only LEARNS how many reports each parameter produces per step (shared decoder weights are written by
+    twelve passes, graph-captured passes report nothing); from the second step on a bucket whose parameters all
+    reached their learned count is reduced asynchronously while backward continues.
+
+    Every rank issues the collectives in the same order whatever the timing: eligible buckets (every parameter reports)
+    strictly from the last one to the first — the order backward finishes them — and the rest, in index order, in
+    `finish()`.  A bucket that is not complete when backward ends is simply reduced in `finish()`, in that same order.
+    """
+
+    def __init__(self, params, flat, world_size: int, bucket_bytes: int = 24 << 20):
+        self.params = list(params)
+        self.flat, self.world = flat, world_size
+        self.bounds, self.members = [], []          # bucket -> (start, end) in flat, list of param indices
+        self.bucket_of = {}
+        off, start, cur = 0, 0, []
+        for i, p in enumerate(self.params):
+            cur.append(i)
+            self.bucket_of[id(p)] = len(self.bounds)
+            off += p.numel()
+            if (off - start) * flat.element_size() >= bucket_bytes:
+                self.bounds.append((start, off))
+                self.members.append(cur)
+                start, cur = off, []
+        if cur:
+            self.bounds.append((start, off))
+            self.members.append(cur)
+        for i in self.members[-1]:
+            self.bucket_of[id(self.params[i])] = len(self.bounds) - 1
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.expected = None                         # learned reports per parameter and step
+        self.counts = [0] * len(self.params)
+        self.order, self.cursor = [], 0              # eligible buckets, last first
+        self.handles, self.launched = [], []
+        self.started_during_backward = 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self.on_grad) for p in self.params]
+
+    def install(self):
+        from . import ops
+        ops.GRAD_WRITTEN_HOOK = self.on_grad
+        return self
+
+    def begin_step(self):
+        self.counts = [0] * len(self.params)
+        self.handles, self.launched, self.cursor = [], [False] * len(self.bounds), 0
+
+    def on_grad(self, param):
+        i = self.index.get(id(param))
+        if i is None:
+            return
+        self.counts[i] += 1
+        if self.expected is not None:
+            self._advance()
+
+    def _complete(self, b):
+        return all(self.counts[i] >= self.expected[i] for i in self.members[b])
+
+    def _launch(self, b):
+        import torch.distributed as dist
+        s, e = self.bounds[b]
+        self.handles.append(dist.all_reduce(self.flat[s:e], async_op=True))
+        self.launched[b] = True
+
+    def _advance(self):
+        while self.cursor < len(self.order) and self._complete(self.order[self.cursor]):
+            self._launch(self.order[self.cursor])
+            self.cursor += 1
+
+    def finish(self):
+        """After backward: reduce what has not been started (same order on every rank), wait, average."""
+        self.started_during_backward = sum(self.launched)
+        if self.expected is None:
+            self.expected = list(self.counts)
+            eligible = [b for b in range(len(self.bounds)) if all(self.expected[i] > 0 for i in self.members[b])]
+            self.order = sorted(eligible, reverse=True)
+        for b in self.order[self.cursor:]:
+            self._launch(b)
+        self.cursor = len(self.order)
+        for b in range(len(self.bounds)):
+            if not self.launched[b]:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        self.flat.div_(self.world)
+        return self.flat

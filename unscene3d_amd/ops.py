@@ -306,11 +306,21 @@ def pairs_gemm(feats, W, rows_in, rows_out, koff, P, n_out):
 GRAD_IN_PLACE = os.environ.get("USC3D_GRAD_IN_PLACE", "1") == "1"
 
 
+GRAD_WRITTEN_HOOK = None   # callable(param), set by ddp.BucketedGradReducer: "the kernels that add into p.grad are queued"
+
+
 def _grad_target(param):
     if GRAD_IN_PLACE and isinstance(param, torch.nn.Parameter) and param.is_leaf and param.grad is not None \
             and param.grad.is_contiguous() and not param._backward_hooks:
         return param.grad
     return None
+
+
+def _grad_written(*params):
+    if GRAD_WRITTEN_HOOK is not None:
+        for p in params:
+            if p is not None:
+                GRAD_WRITTEN_HOOK(p)
 
 
 def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None, into=None, out=None):
@@ -366,6 +376,7 @@ class _ConvSame(torch.autograd.Function):
                 dW = wgrad(feats, dout, K, rb.in_idx, rb.out_idx, rb.koff, into=tgt)
             if tgt is not None:
                 dW = None
+                _grad_written(ctx.w_param)
             elif ctx.w_dim == 2:
                 dW = dW[0]
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -399,6 +410,7 @@ class _ConvDown2(torch.autograd.Function):
             dW = wgrad(feats, dout, W.shape[0], rb.in_idx, rb.out_idx, rb.koff, into=tgt)
             if tgt is not None:
                 dW = None
+                _grad_written(ctx.w_param)
         return dfeats, dW, None, None
 
 
@@ -429,6 +441,7 @@ class _ConvTrUp2(torch.autograd.Function):
             dW = wgrad(feats, dout, W.shape[0], rb.out_idx, rb.in_idx, rb.koff, into=tgt)
             if tgt is not None:
                 dW = None
+                _grad_written(ctx.w_param)
         return dfeats, dW, None, None, None
 
 
@@ -519,6 +532,8 @@ class _BatchNormAct(torch.autograd.Function):
         dres = torch.empty_like(x) if ctx.has_res else None
         check(lib.usc_bn_backward_dx(_ptr(x), _ptr(dy), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(red[2]),
                                      _ptr(red[3]), _ptr(dx), _ptr(dres), n, c, _stream()), "usc_bn_backward_dx")
+        if in_place:
+            _grad_written(ctx.gamma_param, ctx.beta_param)
         return (dx, (None if in_place else red[0]), (None if in_place else red[1]), dres, None, None, None, None, None,
                 None, None)
 
@@ -750,6 +765,7 @@ class _LayerNorm(torch.autograd.Function):
               "usc_layernorm_bwd")
         if in_place:
             dgamma = dbeta = None
+            _grad_written(ctx.w_param, ctx.b_param)
         return dx.view(ctx.shape), dgamma, dbeta, None
 
 
@@ -832,6 +848,7 @@ class _LinearRows(torch.autograd.Function):
         dx = _lin_bwd(dy2, x2, W, dW, db, need_dx=ctx.needs_input_grad[0], accumulate=in_place)
         if in_place:
             dW = db = None
+            _grad_written(ctx.w_param, ctx.b_param if ctx.has_bias else None)
         return (None if dx is None else dx.view(ctx.shape)), dW, db
 
 
@@ -875,6 +892,7 @@ class _InProj(torch.autograd.Function):
                                 need_dx=ctx.needs_input_grad[j], accumulate=in_place))
         if in_place:
             dW = db = None
+            _grad_written(ctx.w_param, ctx.b_param)
         return tuple(None if d is None else d.view(shp) for d, shp in zip(dxs, ctx.shapes)) + (dW, db)
 
 
