@@ -524,6 +524,19 @@ int usc_project_predictions(const int32_t* preds, int32_t c, const int32_t* hit,
 int usc_unproject_depth(const float* depth, const float* views, const float* intrinsics,
                         int32_t V, int32_t H, int32_t W, float* cloud, usc_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * A1  elastic distortion of the training augmentation — the per-point half of
+ * datasets/semseg.py:651-688 `elastic_distortion` (called from freemask_semseg.py:356-361):
+ * xyz_out[i,0:3] = xyz_in[i,0:3] + magnitude * trilinear(noise)(xyz_in[i,0:3]), evaluated in f64 like
+ * scipy's RegularGridInterpolator(bounds_error=0, fill_value=0).  xyz f32 or f64 [n,row_stride] (only the
+ * first three columns are read/written; in place allowed), noise f32[dim_x,dim_y,dim_z,3] (already
+ * smoothed), axis_* f64[dim_*] the grid coordinates (np.linspace of the reference).
+ * ---------------------------------------------------------------------- */
+int usc_elastic_displace(const void* xyz_in, int32_t is_f64, int64_t n, int32_t row_stride,
+                         const float* noise, int32_t dim_x, int32_t dim_y, int32_t dim_z,
+                         const double* axis_x, const double* axis_y, const double* axis_z,
+                         double magnitude, void* xyz_out, usc_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

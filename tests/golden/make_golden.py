@@ -9,6 +9,7 @@ not installed: SURVEY.md Appendix A), feeds them seeded inputs and stores inputs
     python tests/golden/make_golden.py ncut       # NCut fixtures (separate interpreter: different stubs)
     python tests/golden/make_golden.py export     # eval/export post-processing fixtures (trainer.eval_instance_step)
     python tests/golden/make_golden.py dataset    # self-train mask merge + validation-mode scene reader fixtures
+    python tests/golden/make_golden.py elastic    # elastic distortion fixtures (datasets.semseg.elastic_distortion)
 """
 import importlib
 import os
@@ -469,10 +470,41 @@ def make_dataset(ds):
     np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
 
 
+def make_elastic():
+    stub("open3d", "felzenszwalb_cpp", "albumentations", "volumentations", "imageio", "MinkowskiEngine", "plyfile",
+         "natsort", "loguru", "fire", "torch_scatter", "hydra")
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    semseg = importlib.import_module("datasets.semseg")
+    rng = np.random.default_rng(5)
+    out = {}
+    for name, dtype in (("f32", np.float32), ("f64", np.float64)):
+        pts = np.concatenate([rng.uniform(-3.1, 4.3, (5000, 1)), rng.uniform(0.2, 5.7, (5000, 1)),
+                              rng.uniform(-0.1, 2.6, (5000, 1)), rng.uniform(0, 1, (5000, 3))], 1).astype(dtype)
+        out[f"{name}/points"] = pts.copy()
+        np.random.seed(1234)
+        res = pts.copy()
+        drawn = []
+        orig = np.random.randn
+        np.random.randn = lambda *a: drawn.append(orig(*a)) or drawn[-1]
+        try:
+            for granularity, magnitude in ((0.2, 0.4), (0.8, 1.6)):       # freemask_semseg.py:356-361
+                res = semseg.elastic_distortion(res, granularity, magnitude)
+        finally:
+            np.random.randn = orig
+        out[f"{name}/result"] = res
+        for j, d in enumerate(drawn):
+            out[f"{name}/noise{j}"] = d.astype(np.float32)
+        print(name, res.dtype, [d.shape for d in drawn], float(np.abs(res[:, :3] - pts[:, :3]).max()))
+    np.savez_compressed(os.path.join(HERE, "elastic.npz"), **out)
+
+
 if __name__ == "__main__":
     cwd = os.getcwd()
     if len(sys.argv) > 1 and sys.argv[1] == "ncut":
         make_ncut(import_reference_ncut())
+    elif len(sys.argv) > 1 and sys.argv[1] == "elastic":
+        make_elastic()
     elif len(sys.argv) > 1 and sys.argv[1] == "dataset":
         make_dataset(import_reference_dataset())
     elif len(sys.argv) > 1 and sys.argv[1] == "export":

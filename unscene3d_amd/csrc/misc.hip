@@ -169,6 +169,57 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(const int32_t* __restr
   }
 }
 
+// ---------------------------------------------------------------------------
+// Elastic distortion of a point cloud: xyz += magnitude * trilinear(noise grid)(xyz), in f64 like scipy's
+// RegularGridInterpolator (datasets/semseg.py:651-688).  The grid axes come in as the caller's f64 arrays (they are
+// np.linspace values); cell index = searchsorted(axis, x) - 1 clipped to [0, dim-2], fraction = (x - a[i]) / (a[i+1] - a[i]).
+template <class T>
+__global__ __launch_bounds__(256) void elastic_displace_kernel(const T* __restrict__ xyz_in, int64_t n, int32_t stride,
+                                                              const float* __restrict__ noise, int dx, int dy, int dz,
+                                                              const double* __restrict__ ax, const double* __restrict__ ay,
+                                                              const double* __restrict__ az, double magnitude,
+                                                              T* __restrict__ xyz_out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double p[3] = {(double)xyz_in[i * stride + 0], (double)xyz_in[i * stride + 1], (double)xyz_in[i * stride + 2]};
+  const double* axes[3] = {ax, ay, az};
+  const int dims[3] = {dx, dy, dz};
+  int c0[3];
+  double f[3];
+  bool inside = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double* g = axes[a];
+    const int d = dims[a];
+    inside = inside && p[a] >= g[0] && p[a] <= g[d - 1];
+    int k = (int)floor((p[a] - g[0]) / (g[1] - g[0]));     // uniform axis: the guess is off by at most one
+    k = k < 0 ? 0 : (k > d - 2 ? d - 2 : k);
+    while (k > 0 && p[a] <= g[k]) --k;                      // searchsorted(side='left') - 1
+    while (k < d - 2 && p[a] > g[k + 1]) ++k;
+    c0[a] = k;
+    f[a] = (p[a] - g[k]) / (g[k + 1] - g[k]);
+  }
+  double disp[3] = {0.0, 0.0, 0.0};
+  if (inside) {                                             // bounds_error=0, fill_value=0 outside the grid
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+      const int ox = corner >> 2, oy = (corner >> 1) & 1, oz = corner & 1;
+      const double w = (ox ? f[0] : 1.0 - f[0]) * (oy ? f[1] : 1.0 - f[1]) * (oz ? f[2] : 1.0 - f[2]);
+      const float* v = noise + ((((int64_t)(c0[0] + ox) * dy + (c0[1] + oy)) * dz) + (c0[2] + oz)) * 3;
+      // products and sums rounded separately, like numpy's  value += values[corner] * weight
+      const double t0 = (double)v[0] * w, t1 = (double)v[1] * w, t2 = (double)v[2] * w;
+      disp[0] += t0;
+      disp[1] += t1;
+      disp[2] += t2;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double d = disp[a] * magnitude;
+    xyz_out[i * stride + a] = (T)(p[a] + d);
+  }
+}
+
 }  // namespace usc
 
 using namespace usc;
@@ -247,6 +298,23 @@ int usc_project_planes_bwd(const int32_t* coords, int64_t V, int32_t inst, int32
   hipLaunchKernelGGL(project_bwd_kernel, dim3((unsigned)ceil_div(V, 256)), dim3(256), 0, as_stream(s), coords, V, (int)inst,
                      (int)dim_x, (int)dim_y, (int)dim_z, g_xy, g_xz, g_yz, grad_pred);
   USC_CHECK_LAUNCH("usc_project_planes_bwd");
+  return USC_OK;
+}
+
+int usc_elastic_displace(const void* xyz_in, int32_t is_f64, int64_t n, int32_t row_stride, const float* noise,
+                         int32_t dim_x, int32_t dim_y, int32_t dim_z, const double* axis_x, const double* axis_y,
+                         const double* axis_z, double magnitude, void* xyz_out, usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && row_stride >= 3 && dim_x >= 2 && dim_y >= 2 && dim_z >= 2, "usc_elastic_displace: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(xyz_in && noise && axis_x && axis_y && axis_z && xyz_out, "usc_elastic_displace: null pointer");
+  const dim3 grid((unsigned)ceil_div(n, 256));
+  if (is_f64)
+    hipLaunchKernelGGL(elastic_displace_kernel<double>, grid, dim3(256), 0, as_stream(s), (const double*)xyz_in, n,
+                       row_stride, noise, dim_x, dim_y, dim_z, axis_x, axis_y, axis_z, magnitude, (double*)xyz_out);
+  else
+    hipLaunchKernelGGL(elastic_displace_kernel<float>, grid, dim3(256), 0, as_stream(s), (const float*)xyz_in, n,
+                       row_stride, noise, dim_x, dim_y, dim_z, axis_x, axis_y, axis_z, magnitude, (float*)xyz_out);
+  USC_CHECK_LAUNCH("usc_elastic_displace");
   return USC_OK;
 }
 
