@@ -39,6 +39,9 @@ def parse():
                          "backbone: configs[1] Res16UNet34C fwd+bwd only; "
                          "ncut: configs[4] masked-NCut pseudo-mask loop on a 625-segment scene (secondary metric)")
     ap.add_argument("--no-graphs", action="store_true", help="do not capture the decoder passes as HIP graphs")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="voxelise and build the coordinate maps at the start of the step on the compute stream "
+                         "instead of ahead of time on a side stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the measured configuration); gloo only to smoke-test the N>1 code path on a box "
@@ -118,8 +121,17 @@ def make_mask3d_step(args, dev, rank, world):
         from unscene3d_amd.ddp import BucketedGradReducer
         reducer = BucketedGradReducer(params, flat, world).install()     # ~24 MB buckets, started during backward
 
+    prefetch = None
+    if not args.no_prefetch:
+        from unscene3d_amd.datasets.prefetch import ScenePrefetcher
+        prefetch = ScenePrefetcher(collate, add_raw_coordinates=cfg.data.add_raw_coordinates, device=dev)
+        prefetch.submit([sample])      # the first batch, outside the timed region like the resident raw arrays
+
     def step(w):
-        batch = collate([sample])
+        if prefetch is not None:
+            batch = prefetch.take()
+        else:
+            batch = collate([sample])
         out = module.training_step(batch)
         total, _ = out
         opt.zero_grad(set_to_none=False)
@@ -133,6 +145,8 @@ def make_mask3d_step(args, dev, rank, world):
             flat.div_(w)
         opt.step()
         sched.step()
+        if prefetch is not None:
+            prefetch.submit([sample])  # the next step's voxelisation + coordinate maps, on a side stream under backward
         return total.detach(), batch[0].coordinates.shape[0]
 
     step.reducer = reducer

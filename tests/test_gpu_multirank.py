@@ -47,3 +47,20 @@ def test_bench_two_ranks_gloo():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["roofline"] is not None and rec["cpu_baseline"] is None
+
+
+def _run_single(extra):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--voxels", "40000",
+           "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_prefetched_batches_give_the_same_training_trajectory():
+    """Voxelisation + coordinate maps of the next batch on a side stream (datasets/prefetch.py) vs built at the start
+    of the step on the compute stream: same scene, same weights, so the loss after six steps must agree to the bit —
+    a cross-stream lifetime bug would show up as a different or non-finite loss."""
+    a, b = _run_single([]), _run_single(["--no-prefetch"])
+    assert a["config"]["loss"] == b["config"]["loss"], (a["config"]["loss"], b["config"]["loss"])
+    assert a["config"]["voxels_per_scene"] == b["config"]["voxels_per_scene"]

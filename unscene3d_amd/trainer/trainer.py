@@ -50,12 +50,16 @@ class InstanceSegmentation(nn.Module):
             raise RuntimeError("BATCH TOO BIG")
         if len(target) == 0:
             return None
-        feats, raw_coordinates = data.features, None
-        if self.config.data.add_raw_coordinates:
-            raw_coordinates = feats[:, -3:].contiguous()
-            feats = feats[:, :-3].contiguous()
-        dev = next(self.parameters()).device
-        x = ME.SparseTensor(coordinates=data.coordinates, features=feats, device=dev)
+        x = getattr(data, "sparse_tensor", None)      # built ahead of time by datasets.prefetch.ScenePrefetcher
+        if x is not None:
+            raw_coordinates = data.raw_coordinates
+        else:
+            feats, raw_coordinates = data.features, None
+            if self.config.data.add_raw_coordinates:
+                raw_coordinates = feats[:, -3:].contiguous()
+                feats = feats[:, :-3].contiguous()
+            dev = next(self.parameters()).device
+            x = ME.SparseTensor(coordinates=data.coordinates, features=feats, device=dev)
         try:
             output = self.forward(x, point2segment=[t["point2segment"] for t in target],
                                   raw_coordinates=raw_coordinates)
