@@ -39,6 +39,7 @@ def parse():
                          "backbone: configs[1] Res16UNet34C fwd+bwd only; "
                          "ncut: configs[4] masked-NCut pseudo-mask loop on a 625-segment scene (secondary metric)")
     ap.add_argument("--no-graphs", action="store_true", help="do not capture the decoder passes as HIP graphs")
+    ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of the flat-buffer kernel")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="voxelise and build the coordinate maps at the start of the step on the compute stream "
                          "instead of ahead of time on a side stream")
@@ -105,7 +106,11 @@ def make_mask3d_step(args, dev, rank, world):
     module = InstanceSegmentation(cfg).to(dev).train()
     params = [p for n, p in module.named_parameters() if ".backbone.final." not in n]    # unused in forward
     flat = flatten_grads(params)
-    opt = torch.optim.AdamW(params, lr=cfg.optimizer.lr, fused=True)
+    if args.torch_adamw:
+        opt = torch.optim.AdamW(params, lr=cfg.optimizer.lr, fused=True)
+    else:
+        from unscene3d_amd.optim import FlatAdamW
+        opt = FlatAdamW(params, lr=cfg.optimizer.lr, flat_grad=flat)     # same defaults as torch.optim.AdamW
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=cfg.optimizer.lr, total_steps=100000)
     sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=args.voxels, seed=2000 + rank)[0]
     # raw scene arrays resident in HBM before the timed region (the collate reads them from there)

@@ -525,6 +525,16 @@ int usc_unproject_depth(const float* depth, const float* views, const float* int
                         int32_t V, int32_t H, int32_t W, float* cloud, usc_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * T  optimizer step — torch.optim.AdamW(lr, betas, eps, weight_decay) of
+ * `configure_optimizers` (trainer/trainer.py:953-966) over FLAT f32 buffers of n elements
+ * (16-byte aligned): p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
+ * p -= (lr / (1 - b1^step)) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).  step counts from 1.
+ * ---------------------------------------------------------------------- */
+int usc_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t step, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
  * A1  elastic distortion of the training augmentation — the per-point half of
  * datasets/semseg.py:651-688 `elastic_distortion` (called from freemask_semseg.py:356-361):
  * xyz_out[i,0:3] = xyz_in[i,0:3] + magnitude * trilinear(noise)(xyz_in[i,0:3]), evaluated in f64 like

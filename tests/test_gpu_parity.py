@@ -902,3 +902,31 @@ def test_decoder_graph_capture_equals_eager(device):
         results.append((float(total.detach()), g.clone()))
     assert abs(results[0][0] - results[1][0]) <= 1e-5 * abs(results[0][0])
     assert rel_err(results[1][1], results[0][1]) < 1e-4
+
+
+def test_flat_adamw_matches_torch_adamw(device):
+    """usc_adamw_step over flat buffers vs torch.optim.AdamW (fused) under OneCycleLR (lr and beta1 change every step),
+    odd parameter sizes (tail of the float4 loop), five steps."""
+    from unscene3d_amd.optim import FlatAdamW
+
+    torch.manual_seed(0)
+    shapes = [(33, 7), (5,), (128, 64), (1, 3), (1001,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device=device)) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa = FlatAdamW(pa, lr=1e-3, weight_decay=0.01)
+    ob = torch.optim.AdamW(pb, lr=1e-3, weight_decay=0.01, fused=True)
+    sa = torch.optim.lr_scheduler.OneCycleLR(oa, max_lr=1e-3, total_steps=50)
+    sb = torch.optim.lr_scheduler.OneCycleLR(ob, max_lr=1e-3, total_steps=50)
+    assert all(p.data_ptr() >= oa.flat_param.data_ptr() for p in pa)
+    for it in range(5):
+        oa.zero_grad(set_to_none=False)
+        ob.zero_grad(set_to_none=False)
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a) * (1 + it)
+            a.grad.copy_(g)                        # views of the flat gradient buffer
+            b.grad = g.clone()
+        oa.step(); sa.step()
+        ob.step(); sb.step()
+        assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())

@@ -4,6 +4,8 @@
 // child table, row gather and segment mean (torch_scatter.scatter_mean) with a
 // stable counting-sort CSR so that every floating-point sum has a fixed order.
 // All kernels move 16 B per lane where the channel count allows it.
+#include <math.h>
+
 #include "common.h"
 #include "scan.h"
 
@@ -522,6 +524,32 @@ __global__ __launch_bounds__(256) void segment_mean_bwd_kernel(const float* __re
   }
 }
 
+// ---------------------------------------------------------------------------
+// AdamW over flat parameter / gradient / moment buffers (trainer/trainer.py:953-966 configures torch.optim.AdamW;
+// operation order of PyTorch's fused kernel).  One pass: reads p, g, m, v and writes p, m, v — 28 B per parameter.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4, int64_t n,
+                                                   float lr, float beta1, float beta2, float eps, float wd,
+                                                   float step_size, float bc2_sqrt) {
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    pp -= lr * wd * pp;
+    mm = mm + (1.0f - beta1) * (gg - mm);      // lerp(m, g, 1 - beta1)
+    vv = beta2 * vv + (1.0f - beta2) * gg * gg;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step_size * mm / denom;
+  };
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4; j += (int64_t)gridDim.x * 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[j], mv = reinterpret_cast<float4*>(m)[j], vv = reinterpret_cast<float4*>(v)[j];
+    const float4 gv = reinterpret_cast<const float4*>(g)[j];
+    upd(pv.x, gv.x, mv.x, vv.x); upd(pv.y, gv.y, mv.y, vv.y); upd(pv.z, gv.z, mv.z, vv.z); upd(pv.w, gv.w, mv.w, vv.w);
+    reinterpret_cast<float4*>(p)[j] = pv; reinterpret_cast<float4*>(m)[j] = mv; reinterpret_cast<float4*>(v)[j] = vv;
+  }
+  if (blockIdx.x == 0) {
+    const int64_t j = n4 * 4 + threadIdx.x;
+    if (j < n) upd(p[j], g[j], m[j], v[j]);
+  }
+}
+
 }  // namespace usc
 
 using namespace usc;
@@ -738,6 +766,22 @@ int usc_segment_mean_bwd(const float* dout, int32_t c, const int64_t* seg, const
     hipLaunchKernelGGL((segment_mean_bwd_kernel<1>), dim3(stream_grid(n * c, 256)), dim3(256), 0, as_stream(s), dout,
                        (int)c, seg, seg_off, n, dsrc);
   USC_CHECK_LAUNCH("usc_segment_mean_bwd");
+  return USC_OK;
+}
+
+int usc_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int64_t step, usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && step >= 1, "usc_adamw_step: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(param && grad && exp_avg && exp_avg_sq, "usc_adamw_step: null pointer");
+  USC_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+              "usc_adamw_step: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(n4 > 0 ? n4 : 1, 256)), dim3(256), 0, as_stream(s), param, grad,
+                     exp_avg, exp_avg_sq, n4, n, lr, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt);
+  USC_CHECK_LAUNCH("usc_adamw_step");
   return USC_OK;
 }
 
