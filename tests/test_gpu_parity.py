@@ -930,3 +930,57 @@ def test_flat_adamw_matches_torch_adamw(device):
         assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"]
     for a, b in zip(pa, pb):
         assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
+
+
+def test_flat_adamw_state_dict_round_trip_and_guards(device):
+    from unscene3d_amd.optim import FlatAdamW
+
+    torch.manual_seed(1)
+    pa = [torch.nn.Parameter(torch.randn(17, 5, device=device)), torch.nn.Parameter(torch.randn(9, device=device))]
+    oa = FlatAdamW(pa, lr=1e-2)
+    for p in pa:
+        p.grad.normal_()
+    oa.step()
+    sd = oa.state_dict()
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    ob = FlatAdamW(pb, lr=1e-2)
+    ob.load_state_dict(sd)
+    assert ob.steps == 1 and torch.equal(ob.exp_avg, oa.exp_avg) and torch.equal(ob.exp_avg_sq, oa.exp_avg_sq)
+    for a, b in zip(pa, pb):
+        b.grad.copy_(a.grad)
+    oa.step(); ob.step()
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+    with pytest.raises(RuntimeError):
+        oa.zero_grad(set_to_none=True)
+    oa.zero_grad()
+    assert float(oa.flat_grad.abs().sum()) == 0.0 and all(float(p.grad.abs().sum()) == 0.0 for p in pa)
+
+
+def test_scene_prefetcher_hands_over_prepared_batches(device):
+    """submit() on the side stream, take() on the compute stream: coordinates, features and the prepared pyramid are
+    those of a plain collate + SparseTensor; take() without submit() is an error."""
+    from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd.datasets.prefetch import ScenePrefetcher
+    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+
+    sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=6000, seed=5)[0]
+    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=device)
+    pre = ScenePrefetcher(collate, add_raw_coordinates=True, device=device)
+    with pytest.raises(RuntimeError):
+        pre.take()
+    pre.submit([sample])
+    data, target, names = pre.take()
+    ref, ref_target, ref_names = collate([sample])
+    assert names == ref_names and len(target) == len(ref_target)
+    assert torch.equal(data.coordinates, ref.coordinates) and torch.equal(data.features, ref.features)
+    x = data.sparse_tensor
+    assert torch.equal(x.C, ref.coordinates.to(x.C.dtype)) and torch.equal(x.F, ref.features[:, :-3])
+    assert torch.equal(data.raw_coordinates, ref.features[:, -3:])
+    cm = x.coordinate_manager
+    plain = ME.SparseTensor(coordinates=ref.coordinates, features=ref.features[:, :-3].contiguous(), device=device)
+    plain.coordinate_manager.prepare(1, n_down=4, ksize=3)
+    for ts in (1, 2, 4, 8, 16):
+        assert torch.equal(cm.coord_map(ts).coords, plain.coordinate_manager.coord_map(ts).coords)
+        assert torch.equal(cm.cube_map(ts)["nbr"], plain.coordinate_manager.cube_map(ts)["nbr"])
+    torch.cuda.synchronize()
