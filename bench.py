@@ -1,12 +1,17 @@
 #!/usr/bin/env python
 """bench.py — training scenes/sec of UnScene3D's self-training hot path on MI355X.
 
-`python bench.py --gpus N --steps K --warmup W`  (N>1: launched by torch.distributed.run,
-one rank per GPU over RCCL).  One "step" = one pass of the hot path over one synthetic
-ScanNet-shaped 150k-voxel scene per GPU: 2 cm voxelisation (hash unique) -> coordinate /
-kernel maps -> Res16UNet34C forward -> backward -> (N>1: gradient all-reduce) -> AdamW.
-Inputs (points, colours) are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line (see DESIGN.md §Measurement for the roofline / cpu_baseline definitions).
+`python bench.py --gpus N --steps K --warmup W`.  N>1 needs one process per GPU over RCCL: either the caller
+launches the ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) or, when WORLD_SIZE is not set, this script
+re-executes itself through torch.distributed.run with N ranks on 127.0.0.1.  In both cases the world size must
+equal --gpus (checked), the backend is nccl (= RCCL) and every rank owns one device.
+
+One "step" (default --mode mask3d, BASELINE.json configs[2]) = one full self-training step over one synthetic
+ScanNet-shaped 150k-voxel scene per GPU: device collate (2 cm voxelisation, hash unique, targets) -> coordinate /
+kernel maps -> Res16UNet34C -> 3x4 decoder passes -> 13 cost matrices -> Hungarian (scipy, host) -> 52 losses ->
+backward -> (N>1: gradient all-reduce) -> AdamW + OneCycleLR.  The raw scene arrays are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line (DESIGN.md §5 defines `roofline` and `cpu_baseline`).
 """
 import argparse
 import json
@@ -310,22 +315,53 @@ def run_ncut(args, dev):
     }))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`bench.py --gpus N` started as ONE process: re-execute through torch.distributed.run with N ranks on this node
+    (the reference gets its ranks from pl.Trainer(gpus=cfg.general.gpus), main_instance_segmentation.py:86-92)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    import subprocess
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
     if args.mode == "ncut":
         torch.cuda.set_device(0)
         return run_ncut(args, torch.device("cuda", 0))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch exactly one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if args.dist_backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} devices, this node shows "
+                         f"{torch.cuda.device_count()} (--dist-backend gloo shares devices; smoke test only)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
     if args.dist_backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world,
+                                **({"device_id": dev} if args.dist_backend == "nccl" else {}))
+        assert dist.get_world_size() == args.gpus
 
     from unscene3d_amd import profiler
     from unscene3d_amd.ddp import flatten_grads

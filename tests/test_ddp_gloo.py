@@ -69,6 +69,54 @@ def _worker(rank, world, port, out):
             assert (early == 0) if it == 0 else (early >= len(red.bounds) - 1), (it, early)
             assert all(p.grad.data_ptr() >= dflat.data_ptr() for p in dparams)
 
+        # 1c. ranks whose report counts differ (data-dependent eager/graphed passes): the divergent bucket is not
+        #     eligible on ANY rank, so both issue the same collectives; result still the mean
+        torch.manual_seed(2)
+        net = torch.nn.Sequential(*[torch.nn.Linear(12, 12) for _ in range(4)])
+        nparams = list(net.parameters())
+        nflat = flatten_grads(nparams)
+        ntwin = copy.deepcopy(net)                   # local gradients without a reducer (buckets reduce in place, early)
+        ntflat = flatten_grads(list(ntwin.parameters()))
+        red2 = BucketedGradReducer(nparams, nflat, world, bucket_bytes=600)
+        nb = len(red2.bounds)
+        for it in range(3):
+            net.zero_grad(set_to_none=False)
+            red2.begin_step()
+            ntwin.zero_grad(set_to_none=False)
+            ntwin(torch.full((4, 12), float(rank + 1))).sum().backward()
+            local = ntflat.clone()
+            net(torch.full((4, 12), float(rank + 1))).sum().backward()
+            if rank == 1:
+                red2.on_grad(nparams[-1])          # rank 1 reports the last parameter twice per step
+            red2.finish()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            assert torch.equal(nflat, (gathered[0] + gathered[1]) / world), it
+        last_bucket = red2.bucket_of[id(nparams[-1])]
+        assert last_bucket not in red2.order and len(red2.order) == nb - 1
+        got = [None, None]
+        dist.all_gather_object(got, red2.order)
+        assert got[0] == got[1]
+
+        # 1d. a write after its bucket's all-reduce started: raised on EVERY rank at the next step, not just the culprit
+        for h in red2._hooks:
+            h.remove()
+        red3 = BucketedGradReducer(nparams, nflat, world, bucket_bytes=600)
+        raised = False
+        try:
+            for it in range(3):
+                net.zero_grad(set_to_none=False)
+                red3.begin_step()
+                net(torch.ones(4, 12)).sum().backward()
+                if it == 1 and rank == 0:
+                    red3.on_grad(nparams[-1])      # late report on rank 0 only, bucket already in flight
+                red3.finish()
+        except RuntimeError as err:
+            raised = "after its bucket's all-reduce had started" in str(err) and it == 2
+        assert raised, rank
+        for h in red3._hooks:
+            h.remove()
+
         # 2. criterion: num_masks is summed over ranks and divided by the world size
         g = torch.Generator().manual_seed(3)
         T = 2 + 3 * rank                      # 2 targets on rank 0, 5 on rank 1 -> global mean 3.5

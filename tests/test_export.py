@@ -123,3 +123,46 @@ def test_save_for_freemask_format(tmp_path):
 def test_export_device_path_matches_reference(device, name):
     scenes, general = _load(np.load(GOLD), name)
     _check(_run(scenes, general, device), scenes)
+
+
+@pytest.mark.gpu
+def test_export_runs_on_the_collate_output(device):
+    """export_instances on exactly what FreeMaskVoxelizeCollate hands over (point2segment is a column of the
+    [N, K+2] table there; the row-gather kernels need it dense): model-shaped random predictions, then every full-res
+    mask must be constant per full-res segment and the masks of a single-query oracle must come back unchanged."""
+    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+    from unscene3d_amd.trainer import postprocess as PP
+
+    ds = SyntheticFreeMaskDataset(n_scenes=2, target_voxels=6000, seed=4100)
+    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="validation", device=str(device))
+    data, target, _ = collate([ds[0], ds[1]])
+    Q = 12
+    g = torch.Generator().manual_seed(0)
+    masks, logits = [], []
+    for t in target:
+        assert t["point2segment"].is_contiguous()
+        S = int(t["point2segment"].max()) + 1
+        m = torch.randn(S, Q, generator=g)
+        seg_mask = t["segment_mask"].float().cpu()                    # plant the targets as confident query masks
+        k = min(Q, seg_mask.shape[0])
+        m[:, :k] = (seg_mask[:k].T * 2 - 1) * 6
+        masks.append(m.to(device))
+        logits.append(torch.randn(Q, 3, generator=g))
+    output = {"aux_outputs": [], "pred_logits": torch.stack(logits).to(device), "pred_masks": masks}
+    general = NS(use_dbscan=False, dbscan_eps=0.95, topk_per_image=-1, filter_out_instances=False,
+                 scores_threshold=0.1, iou_threshold=0.66)
+    for eval_on_segments in (False, True):
+        res = PP.export_instances(output, target, data.target_full, data.inverse_maps, None, general, num_classes=3,
+                                  full_res_coords=data.full_res_coords, eval_on_segments=eval_on_segments)
+        for bid, r in enumerate(res):
+            full = r["pred_masks"]
+            inv = data.inverse_maps[bid]
+            assert full.shape[0] == inv.shape[0] and full.dtype == torch.bool and full.shape[1] == Q
+            if eval_on_segments:
+                continue
+            # every exported column is one of the Q query masks lifted segment -> voxel -> full resolution
+            lifted = (masks[bid] > 0)[target[bid]["point2segment"]][inv].T.cpu().numpy()      # [Q, N_full]
+            have = {c.tobytes() for c in np.packbits(lifted, axis=1)}
+            for c in np.packbits(full.T.cpu().numpy(), axis=1):
+                assert c.tobytes() in have

@@ -49,6 +49,32 @@ def test_bench_two_ranks_gloo():
     assert rec["roofline"] is not None and rec["cpu_baseline"] is None
 
 
+def test_bench_gpus_2_without_a_launcher_spawns_two_ranks():
+    """`python bench.py --gpus 2` as ONE process (no torchrun, no WORLD_SIZE): the script launches the two ranks itself
+    and the line reports n_gpus == 2 (gloo here because the test box has one device; the default backend is RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--voxels", "40000", "--dist-backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["config"]["parallelism"] == "dp2"
+
+
+def test_bench_refuses_rccl_ranks_without_devices():
+    """nccl with more ranks than devices must fail loudly instead of reporting a shared-device number as N GPUs."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "devices" in (out.stderr + out.stdout)
+
+
 def _run_single(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--voxels", "40000",
            "--no-cpu-baseline"] + extra

@@ -876,15 +876,18 @@ def test_triplane_projection_loss(device):
     assert lg.grad.shape == logits.shape and bool(torch.isfinite(lg.grad).all()) and float(lg.grad.abs().sum()) > 0
 
 
-def test_decoder_graph_capture_equals_eager(device):
+@pytest.mark.parametrize("level_embed", [False, True])
+def test_decoder_graph_capture_equals_eager(device, level_embed):
     """The HIP-graph captured decoder passes give the same loss and gradients as the eager path.
-    (Two module instances with identical weights: capture must happen before the module's first backward.)"""
+    (Two module instances with identical weights: capture must happen before the module's first backward.)
+    With use_level_embed the embedding weight must receive its gradient from the captured passes too."""
     from unscene3d_amd.config import apply_overrides, default_config
     from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
     from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
     from unscene3d_amd.trainer.trainer import InstanceSegmentation
 
-    cfg = apply_overrides(default_config(), ["general.num_targets=3", "model.sample_sizes=[20,50,100,200,800]"])
+    cfg = apply_overrides(default_config(), ["general.num_targets=3", "model.sample_sizes=[20,50,100,200,800]",
+                                             f"model.use_level_embed={level_embed}"])
     ds = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=12000, seed=3300)
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device))
     torch.manual_seed(3)
@@ -900,6 +903,9 @@ def test_decoder_graph_capture_equals_eager(device):
         g = torch.cat([p.grad.reshape(-1) for n, p in module.named_parameters()
                        if p.grad is not None and "backbone" not in n])
         results.append((float(total.detach()), g.clone()))
+        if level_embed:
+            ge = module.model.level_embed.weight.grad
+            assert ge is not None and float(ge.abs().sum()) > 0
     assert abs(results[0][0] - results[1][0]) <= 1e-5 * abs(results[0][0])
     assert rel_err(results[1][1], results[0][1]) < 1e-4
 
@@ -954,6 +960,55 @@ def test_flat_adamw_state_dict_round_trip_and_guards(device):
         oa.zero_grad(set_to_none=True)
     oa.zero_grad()
     assert float(oa.flat_grad.abs().sum()) == 0.0 and all(float(p.grad.abs().sum()) == 0.0 for p in pa)
+
+
+def test_flat_adamw_resumes_from_a_torch_adamw_checkpoint_and_guards_its_views(device):
+    """A torch.optim.AdamW state_dict (the reference's checkpoints): per-parameter moments land in the flat buffers and
+    the next step equals torch's; the caller's dict is left alone; a parameter moved after construction is refused."""
+    from unscene3d_amd.optim import FlatAdamW
+
+    torch.manual_seed(2)
+    shapes = [(19, 3), (7,), (64, 32)]
+    pb = [torch.nn.Parameter(torch.randn(s, device=device)) for s in shapes]
+    ob = torch.optim.AdamW(pb, lr=1e-2, weight_decay=0.01, fused=True)
+    for it in range(3):
+        for b in pb:
+            b.grad = torch.randn_like(b)
+        ob.step()
+    sd = ob.state_dict()
+    keys = set(sd.keys())
+    pa = [torch.nn.Parameter(p.detach().clone()) for p in pb]
+    oa = FlatAdamW(pa, lr=1e-2, weight_decay=0.01)
+    oa.load_state_dict(sd)
+    assert set(sd.keys()) == keys and len(sd["state"]) == 3          # caller's dict untouched
+    assert oa.steps == 3 and float(oa.exp_avg.abs().sum()) > 0
+    for a, b in zip(pa, pb):
+        g = torch.randn_like(a)
+        a.grad.copy_(g)
+        b.grad = g.clone()
+    oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), float((a - b).abs().max())
+    pa[1].data = pa[1].data.clone()                                  # what module.to()/.float() would do
+    with pytest.raises(RuntimeError, match="no longer aliases"):
+        oa.step()
+
+
+def test_decoder_graphs_refuse_parameters_moved_after_capture(device):
+    """Graph capture bakes parameter addresses in: building FlatAdamW (which re-points p.data) AFTER
+    enable_decoder_graphs must raise at the next replay instead of silently reading stale weights."""
+    from unscene3d_amd.graphs import capture_passes
+    from unscene3d_amd.optim import FlatAdamW
+
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(32, 32).to(device)
+    x = torch.randn(8, 32, device=device, requires_grad=True)
+    (fn,) = capture_passes([lin], [(x,)])
+    y = fn(x)
+    y.sum().backward()
+    FlatAdamW(list(lin.parameters()), lr=1e-3)
+    with pytest.raises(RuntimeError, match="storage moved after capture"):
+        fn(x)
 
 
 def test_scene_prefetcher_hands_over_prepared_batches(device):

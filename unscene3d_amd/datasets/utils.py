@@ -108,7 +108,7 @@ def freemask_voxelize(batch, ignore_label, voxel_size, mode, ignore_class_thresh
             segment2label.append(t[first][:, :-1])
         target = get_instance_freemasks(tables, list_segments=segment2label)
         for i in range(len(target)):
-            target[i]["point2segment"] = tables[i][:, -1]
+            target[i]["point2segment"] = tables[i][:, -1].contiguous()   # a row-gather index: the kernels take dense i64
         full = [m if isinstance(m, torch.Tensor) else torch.as_tensor(np.asarray(m)) for m in original_freemasks]
         target_full = get_instance_freemasks(full)
         for i in range(len(target_full)):

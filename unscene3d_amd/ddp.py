@@ -47,6 +47,13 @@ class BucketedGradReducer:
     Every rank issues the collectives in the same order whatever the timing: eligible buckets (every parameter reports)
     strictly from the last one to the first — the order backward finishes them — and the rest, in index order, in
     `finish()`.  A bucket that is not complete when backward ends is simply reduced in `finish()`, in that same order.
+
+    The report counts depend on data-dependent paths (a scene with fewer voxels than a level's sample size runs that
+    decoder pass eagerly and reports, a graph-replayed pass does not), so the ranks AGREE on the learned state after
+    the first step: `expected` is the maximum over ranks and a bucket is eligible only if every one of its parameters
+    reports on every rank with the same count.  A gradient write that arrives after its bucket's all-reduce was
+    started (more reports than learned) would race with the collective; it is detected, exchanged between the ranks
+    with the next step's collectives and raised on every rank (`RuntimeError`) instead of corrupting the weights.
     """
 
     def __init__(self, params, flat, world_size: int, bucket_bytes: int = 24 << 20):
@@ -74,6 +81,7 @@ class BucketedGradReducer:
         self.order, self.cursor = [], 0              # eligible buckets, last first
         self.handles, self.launched = [], []
         self.started_during_backward = 0
+        self._late, self._late_flag, self._late_handle = False, None, None
         self._hooks = [p.register_post_accumulate_grad_hook(self.on_grad) for p in self.params]
 
     def install(self):
@@ -91,6 +99,8 @@ class BucketedGradReducer:
             return
         self.counts[i] += 1
         if self.expected is not None:
+            if self.launched and self.launched[self.bucket_of[id(param)]]:
+                self._late = True        # the kernels of this write race with the bucket's collective already in flight
             self._advance()
 
     def _complete(self, b):
@@ -109,10 +119,26 @@ class BucketedGradReducer:
 
     def finish(self):
         """After backward: reduce what has not been started (same order on every rank), wait, average."""
+        import torch.distributed as dist
         self.started_during_backward = sum(self.launched)
+        if self._late_handle is not None:        # last step's flag: long complete by now, no stall
+            self._late_handle.wait()
+            self._late_handle = None
+            if float(self._late_flag.item()) > 0:
+                raise RuntimeError("BucketedGradReducer: on some rank a gradient was written after its bucket's "
+                                   "all-reduce had started (more writes per step than learned in the first step); "
+                                   "the previous step's gradients are unreliable — rebuild the reducer or set "
+                                   "USC3D_OVERLAP_ALLREDUCE=0")
         if self.expected is None:
-            self.expected = list(self.counts)
-            eligible = [b for b in range(len(self.bounds)) if all(self.expected[i] > 0 for i in self.members[b])]
+            # agree across ranks: max count, and eligibility only where min == max > 0 on every rank
+            cnt = torch.tensor(self.counts, dtype=torch.int64, device=self.flat.device)
+            lo, hi = cnt.clone(), cnt.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            lo, hi = lo.tolist(), hi.tolist()
+            self.expected = hi
+            eligible = [b for b in range(len(self.bounds))
+                        if all(lo[i] > 0 and lo[i] == hi[i] for i in self.members[b])]
             self.order = sorted(eligible, reverse=True)
         for b in self.order[self.cursor:]:
             self._launch(b)
@@ -120,6 +146,11 @@ class BucketedGradReducer:
         for b in range(len(self.bounds)):
             if not self.launched[b]:
                 self._launch(b)
+        if self._late_flag is None:
+            self._late_flag = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
+        self._late_flag.fill_(1.0 if self._late else 0.0)
+        self._late = False
+        self._late_handle = dist.all_reduce(self._late_flag, op=dist.ReduceOp.MAX, async_op=True)
         for h in self.handles:
             h.wait()
         self.flat.div_(self.world)

@@ -32,8 +32,21 @@ class _Runner:
         self.static_grad_out = None
         self.static_grad_in = None
         self.grad_ptrs = None
+        self.data_ptrs = None
+
+    def check_param_data(self):
+        """The captured kernels hold each parameter's device address: a parameter whose storage moved after capture
+        (module.to()/.float(), an optimizer that re-points p.data into a flat buffer, load_state_dict(assign=True))
+        would be read from freed memory while the optimizer updates storage the graphs never see."""
+        for p, ptr in zip(self.params, self.data_ptrs):
+            if p.data_ptr() != ptr:
+                raise RuntimeError(
+                    "graphed decoder pass: a parameter's storage moved after capture; build the optimizer (FlatAdamW "
+                    "re-points p.data) and finish .to()/.float() BEFORE enable_decoder_graphs(), or call "
+                    "disable_decoder_graphs() and capture again")
 
     def check_param_grads(self):
+        self.check_param_data()
         for p, ptr in zip(self.params, self.grad_ptrs):
             if p.grad is None or p.grad.data_ptr() != ptr:
                 raise RuntimeError(
@@ -44,6 +57,7 @@ class _Runner:
 class _GraphedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, *inputs):
+        runner.check_param_data()
         for s, a in zip(runner.static_in, inputs):
             if s.data_ptr() != a.data_ptr():
                 s.copy_(a)
@@ -116,5 +130,6 @@ def capture_passes(modules, sample_inputs, warmup_iters: int = 3):
                 torch._foreach_add_(dst, src)
         r.static_grad_in = list(grads[:n_in])
         r.grad_ptrs = [p.grad.data_ptr() for p in r.params]
+        r.data_ptrs = [p.data_ptr() for p in r.params]
     torch.cuda.synchronize()
     return [GraphedPass(r) for r in runners]

@@ -139,8 +139,16 @@ class SetCriterion(nn.Module):
                         per_level[l][b] = C[l]
         flat = [C for Cs in per_level for C in Cs]
         widths = [C.shape[1] for C in flat]
-        host = torch.cat(flat, dim=1).cpu()                                   # the single D2H of the step
-        pieces = torch.split(host, widths, dim=1)
+        costs = torch.cat(flat, dim=1)
+        # the target labels ride along as one extra row (class ids are exact in fp32), so that the batched losses
+        # need no device->host copy of their own
+        labels = torch.cat([t["labels"].reshape(-1) for t in targets]).to(costs)
+        row = torch.zeros((1, costs.shape[1]), dtype=costs.dtype, device=costs.device)
+        row[0, :labels.shape[0]] = labels
+        host = torch.cat([costs, row], dim=0).cpu()                           # the single D2H of the step
+        lab = host[-1, :labels.shape[0]].to(torch.int64)
+        self._labels_host = list(torch.split(lab, [t["labels"].numel() for t in targets]))
+        pieces = torch.split(host[:-1], widths, dim=1)
         out, q = [], 0
         for Cs in per_level:
             out.append([m.solve(pieces[q + b]) for b in range(len(Cs))])
@@ -156,10 +164,10 @@ class SetCriterion(nn.Module):
         logits = torch.stack([lv["pred_logits"] for lv in levels]).float()                # [L,B,Q,C]
         Q = logits.shape[2]
         tc = torch.full((L, B, Q), self.num_classes, dtype=torch.int64)
+        labels_host = self._labels_host            # filled by match_all_levels from the step's single D2H copy
         for l in range(L):
             for b, (src, J) in enumerate(all_indices[l]):
-                tc[l, b, src] = targets[b]["labels"].cpu()[J] if targets[b]["labels"].device.type != "cpu" \
-                    else targets[b]["labels"][J]
+                tc[l, b, src] = labels_host[b][J]
         tc = tc.to(dev)
         nll = F.cross_entropy(logits.reshape(L * B * Q, -1), tc.reshape(-1), self.empty_weight, ignore_index=253,
                               reduction="none").reshape(L, -1)

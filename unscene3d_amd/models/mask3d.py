@@ -99,8 +99,10 @@ class Mask3D(nn.Module):
 
     # ------------------------------------------------------------------
     def _eager_pass(self, dec, i):
+        # the embedding MODULE, not a slice of its weight: the pass must own the parameter so that graph capture
+        # differentiates with respect to it and reads its live storage (a slice taken here would be a constant)
         return _DecoderPass(self.lin_squeeze[dec][i], self.cross_attention[dec][i], self.self_attention[dec][i],
-                            self.ffn_attention[dec][i], self.level_embed.weight[i] if self.use_level_embed else None,
+                            self.ffn_attention[dec][i], self.level_embed if self.use_level_embed else None, i,
                             self.num_heads)
 
     def _decoder_pass(self, decoder_counter, dec, i):
@@ -370,15 +372,15 @@ class _DecoderPass(nn.Module):
     (Mask3D.enable_decoder_graphs): ~45 forward and ~90 backward launches per pass become one graph launch
     each, removing most of the host launch overhead of the 12 passes."""
 
-    def __init__(self, squeeze, cross, self_attn, ffn, level_embed, num_heads):
+    def __init__(self, squeeze, cross, self_attn, ffn, level_embed, level, num_heads):
         super().__init__()
         self.squeeze, self.cross, self.self_attn, self.ffn = squeeze, cross, self_attn, ffn
-        self.level_embed, self.num_heads = level_embed, num_heads
+        self.level_embed, self.level, self.num_heads = level_embed, level, num_heads   # nn.Embedding or None
 
     def forward(self, queries, query_pos, batched_aux, batched_attn, batched_pos_enc):
         src = self.squeeze(batched_aux.permute(1, 0, 2))
         if self.level_embed is not None:
-            src = src + self.level_embed
+            src = src + self.level_embed.weight[self.level]          # reference mask3d.py:353-354
         out = self.cross(queries.permute(1, 0, 2), src, memory_mask=None, memory_mask_bsl=batched_attn,
                          memory_key_padding_mask=None, pos=batched_pos_enc.permute(1, 0, 2), query_pos=query_pos)
         out = self.self_attn(out, tgt_mask=None, tgt_key_padding_mask=None, query_pos=query_pos)

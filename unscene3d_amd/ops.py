@@ -310,8 +310,13 @@ GRAD_WRITTEN_HOOK = None   # callable(param), set by ddp.BucketedGradReducer: "t
 
 
 def _grad_target(param):
+    """p.grad when the backward kernels may add into it directly, else None (the gradient is then returned to
+    autograd).  Never when somebody else listens for the gradient through autograd: tensor hooks, or
+    post-accumulate hooks (torch DDP, FSDP, user hooks) unless they belong to this package's own reducer, which is
+    told about in-place writes through GRAD_WRITTEN_HOOK."""
     if GRAD_IN_PLACE and isinstance(param, torch.nn.Parameter) and param.is_leaf and param.grad is not None \
-            and param.grad.is_contiguous() and not param._backward_hooks:
+            and param.grad.is_contiguous() and not param._backward_hooks \
+            and (GRAD_WRITTEN_HOOK is not None or not getattr(param, "_post_accumulate_grad_hooks", None)):
         return param.grad
     return None
 

@@ -45,11 +45,29 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(self.flat_param)
         self.exp_avg_sq = torch.zeros_like(self.flat_param)
         self.steps = 0
+        self._params = params
+
+    def _check_views(self):
+        """Every p.data / p.grad must still be the view handed out in __init__ (module.to(), .float(),
+        zero_grad(set_to_none=True) or a load_state_dict(assign=True) after construction would detach them, and the
+        kernel would then update buffers nobody reads)."""
+        lo, esz = self.flat_param.data_ptr(), self.flat_param.element_size()
+        glo = self.flat_grad.data_ptr()
+        off = 0
+        for p in self._params:
+            if p.data_ptr() != lo + off * esz:
+                raise RuntimeError("FlatAdamW: a parameter no longer aliases the flat parameter buffer (moved or "
+                                   "re-allocated after the optimizer was built); rebuild the optimizer")
+            if p.grad is None or p.grad.data_ptr() != glo + off * esz:
+                raise RuntimeError("FlatAdamW: a parameter's .grad no longer aliases the flat gradient buffer; keep "
+                                   "gradients allocated (zero_grad(set_to_none=False))")
+            off += p.numel()
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         g = self.param_groups[0]
+        self._check_views()
         self.steps += 1
         b1, b2 = g["betas"]
         check(lib.usc_adamw_step(_ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
@@ -68,9 +86,34 @@ class FlatAdamW(torch.optim.Optimizer):
         return d
 
     def load_state_dict(self, state_dict):
+        """Accepts this class's own state (key "flat") and the state of a torch.optim.AdamW over the same parameter
+        list (the reference's checkpoints, trainer/trainer.py:953-966): its per-parameter exp_avg / exp_avg_sq / step
+        are copied into the flat moment buffers.  The caller's dict is not modified."""
+        state_dict = dict(state_dict)
         flat = state_dict.pop("flat", None)
+        per_param = state_dict.get("state") or {}
+        state_dict["state"] = {}
         super().load_state_dict(state_dict)
         if flat is not None:
             self.exp_avg.copy_(flat["exp_avg"])
             self.exp_avg_sq.copy_(flat["exp_avg_sq"])
             self.steps = int(flat["steps"])
+        elif per_param:
+            ids = [i for grp in state_dict["param_groups"] for i in grp["params"]]
+            if len(ids) != len(self._params):
+                raise RuntimeError("FlatAdamW.load_state_dict: the checkpoint covers a different parameter list")
+            steps, off = set(), 0
+            for i, p in zip(ids, self._params):
+                st = per_param.get(i)
+                n = p.numel()
+                if st is not None:
+                    if st["exp_avg"].numel() != n:
+                        raise RuntimeError("FlatAdamW.load_state_dict: moment shape does not match its parameter")
+                    self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(st["step"]))
+                off += n
+            if len(steps) > 1:
+                raise RuntimeError("FlatAdamW.load_state_dict: parameters with different step counts (one shared "
+                                   "bias-correction step is kept)")
+            self.steps = steps.pop() if steps else 0

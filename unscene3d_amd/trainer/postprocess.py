@@ -103,7 +103,8 @@ def export_instances(output, target_low_res, target_full_res, inverse_maps, raw_
         dev = pred["pred_masks"][bid].device
         masks = pred["pred_masks"][bid].detach().float()
         if train_on_segments:
-            masks = ops.gather_rows(masks.contiguous(), target_low_res[bid]["point2segment"].to(dev))
+            p2s = torch.as_tensor(target_low_res[bid]["point2segment"]).to(dev, torch.int64).contiguous()
+            masks = ops.gather_rows(masks.contiguous(), p2s)
         if general.use_dbscan:
             n = masks.shape[0]
             coords = torch.as_tensor(raw_coords[offset:offset + n], dtype=torch.float32, device=dev)
@@ -114,8 +115,8 @@ def export_instances(output, target_low_res, target_full_res, inverse_maps, raw_
         else:
             scores, masks, classes, heatmap = get_mask_and_scores(logits[bid], masks, logits.shape[1],
                                                                   num_classes - 1, general.topk_per_image)
-        inv = torch.as_tensor(inverse_maps[bid], dtype=torch.int64, device=dev)
-        seg_full = torch.as_tensor(target_full_res[bid]["point2segment"], dtype=torch.int64, device=dev)
+        inv = torch.as_tensor(inverse_maps[bid], dtype=torch.int64, device=dev).contiguous()
+        seg_full = torch.as_tensor(target_full_res[bid]["point2segment"], dtype=torch.int64, device=dev).contiguous()
         csr = ops.segment_csr(seg_full, int(seg_full.max()) + 1) if eval_on_segments else None
         masks = get_full_res_mask(masks, inv, csr)
         order = scores.cpu().sort(descending=True)
