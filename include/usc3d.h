@@ -312,6 +312,13 @@ int usc_segment_mean_nonzero(const float* feats, int32_t d,
                              const int64_t* order, const int64_t* seg_off,
                              int64_t S, float* out, int64_t* nonzero_cnt,
                              usc_stream_t s);
+/* Same with the per-channel MAX over the non-zero rows (aggregation_mode 'max',
+ * unscene3d_pseudo_main.py:366: valid_segment_feats.max(0)[0]); segments without
+ * a non-zero row give 0. */
+int usc_segment_max_nonzero(const float* feats, int32_t d,
+                            const int64_t* order, const int64_t* seg_off,
+                            int64_t S, float* out, int64_t* nonzero_cnt,
+                            usc_stream_t s);
 
 /* Masked cross attention of the mask decoder, all heads at once:
  *   o = softmax(q k^T / sqrt(16) + mask) v   per (batch, head), head dim 16, L <= 128 queries,

@@ -10,6 +10,33 @@ import torch.nn.functional as F
 from scipy.linalg import eigh
 
 
+def aggregate_features(feats, seg, conn, mode="mean"):
+    """N1 (reference pseudo_masks/unscene3d_pseudo_main.py:350-402): per-segment mean (or max) over the rows that have
+    a non-zero entry (:362-366); a segment without one gets the mean of the non-zero aggregated features of the
+    segments connected to `zero_segments[0]` — the FIRST zero segment's neighbours for every zero segment (:387) — or
+    the mean over all aggregated rows when none qualifies (:397), each fill visible to the next one.
+    numpy f32 in torch's reduction conventions (pairwise-summed means), -> (f32[S,d], unique segment ids)."""
+    feats = np.asarray(feats, np.float32)
+    seg = np.asarray(seg)
+    conn = np.asarray(conn)
+    uniq = np.unique(seg)
+    valid = np.any(feats != 0, axis=-1)
+    agg = np.zeros((len(uniq), feats.shape[1]), np.float32)
+    for i, s in enumerate(uniq):
+        rows = feats[valid & (seg == s)]
+        if len(rows):
+            agg[i] = rows.max(0) if mode == "max" else rows.mean(0, dtype=np.float32)
+    zero = uniq[np.all(agg == 0, axis=-1)]
+    if len(zero):
+        nbr = conn[conn[:, 0] == zero[0]][:, 1]
+        nbr_idx = np.array([int(np.nonzero(uniq == s)[0][0]) for s in nbr], dtype=np.int64)
+        for z in zero:
+            cand = agg[nbr_idx] if len(nbr_idx) else agg[:0]
+            cand = cand[np.any(cand != 0, axis=-1)]
+            agg[int(np.nonzero(uniq == z)[0][0])] = (cand if len(cand) else agg).mean(0, dtype=np.float32)
+    return agg, uniq
+
+
 def cosine_sim(k, q):
     eps = 10e-10
     kf = k / (k.norm(dim=1, keepdim=True) + eps)

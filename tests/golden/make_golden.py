@@ -6,6 +6,8 @@ not installed: SURVEY.md Appendix A), feeds them seeded inputs and stores inputs
 .npz fixtures next to this script.  Nothing from /root/reference is copied; the fixtures are data.
 
     python tests/golden/make_golden.py            # criterion / posenc / decoder_layers fixtures
+    python tests/golden/make_golden.py decoder_pass   # one decoder pass, head-shared mask, forward + backward
+    python tests/golden/make_golden.py aggregate  # N1 aggregate_features (mean / max, zero-segment fill)
     python tests/golden/make_golden.py ncut       # NCut fixtures (separate interpreter: different stubs)
     python tests/golden/make_golden.py export     # eval/export post-processing fixtures (trainer.eval_instance_step)
     python tests/golden/make_golden.py dataset    # self-train mask merge + validation-mode scene reader fixtures
@@ -154,6 +156,50 @@ def make_decoder_layers(mods):
     print("decoder layers ok")
 
 
+def make_decoder_pass(mods):
+    """One decoder pass of the reference (CrossAttentionLayer -> SelfAttentionLayer -> FFNLayer, models/mask3d.py:491-651)
+    in the PRODUCT shape of the mask: one bool[B, K, Q] mask shared by all heads, repeated per head exactly like
+    mask3d.py:349 (`repeat_interleave(num_heads, dim=0).permute((0, 2, 1))`), forward AND backward.  Weights are the
+    ones already stored in decoder_layers.npz; inputs are fp16-representable so that they store compactly."""
+    m3 = mods["mask3d"]
+    z = np.load(os.path.join(HERE, "decoder_layers.npz"))
+    d, H, Q, K, B = 128, 8, 40, 160, 2
+    ca, sa, ffn = m3.CrossAttentionLayer(d, H), m3.SelfAttentionLayer(d, H), m3.FFNLayer(d, 256)
+    for name, mod in (("ca", ca), ("sa", sa), ("ffn", ffn)):
+        mod.load_state_dict({k[len(name) + 1:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "/")})
+    g = torch.Generator().manual_seed(21)
+    h16 = lambda *shape: torch.randn(*shape, generator=g).half().float()
+    tgt, mem, pos, qpos, w = h16(Q, B, d), h16(K, B, d), h16(K, B, d), h16(Q, B, d), h16(Q, B, d)
+    bsl = torch.rand(B, K, Q, generator=g) < 0.4
+    bsl[:, 0, :] = False                       # every query keeps one key
+    bsl[0, :, 3] = True                        # ... except these two, which the decoder then un-masks (mask3d.py:346)
+    bsl[1, :, 17] = True
+    bsl.permute(0, 2, 1)[bsl.sum(1) == K] = False
+    bsl[1, 100:, :] = True                     # scene 1 shorter than the sample size: padded keys masked (:316-323)
+    leaves = {"tgt": tgt, "mem": mem, "pos": pos, "qpos": qpos}
+    for v in leaves.values():
+        v.requires_grad_()
+    mask = bsl.repeat_interleave(H, dim=0).permute(0, 2, 1)
+    o1 = ca(tgt, mem, memory_mask=mask, memory_key_padding_mask=None, pos=pos, query_pos=qpos)
+    o2 = sa(o1, tgt_mask=None, tgt_key_padding_mask=None, query_pos=qpos)
+    o3 = ffn(o2)
+    (o3 * w).sum().backward()
+    out = {k: v.detach().numpy().astype(np.float16) for k, v in leaves.items()}
+    out["w"] = w.numpy().astype(np.float16)
+    out["mask_bsl"] = np.packbits(bsl.numpy(), axis=2)
+    out["shape"] = np.array([Q, K, B, H, d])
+    out.update(t2n({"o1": o1, "o3": o3, "g_tgt": tgt.grad, "g_mem": mem.grad, "g_qpos": qpos.grad}))
+    for name, mod, keys in (("ca", ca, ("multihead_attn.in_proj_weight", "multihead_attn.in_proj_bias",
+                                        "multihead_attn.out_proj.bias", "norm.weight", "norm.bias")),
+                            ("sa", sa, ("self_attn.in_proj_bias", "norm.weight")),
+                            ("ffn", ffn, ("linear1.bias", "linear2.bias", "norm.bias"))):
+        params = dict(mod.named_parameters())
+        for k in keys:
+            out[f"grad/{name}/{k}"] = params[k].grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "decoder_pass.npz"), **out)
+    print("decoder pass ok", {k: v.shape for k, v in out.items() if k.startswith("g")})
+
+
 def import_reference_ncut():
     """pseudo_masks/unscene3d_pseudo_main.py with stubs (recipe 2). Run in a fresh
     interpreter state: its `models`/`datasets`/`utils.*` imports are stubbed, unlike recipe 1."""
@@ -246,6 +292,40 @@ def make_ncut(ref):
         gaps = [float((w[1] - w[0]) / max(w[1], 1e-300)) for (_, _, _, w) in trace]
         print("ncut", name, "S", S, "objects placed", placed, "masks", masks.shape, "rel gaps", np.round(gaps, 4))
     np.savez_compressed(os.path.join(HERE, "ncut.npz"), **out)
+
+
+def make_aggregate(ref):
+    """N1: `aggregate_features` (pseudo_masks/unscene3d_pseudo_main.py:350-402) on seeded point features: segment ids
+    with gaps, ~20 % all-zero (invalid) rows, segments whose rows are ALL zero — filled from the connected segments of
+    `zero_segments[0]` for every zero segment (the :387 quirk), or from the global mean when that one has no valid
+    neighbour — in both aggregation modes."""
+    from types import SimpleNamespace as NS
+    out = {}
+    for case, first_zero_connected in (("neigh", True), ("global", False)):
+        rng = np.random.default_rng(77 if first_zero_connected else 78)
+        S, N, d = 48, 3000, 24
+        ids = np.sort(rng.choice(np.arange(5, 400), S, replace=False)).astype(np.int64)   # ids with gaps
+        seg = ids[rng.integers(0, S, N)]
+        feats = rng.standard_normal((N, d)).astype(np.float32)
+        feats[rng.random(N) < 0.2] = 0.0                                                  # invalid rows
+        zero_segs = ids[[4, 17, 30]]                                                      # every row invalid
+        feats[np.isin(seg, zero_segs)] = 0.0
+        pairs = set()
+        for a in range(S):                                                                # ring + a few chords
+            for b in (a + 1, a + 5):
+                pairs.add((ids[a], ids[b % S])); pairs.add((ids[b % S], ids[a]))
+        if not first_zero_connected:                                                      # isolate zero_segments[0]
+            pairs = {(a, b) for (a, b) in pairs if a != zero_segs[0] and b != zero_segs[0]}
+        conn = np.array(sorted(pairs), dtype=np.int64)
+        out[f"{case}/feats"], out[f"{case}/seg"], out[f"{case}/conn"] = feats, seg, conn
+        for mode in ("mean", "max"):
+            cfg = NS(freemask=NS(aggregation_mode=mode))
+            agg, uniq = ref.aggregate_features(torch.from_numpy(feats), torch.from_numpy(seg), torch.from_numpy(conn), cfg)
+            assert np.array_equal(uniq.numpy(), ids)
+            out[f"{case}/{mode}"] = agg.numpy()
+        out[f"{case}/uniq"] = ids
+        print("aggregate", case, "zero segments", zero_segs, "conn", conn.shape)
+    np.savez_compressed(os.path.join(HERE, "aggregate.npz"), **out)
 
 
 def import_reference_trainer():
@@ -509,6 +589,10 @@ if __name__ == "__main__":
         make_dataset(import_reference_dataset())
     elif len(sys.argv) > 1 and sys.argv[1] == "export":
         make_export(import_reference_trainer())
+    elif len(sys.argv) > 1 and sys.argv[1] == "decoder_pass":
+        make_decoder_pass(import_reference_models())
+    elif len(sys.argv) > 1 and sys.argv[1] == "aggregate":
+        make_aggregate(import_reference_ncut())
     else:
         mods = import_reference_models()
         make_criterion(mods)

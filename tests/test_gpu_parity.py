@@ -847,33 +847,48 @@ def test_triplane_projection_loss(device):
     logits = torch.randn(T, V, generator=g)
     tgt = (torch.rand(T, V, generator=g) < 0.3).float()
 
-    # torch restatement of noise_robust_loss.py + the two CUDA kernels (cuda_utils_kernel.cu:371-556)
+    # torch restatement of noise_robust_loss.py + the two CUDA kernels (cuda_utils_kernel.cu:371-603)
+    cc = (coords - coords.amin(0)).long()
+    xd, yd, zd = (int(v) for v in cc[:, 1:].max(0)[0])
+    ok = (cc[:, 1] < xd) & (cc[:, 2] < yd) & (cc[:, 3] < zd)
+    x, y, z = cc[ok, 1], cc[ok, 2], cc[ok, 3]
+    views = ((x, y, xd, yd), (x, z, xd, zd), (y, z, yd, zd))
+
     def ref_loss(lg):
-        cc = (coords - coords.amin(0)).long()
-        xd, yd, zd = (int(v) for v in cc[:, 1:].max(0)[0])
-        ok = (cc[:, 1] < xd) & (cc[:, 2] < yd) & (cc[:, 3] < zd)
+        """forward: per-plane sums / (count + 10e-9), BCE on the occupied pixels; returns the plane leaves too"""
         p, t = torch.sigmoid(lg.T)[ok], tgt.T[ok]
-        x, y, z = cc[ok, 1], cc[ok, 2], cc[ok, 3]
-        total, shape = 0.0, 0
-        for a, b, da, db in ((x, y, xd, yd), (x, z, xd, zd), (y, z, yd, zd)):
+        total, shape, leaves = 0.0, 0, []
+        for a, b, da, db in views:
             cell = a * db + b
             n = torch.zeros(da * db).index_add_(0, cell, torch.ones(len(cell)))
-            ps = torch.zeros(da * db, T).index_add_(0, cell, p) / (n[:, None] + 10e-9)
+            ps = (torch.zeros(da * db, T).index_add_(0, cell, p) / (n[:, None] + 10e-9)).detach().requires_grad_()
             ts = torch.zeros(da * db, T).index_add_(0, cell, t) / (n[:, None] + 10e-9)
             l = torch.nn.functional.binary_cross_entropy(ps.clamp(0, 1), ts.clamp(0, 1), reduction="none")
             total = total + l[n > 0].sum()
             shape += T * int((n > 0).sum())
-        return total, shape
+            leaves.append((ps, cell))
+        return total, shape, leaves
 
-    exp, exp_shape = ref_loss(logits)
+    exp, exp_shape, leaves = ref_loss(logits)
     mod = ProjectionMaskLoss(directions="xyz")
     lg = logits.to(device).requires_grad_()
     loss, shape = mod(lg, tgt.to(device), coords.to(device))
     assert shape == exp_shape
     assert abs(float(loss) - float(exp)) / float(exp) < 1e-4
     loss.backward()
-    # backward follows the reference kernel: mean of the non-zero plane gradients (not the analytic gradient)
-    assert lg.grad.shape == logits.shape and bool(torch.isfinite(lg.grad).all()) and float(lg.grad.abs().sum()) > 0
+    # backward of the reference (noise_robust_loss.py:62-73 -> cuda_utils_kernel.cu:496-556): the plane gradients
+    # dL/d(plane mean) are handed to every voxel of the pixel UN-normalised and averaged over the views whose
+    # gradient is non-zero (not the analytic gradient of the mean); voxels outside the planes get 0; autograd then
+    # chains through the sigmoid
+    exp.backward()
+    g_planes = [ps.grad[cell] for ps, cell in leaves]                       # [V_ok, T] per view
+    nnz = sum((g != 0).float() for g in g_planes)
+    s_grads = torch.zeros(V, T)
+    s_grads[ok] = torch.where(nnz > 0, sum(g_planes) / nnz.clamp(min=1), torch.zeros(()))
+    sg = torch.sigmoid(logits.T)
+    exp_grad = (s_grads * sg * (1 - sg)).T
+    assert lg.grad.shape == logits.shape
+    assert float(exp_grad.abs().sum()) > 0 and rel_err(lg.grad, exp_grad) < 1e-4, rel_err(lg.grad, exp_grad)
 
 
 @pytest.mark.parametrize("level_embed", [False, True])

@@ -55,3 +55,14 @@ def test_oracle_loop_reproduces_reference_masks_on_irregular_scene():
     ref = np.unpackbits(z[f"{name}/masks"], axis=1)[:int(z[f"{name}/n_masks"]), :S].astype(bool)
     assert masks.shape == ref.shape
     assert np.array_equal(masks, ref)
+
+
+def test_oracle_aggregate_features_matches_reference():
+    """N1 restatement vs the reference's own aggregate_features (tests/golden/aggregate.npz): gapped segment ids,
+    invalid rows, all-zero segments filled from `zero_segments[0]`'s neighbours (:387) or from the global mean."""
+    z = np.load(os.path.join(os.path.dirname(GOLD), "aggregate.npz"))
+    for case in ("neigh", "global"):
+        for mode in ("mean", "max"):
+            agg, uniq = NR.aggregate_features(z[f"{case}/feats"], z[f"{case}/seg"], z[f"{case}/conn"], mode)
+            assert np.array_equal(uniq, z[f"{case}/uniq"])
+            np.testing.assert_allclose(agg, z[f"{case}/{mode}"], rtol=2e-6, atol=1e-7)

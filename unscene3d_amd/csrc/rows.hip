@@ -440,36 +440,57 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
   }
 }
 
+// mode bit 0: use only rows with a non-zero entry; bit 1: per-channel MAX instead of the mean (N1 'max' mode)
 __global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* __restrict__ src, int c,
                                                               const int64_t* __restrict__ order,
                                                               const int64_t* __restrict__ seg_off, int64_t S,
-                                                              int only_nonzero, float* __restrict__ out,
+                                                              int mode, float* __restrict__ out,
                                                               int64_t* __restrict__ nz_cnt) {
-  // one wave per segment; lanes stride the channels; rows summed in CSR order
+  // one wave per segment; lanes stride the channels (up to 8 chunks of 64 held in registers, more in further
+  // sweeps); rows visited once per sweep in CSR order
   const int lane = threadIdx.x & 63;
   const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= S) return;
+  const bool only_nonzero = mode & 1, take_max = mode & 2;
   const int64_t b = seg_off[s], e = seg_off[s + 1];
-  for (int c0 = 0; c0 < c; c0 += 64) {
-    const int ch = c0 + lane;
-    float acc = 0.f;
+  constexpr int CH = 8;
+  for (int base = 0; base < c; base += 64 * CH) {
+    float acc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc[j] = take_max ? -INFINITY : 0.f;
     int64_t cnt = 0;
     for (int64_t q = b; q < e; ++q) {
-      const int64_t r = order[q];
+      const float* row = src + order[q] * (int64_t)c;
+      float v[CH];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int ch = base + 64 * j + lane;
+        v[j] = ch < c ? row[ch] : 0.f;
+      }
       bool use = true;
       if (only_nonzero) {
         // valid row = torch.any(features != 0, dim=-1)  (unscene3d_pseudo_main.py:362)
         bool nz = false;
-        for (int cc = lane; cc < c; cc += 64) nz |= src[r * c + cc] != 0.f;
+        if (c <= 64 * CH) {
+#pragma unroll
+          for (int j = 0; j < CH; ++j) nz |= v[j] != 0.f;
+        } else {
+          for (int cc = lane; cc < c; cc += 64) nz |= row[cc] != 0.f;
+        }
         use = __any(nz);
       }
       if (use) {
         ++cnt;
-        if (ch < c) acc += src[r * c + ch];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) acc[j] = take_max ? fmaxf(acc[j], v[j]) : acc[j] + v[j];
       }
     }
-    if (ch < c) out[s * c + ch] = cnt > 0 ? acc / (float)cnt : 0.f;
-    if (c0 == 0 && lane == 0 && nz_cnt) nz_cnt[s] = cnt;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int ch = base + 64 * j + lane;
+      if (ch < c) out[s * c + ch] = cnt > 0 ? (take_max ? acc[j] : acc[j] / (float)cnt) : 0.f;
+    }
+    if (base == 0 && lane == 0 && nz_cnt) nz_cnt[s] = cnt;
   }
 }
 
@@ -751,6 +772,17 @@ int usc_segment_mean_nonzero(const float* feats, int32_t d, const int64_t* order
   hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, as_stream(s), feats, (int)d,
                      order, seg_off, S, 1, out, nonzero_cnt);
   USC_CHECK_LAUNCH("usc_segment_mean_nonzero");
+  return USC_OK;
+}
+
+int usc_segment_max_nonzero(const float* feats, int32_t d, const int64_t* order, const int64_t* seg_off, int64_t S,
+                            float* out, int64_t* nonzero_cnt, usc_stream_t s) {
+  USC_REQUIRE(d >= 1 && S >= 0, "usc_segment_max_nonzero: bad sizes");
+  if (S == 0) return USC_OK;
+  USC_REQUIRE(feats && order && seg_off && out, "usc_segment_max_nonzero: null pointer");
+  hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, as_stream(s), feats, (int)d,
+                     order, seg_off, S, 3, out, nonzero_cnt);
+  USC_CHECK_LAUNCH("usc_segment_max_nonzero");
   return USC_OK;
 }
 

@@ -41,15 +41,15 @@ class BucketedGradReducer:
     package write parameter gradients straight into `p.grad` (ops.GRAD_IN_PLACE) and report each write through
     `ops.GRAD_WRITTEN_HOOK`; parameters that still go through autograd report through a post-accumulate hook.  The
     first step only LEARNS how many reports each parameter produces per step (shared decoder weights are written by
-    twelve passes, graph-captured passes report nothing); from the second step on a bucket whose parameters all
+    twelve passes — eager kernels and graph replays (graphs.py) both report); from the second step on a bucket whose parameters all
     reached their learned count is reduced asynchronously while backward continues.
 
     Every rank issues the collectives in the same order whatever the timing: eligible buckets (every parameter reports)
     strictly from the last one to the first — the order backward finishes them — and the rest, in index order, in
     `finish()`.  A bucket that is not complete when backward ends is simply reduced in `finish()`, in that same order.
 
-    The report counts depend on data-dependent paths (a scene with fewer voxels than a level's sample size runs that
-    decoder pass eagerly and reports, a graph-replayed pass does not), so the ranks AGREE on the learned state after
+    The report counts may still depend on data-dependent paths (a skipped level, a pass that falls back to eager
+    kernels with a different number of launches per parameter), so the ranks AGREE on the learned state after
     the first step: `expected` is the maximum over ranks and a bucket is eligible only if every one of its parameters
     reports on every rank with the same count.  A gradient write that arrives after its bucket's all-reduce was
     started (more reports than learned) would race with the collective; it is detected, exchanged between the ranks

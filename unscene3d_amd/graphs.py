@@ -72,6 +72,11 @@ class _GraphedFn(torch.autograd.Function):
         if r.static_grad_out.data_ptr() != g.data_ptr():
             r.static_grad_out.copy_(g)
         r.bwd_graph.replay()
+        # the replayed graph added into every parameter's .grad: report it like the eager kernels do, so that a
+        # gradient reducer never starts a bucket while replays that write into it are still to come (and so that
+        # ranks running the same pass eagerly / graphed count the same number of writes)
+        from . import ops
+        ops._grad_written(*r.params)
         out = [None] * (1 + len(r.static_in))
         for j, gi in zip(r.grad_in_idx, r.static_grad_in):
             out[1 + j] = None if gi is None else gi.detach()

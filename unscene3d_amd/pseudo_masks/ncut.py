@@ -137,16 +137,17 @@ def segment_ids_to_mask(selected_ids, unique_segments):
 def aggregate_features(encoded_features, segment_ids, seg_connectivity, aggregation_mode="mean"):
     """Per-segment mean of the non-zero feature rows, zero segments filled from connected segments
     (reference :350-402, incl. its use of `zero_segments[0]`'s neighbours for every zero segment)."""
-    if aggregation_mode != "mean":
-        raise NotImplementedError("aggregation_mode 'max' is not used by the published pipeline")
+    if aggregation_mode not in ("mean", "max"):
+        raise ValueError(f"aggregation_mode {aggregation_mode!r}: 'mean' or 'max' (reference :366)")
     dev = encoded_features.device
     unique_segments, inv = torch.unique(segment_ids, return_inverse=True)
     S = unique_segments.shape[0]
     csr = ops.segment_csr(inv.to(torch.int64).contiguous(), S)
     feats = encoded_features.float().contiguous()
     out = torch.empty((S, feats.shape[1]), dtype=torch.float32, device=dev)
-    check(lib.usc_segment_mean_nonzero(feats.data_ptr(), feats.shape[1], csr.order.data_ptr(), csr.seg_off.data_ptr(),
-                                       S, out.data_ptr(), None, ops._stream()), "usc_segment_mean_nonzero")
+    fn = lib.usc_segment_max_nonzero if aggregation_mode == "max" else lib.usc_segment_mean_nonzero
+    check(fn(feats.data_ptr(), feats.shape[1], csr.order.data_ptr(), csr.seg_off.data_ptr(), S, out.data_ptr(), None,
+             ops._stream()), "usc_segment_mean_nonzero")
     agg = out.clone()
     zero = torch.nonzero(torch.all(agg == 0, dim=-1)).reshape(-1)
     if zero.numel():
