@@ -216,6 +216,102 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout,
                      int32_t K, const int32_t* a_idx, const int32_t* b_idx,
                      const int64_t* koff, int64_t n_rows, float* dW, int32_t accumulate, void* ws,
                      int64_t ws_bytes, usc_stream_t s);
+/* Exact scratch need of usc_spconv_wgrad for pair lists of capacity n_rows (the bound
+ * above assumes the maximum split count). */
+int64_t usc_spconv_wgrad_ws_bytes_rows(int32_t K, int32_t cin, int32_t cout,
+                                       int64_t n_rows);
+
+/* ------------------------------------------------------------------------
+ * Native issue path: whole convolutions and "conv -> batch norm (+ residual)
+ * (+ ReLU)" units behind ONE call each way — the operator granularity of
+ * models/modules/resnet_block.py:48-64 (conv1/norm1/relu, conv2/norm2,
+ * `out += residual`, relu) and of the stem / strided / transposed stages of
+ * models/res16unet.py:231-297.  Same kernels and kernel choice as the
+ * per-operator entry points above; the point is that the host issues 3-6
+ * launches per call instead of one per call from the interpreter.
+ *
+ * usc_kmap describes one kernel map of the batch (built by usc_kernel_map_cube /
+ * usc_kernel_map_down2, usc_rowsort_build, usc_rulebook_compact); all pointers
+ * are device pointers owned by the caller's coordinate manager.
+ *   kind USC_CONV_SAME : k^3 stride-1 conv on one map (n_in == n_out), or a 1x1
+ *                        conv when nbr == NULL and K == 1
+ *        USC_CONV_DOWN : k=2,s=2 conv, fine map (n_in rows) -> coarse map
+ *                        (n_out rows); nbr = child table [8][n_out]
+ *        USC_CONV_UP   : the transposed conv on the SAME map description:
+ *                        input = coarse rows (n_out), output = fine rows (n_in)
+ * ---------------------------------------------------------------------- */
+typedef struct usc_kmap {
+  const int32_t* nbr;        /* i32[K][n_out]; NULL: identity (1x1 conv) */
+  const int32_t* perm;       /* usc_rowsort_build of nbr, or NULL */
+  const uint32_t* tile_mask; /* usc_rowsort_build of nbr, or NULL */
+  const int32_t* pair_in;    /* usc_rulebook_compact of nbr: rows of the n_in side */
+  const int32_t* pair_out;   /*                              rows of the n_out side */
+  const int64_t* koff;       /* i64[K+1] (device) */
+  int64_t n_in, n_out;
+  int64_t pair_capacity;     /* allocated length of pair_in / pair_out */
+  int32_t K;
+  int32_t reserved;
+} usc_kmap;
+
+enum usc_conv_kind { USC_CONV_SAME = 0, USC_CONV_DOWN = 1, USC_CONV_UP = 2 };
+
+/* MinkowskiBatchNorm == BatchNorm1d over rows (models/modules/common.py:22).
+ * training != 0: batch statistics (+ running-stat update when running_* != NULL,
+ * num_batches_tracked incremented when != NULL); else running statistics. */
+typedef struct usc_bn {
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  int64_t* num_batches_tracked;
+  float eps, momentum;
+  int32_t c;
+  int32_t training;
+} usc_bn;
+
+/* Scratch bytes covering forward AND backward of one convolution / one unit. */
+int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin,
+                          int32_t cout);
+int64_t usc_unit_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin,
+                          int32_t cout);
+/* y = conv(x; W) (+ bias; bias only for SAME/DOWN).  W f32[K,cin,cout]. */
+int usc_conv_forward(const usc_kmap* m, int32_t kind, const float* x,
+                     int32_t cin, const float* W, int32_t cout,
+                     const float* bias, float* y, void* ws, int64_t ws_bytes,
+                     usc_stream_t s);
+/* dx (skipped when NULL; dx_accumulate adds into dx — gather forms only) and
+ * dW (skipped when NULL; dW_accumulate adds into a gradient buffer). */
+int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x,
+                      int32_t cin, const float* W, int32_t cout,
+                      const float* dy, float* dx, int32_t dx_accumulate,
+                      float* dW, int32_t dW_accumulate, void* ws,
+                      int64_t ws_bytes, usc_stream_t s);
+/* mean/invstd/scale/shift of an eval-mode batch norm from its running statistics. */
+int usc_bn_eval_stats(const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var,
+                      float eps, int32_t c, float* mean, float* invstd,
+                      float* scale, float* shift, usc_stream_t s);
+/* out = [relu]( BN(conv(x; W)) (+ residual) ).  Saved for the backward pass:
+ * y = conv output f32[n,cout], stats f32[4][cout] = mean | invstd | scale | shift,
+ * out (its sign is the ReLU mask). */
+int usc_conv_bn_act_forward(const usc_kmap* m, int32_t kind, const float* x,
+                            int32_t cin, const float* W, int32_t cout,
+                            const usc_bn* bn, const float* residual,
+                            int32_t relu, float* y, float* stats, float* out,
+                            void* ws, int64_t ws_bytes, usc_stream_t s);
+/* Backward of the unit.  out_relu = the forward output when relu was applied, else
+ * NULL.  dy f32[n,cout] receives d(conv output) (scratch the caller may drop);
+ * dres (or NULL) receives the residual branch's gradient (= masked dout).
+ * dgamma/dbeta: written, or added into when dbn_accumulate. */
+int usc_conv_bn_act_backward(const usc_kmap* m, int32_t kind, const float* x,
+                             int32_t cin, const float* W, int32_t cout,
+                             const usc_bn* bn, const float* y,
+                             const float* stats, const float* out_relu,
+                             const float* dout, float* dy, float* dres,
+                             float* dx, int32_t dx_accumulate, float* dW,
+                             int32_t dW_accumulate, float* dgamma,
+                             float* dbeta, int32_t dbn_accumulate, void* ws,
+                             int64_t ws_bytes, usc_stream_t s);
 
 /* ------------------------------------------------------------------------
  * B  row-wise batch norm / ReLU / residual — replaces [ME] MinkowskiBatchNorm

@@ -189,3 +189,51 @@ def test_150k_voxel_backbone_step_agrees_across_conv_kernel_families(device, ben
     assert rel_err(a[1], b[1]) < 1e-4
     for i in (2, 3, 4):
         assert rel_err(a[i], b[i]) < 2e-2, (i, rel_err(a[i], b[i]))
+
+
+@pytest.mark.parametrize("in_place", [False, True])
+def test_native_unit_path_equals_per_operator_path(device, monkeypatch, in_place):
+    """The native issue path (units.py: one C call per conv+BN unit, one autograd node per residual block, residual
+    gradient accumulated by the input-gradient kernel) against the per-operator path on Res16UNet34C, training mode,
+    40 k voxels: same kernels in the same order, so the features agree to the last bit and the gradients to rounding
+    (only the association of the residual add differs).  `in_place`: gradient buffers pre-allocated, i.e. the
+    kernels add into p.grad and the autograd nodes return None — the trainer's configuration."""
+    from types import SimpleNamespace
+
+    from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd import units
+    from unscene3d_amd.models.res16unet import Res16UNet34C
+    from unscene3d_amd.synthetic import make_scene
+
+    sc = make_scene(2100, target_voxels=40_000, tol=0.05)
+    ec = R.voxel_floor(sc["xyz"], 0.02)
+    eu, _ = R.sparse_quantize(ec)
+    coords4, feats = R.sparse_collate([ec[eu]], [sc["colors"][eu]])
+    torch.manual_seed(11)
+    cfg = SimpleNamespace(bn_momentum=0.02, conv1_kernel_size=3, dilations=[1, 1, 1, 1])
+    model = Res16UNet34C(3, 20, cfg, out_fpn=True).to(device).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    res = {}
+    for native in (False, True):
+        monkeypatch.setattr(units, "ENABLED", native)
+        model.load_state_dict(state)
+        if in_place:
+            for p in model.parameters():
+                p.grad = torch.zeros_like(p)
+        else:
+            model.zero_grad(set_to_none=True)
+        x = ME.SparseTensor(features=_dev(feats, device), coordinates=_dev(coords4, device), device=device)
+        out, fmaps = model(x)
+        loss = out.F.square().mean() + sum(f.F.square().mean() for f in fmaps[:-1])
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in model.named_parameters() if not n.startswith("final.")}
+        stats = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+        res[native] = (out.F.detach().clone(), [f.F.detach().clone() for f in fmaps], grads, stats)
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0])
+    for fa, fb in zip(a[1], b[1]):
+        assert torch.equal(fa, fb)
+    for k in b[3]:
+        assert torch.equal(a[3][k], b[3][k]), k                      # running statistics, batch counters
+    worst = max((rel_err(a[2][n], b[2][n]), n) for n in b[2])
+    assert worst[0] < 1e-4, worst

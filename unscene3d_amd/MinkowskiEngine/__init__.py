@@ -86,6 +86,7 @@ class CoordinateManager:
         self._cube = {}       # (ts, ksize) -> dict(nbr, rulebook)
         self._batch_rows = {}  # ts -> list of (start, end) per batch, or index lists
         self._sorted_input = None
+        self._kmaps = {}      # ("cube", ts, ksize) / ("down", ts) / ("id", ts) -> units.KMapRef (native issue path)
 
     # -- maps
     def insert(self, coords: torch.Tensor, tensor_stride: int = 1):
@@ -130,6 +131,31 @@ class CoordinateManager:
             d["rulebook"] = ops.rulebook_compact(d["nbr"])
         return d["rulebook"]
 
+    # -- kernel-map descriptors of the native issue path (csrc/units.hip); built once per batch
+    def kmap_cube(self, ts: int, ksize: int = 3):
+        key = ("cube", ts, ksize)
+        if key not in self._kmaps:
+            from .. import units
+            n = self._maps[ts].n
+            self._kmaps[key] = units.kmap_from_table(self.cube_map(ts, ksize)["nbr"], self.cube_rulebook(ts, ksize), n)
+        return self._kmaps[key]
+
+    def kmap_down(self, ts: int):
+        """k=2,s=2 map between ts (fine, n_in) and 2ts (coarse, n_out); the transposed conv uses it too."""
+        key = ("down", ts)
+        if key not in self._kmaps:
+            from .. import units
+            d = self.stride_map(ts)
+            self._kmaps[key] = units.kmap_from_table(d["nbr2"], self.down_rulebook(ts), self._maps[ts].n)
+        return self._kmaps[key]
+
+    def kmap_identity(self, ts: int):
+        key = ("id", ts)
+        if key not in self._kmaps:
+            from .. import units
+            self._kmaps[key] = units.kmap_identity(self._maps[ts].n)
+        return self._kmaps[key]
+
     def prepare(self, ts: int, n_down: int, ksize: int = 3):
         """Build the whole pyramid a U-Net needs in one go: maps at ts, 2ts, ... (n_down halvings), their k2/s2
         child tables, the ksize^3 neighbour tables with their mask-sorted row orders, and the per-scene row
@@ -147,6 +173,13 @@ class CoordinateManager:
                 d = self.stride_map(t)
                 ops.rowsort(d["nbr2"])
             self.batch_slices(t)
+            if torch.is_grad_enabled():
+                # the pair lists (weight gradients, transposed convs) and the native path's map descriptors as well:
+                # on the prefetcher's side stream this is off the step's critical path
+                self.kmap_cube(t, ksize)
+                self.kmap_identity(t)
+                if lvl < n_down:
+                    self.kmap_down(t)
             t *= 2
 
     # -- batch decomposition
@@ -416,6 +449,27 @@ def cat(*tensors):
         if t.coordinate_map_key != key:
             raise RuntimeError("cat: tensors live on different coordinate maps")
     return tensors[0]._like(torch.cat([t.F for t in tensors], dim=1))
+
+
+def conv_bn_act(conv, norm, x: SparseTensor, residual: SparseTensor = None, relu: bool = True) -> SparseTensor:
+    """`norm(conv(x))` (+ residual) (+ ReLU) — MinkowskiConvolution[Transpose] followed by MinkowskiBatchNorm
+    (reference models/res16unet.py:231-297, models/modules/resnet_block.py:48-64) through the native issue path
+    (one C call each way, unscene3d_amd/units.py) when it applies, else through the two modules."""
+    from .. import units
+    if isinstance(norm, MinkowskiBatchNorm) and units.usable(x.F, conv):
+        cm, ts = x.coordinate_manager, x._ts()
+        res = None if residual is None else residual.F
+        if isinstance(conv, MinkowskiConvolutionTranspose):
+            if conv.stride == 2 and conv.ksize == 2 and ts // 2 >= 1 and (ts // 2) in cm._down:
+                out = units.conv_bn_act(x.F, conv.kernel, norm.bn, cm.kmap_down(ts // 2), units.UP, res, relu)
+                return SparseTensor(features=out, coordinate_manager=cm, coordinate_map_key=CoordinateMapKey(ts // 2))
+        elif conv.stride == 1:
+            kmap = cm.kmap_identity(ts) if conv.kernel_volume == 1 else cm.kmap_cube(ts, conv.ksize)
+            return x._like(units.conv_bn_act(x.F, conv.kernel, norm.bn, kmap, units.SAME, res, relu))
+        elif conv.stride == 2 and conv.ksize == 2:
+            out = units.conv_bn_act(x.F, conv.kernel, norm.bn, cm.kmap_down(ts), units.DOWN, res, relu)
+            return SparseTensor(features=out, coordinate_manager=cm, coordinate_map_key=CoordinateMapKey(2 * ts))
+    return norm(conv(x), residual=residual, relu=relu)
 
 
 from . import MinkowskiOps, MinkowskiPooling  # noqa: E402,F401

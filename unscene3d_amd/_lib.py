@@ -20,6 +20,21 @@ _i64 = C.c_int64
 _f64 = C.c_double
 _f32 = C.c_float
 
+class KMap(C.Structure):
+    """usc_kmap (include/usc3d.h): one kernel map of the batch."""
+    _fields_ = [("nbr", _p), ("perm", _p), ("tile_mask", _p), ("pair_in", _p), ("pair_out", _p), ("koff", _p),
+                ("n_in", _i64), ("n_out", _i64), ("pair_capacity", _i64), ("K", _i32), ("reserved", _i32)]
+
+
+class BNDesc(C.Structure):
+    """usc_bn (include/usc3d.h)."""
+    _fields_ = [("gamma", _p), ("beta", _p), ("running_mean", _p), ("running_var", _p), ("num_batches_tracked", _p),
+                ("eps", _f32), ("momentum", _f32), ("c", _i32), ("training", _i32)]
+
+
+_kp = C.POINTER(KMap)
+_bp = C.POINTER(BNDesc)
+
 # name -> (restype, [argtypes])   — mirrors include/usc3d.h one to one
 SIGNATURES = {
     "usc_last_error": (C.c_char_p, []),
@@ -45,6 +60,15 @@ SIGNATURES = {
     "usc_spconv_pairs_gemm": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p]),
     "usc_spconv_wgrad_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p, _i64, _p]),
+    "usc_spconv_wgrad_ws_bytes_rows": (_i64, [_i32, _i32, _i32, _i64]),
+    "usc_conv_ws_bytes": (_i64, [_kp, _i32, _i32, _i32]),
+    "usc_unit_ws_bytes": (_i64, [_kp, _i32, _i32, _i32]),
+    "usc_conv_forward": (C.c_int, [_kp, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _p]),
+    "usc_conv_backward": (C.c_int, [_kp, _i32, _p, _i32, _p, _i32, _p, _p, _i32, _p, _i32, _p, _i64, _p]),
+    "usc_bn_eval_stats": (C.c_int, [_p, _p, _p, _p, _f32, _i32, _p, _p, _p, _p, _p]),
+    "usc_conv_bn_act_forward": (C.c_int, [_kp, _i32, _p, _i32, _p, _i32, _bp, _p, _i32, _p, _p, _p, _p, _i64, _p]),
+    "usc_conv_bn_act_backward": (C.c_int, [_kp, _i32, _p, _i32, _p, _i32, _bp, _p, _p, _p, _p, _p, _p, _p, _i32, _p,
+                                           _i32, _p, _p, _i32, _p, _i64, _p]),
     "usc_colstats_ws_bytes": (_i64, [_i64, _i32]),
     "usc_colstats": (C.c_int, [_p, _p, _i64, _i32, _p, _p, _p, _i64, _p]),
     "usc_bn_apply": (C.c_int, [_p, _p, _p, _p, _i32, _p, _i64, _i32, _p]),

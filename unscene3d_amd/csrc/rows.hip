@@ -173,6 +173,21 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __res
   }
 }
 
+// eval-mode batch norm: the same four vectors from the running statistics
+__global__ void bn_eval_stats_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int c,
+                                     float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                     float* __restrict__ shift) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  const float is = 1.f / sqrtf(rvar[ch] + eps);      // torch.rsqrt(running_var + eps) up to rounding
+  const float sc = gamma[ch] * is;
+  mean[ch] = rmean[ch];
+  invstd[ch] = is;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - rmean[ch] * sc;
+}
+
 static int colstats_blocks(int64_t n, int c, int vec) {
   const int CT = c / vec, RP = 256 / CT;
   int64_t b = ceil_div(n, (int64_t)RP * 16);
@@ -605,6 +620,16 @@ int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamm
   BnFwdOut o{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n, num_batches_tracked};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c, o);
   USC_CHECK_LAUNCH("usc_bn_forward_stats");
+  return USC_OK;
+}
+
+int usc_bn_eval_stats(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                      int32_t c, float* mean, float* invstd, float* scale, float* shift, usc_stream_t s) {
+  USC_REQUIRE(gamma && beta && running_mean && running_var && mean && invstd && scale && shift && c >= 1,
+              "usc_bn_eval_stats: bad argument");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)ceil_div(c, 256)), dim3(256), 0, as_stream(s), gamma, beta,
+                     running_mean, running_var, eps, (int)c, mean, invstd, scale, shift);
+  USC_CHECK_LAUNCH("usc_bn_eval_stats");
   return USC_OK;
 }
 

@@ -913,6 +913,19 @@ static int wgrad_splits(int K, int cin, int cout, int NB, int64_t n_rows) {
   if (S < 1) S = 1;
   return (int)S;
 }
+static int wgrad_full_nb(int cb) { return (cb % 3 == 0) ? 3 : (cb % 4 == 0 ? 4 : (cb % 2 == 0 ? 2 : 1)); }
+static int wgrad_full_ct(int ctiles, int NBf) {
+  return (ctiles % 3 == 0 && NBf * 3 <= 9) ? 3 : ((ctiles % 4 == 0 && NBf * 4 <= 9) ? 4 : ((ctiles % 2 == 0 && NBf * 2 <= 9) ? 2 : 1));
+}
+static int64_t wgrad_full_splits(int K, int ctiles, int cb, int CT, int NBf, int64_t n_rows) {
+  const int64_t blocks_per_split = (int64_t)K * (ctiles / CT) * (cb / NBf);
+  int64_t S = 512 / blocks_per_split;                         // one round of 2 workgroups per CU
+  const int64_t by_rows = n_rows / (K > 1 ? 4096 : 256) + 1;   // identity pairs (dense layers): 64 rows per wave suffice
+  if (S > by_rows) S = by_rows;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  return S;
+}
 static int pick_nb(int cout) {
   if (cout <= 32) return 1;
   if (cout <= 64) return 2;
@@ -1117,6 +1130,20 @@ int64_t usc_spconv_wgrad_ws_bytes(int32_t K, int32_t cin, int32_t cout) {
   return (int64_t)64 * K * cin * cout * (int64_t)sizeof(float);
 }
 
+int64_t usc_spconv_wgrad_ws_bytes_rows(int32_t K, int32_t cin, int32_t cout, int64_t n_rows) {
+  // the split count usc_spconv_wgrad will choose for this pair-list capacity (same arithmetic)
+  const int64_t numel = (int64_t)K * cin * cout;
+#ifndef USC_WGRAD_LEGACY
+  const int ctiles = cin / 32, cb = cout / 32;
+  if (cin % 32 == 0 && cout % 32 == 0 && cb > 0) {
+    const int NBf = wgrad_full_nb(cb);
+    if (!(NBf == 3 && ctiles % 3 != 0))
+      return wgrad_full_splits(K, ctiles, cb, wgrad_full_ct(ctiles, NBf), NBf, n_rows) * numel * 4;
+  }
+#endif
+  return (int64_t)wgrad_splits(K, cin, cout, pick_nb(cout), n_rows) * numel * 4;
+}
+
 int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, int32_t K, const int32_t* a_idx,
                      const int32_t* b_idx, const int64_t* koff, int64_t n_rows, float* dW, int32_t accumulate, void* ws, int64_t ws_bytes,
                      usc_stream_t s) {
@@ -1130,18 +1157,13 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
   p.partial = (float*)ws; p.cin = cin; p.cout = cout; p.K = K;
 #ifndef USC_WGRAD_LEGACY
   const int ctiles = cin / 32, cb = cout / 32;
-  const int NBf = (cb % 3 == 0) ? 3 : (cb % 4 == 0 ? 4 : (cb % 2 == 0 ? 2 : 1));
+  const int NBf = wgrad_full_nb(cb);
   // (128 -> 96 channels would need 4x3 tiles = 256 VGPRs + scratch, or 2x3 twice: both measured slower than the
   //  per-input-tile kernel below, 0.78 / 0.82 vs 0.73 ms)
   if (cin % 32 == 0 && cout % 32 == 0 && !(NBf == 3 && ctiles % 3 != 0)) {
     // CT input tiles x NB column tiles per wave, CT*NB <= 9 accumulator tiles
-    const int CT = (ctiles % 3 == 0 && NBf * 3 <= 9) ? 3 : ((ctiles % 4 == 0 && NBf * 4 <= 9) ? 4 : ((ctiles % 2 == 0 && NBf * 2 <= 9) ? 2 : 1));
-    const int64_t blocks_per_split = (int64_t)K * (ctiles / CT) * (cb / NBf);
-    int64_t S = 512 / blocks_per_split;                         // one round of 2 workgroups per CU
-    const int64_t by_rows = n_rows / (K > 1 ? 4096 : 256) + 1;   // identity pairs (dense layers): 64 rows per wave suffice
-    if (S > by_rows) S = by_rows;
-    if (S > 64) S = 64;
-    if (S < 1) S = 1;
+    const int CT = wgrad_full_ct(ctiles, NBf);
+    const int64_t S = wgrad_full_splits(K, ctiles, cb, CT, NBf, n_rows);
     USC_REQUIRE(ws_bytes >= S * numel * 4, "usc_spconv_wgrad: workspace too small");
     p.S = (int)S;
     dim3 grid((unsigned)(K * S), (unsigned)(ctiles / CT), (unsigned)(cb / NBf));

@@ -1,0 +1,235 @@
+// units.hip — native issue path for the backbone: one C call launches every kernel of a
+// "convolution -> batch norm (+ residual) (+ ReLU)" unit, forward or backward.
+//
+// The kernels are the ones behind the per-operator entry points (usc_spconv_*, usc_bn_*); what moves here
+// is the ISSUE LOOP.  From Python every launch cost ~10-20 us of interpreter, ctypes, allocator and autograd
+// bookkeeping, ~1 000 of them per training step for the backbone alone, which put the host level with the
+// device.  A unit is 3-4 launches forward and 4-6 backward behind ONE call; the kernel choice
+// (mask-sorted / tile-compacted / row-order / pair-list form, weight transposes, split counts) that lived in
+// unscene3d_amd/ops.py is restated here so that both paths launch identical kernels.
+//
+// Reference: models/modules/resnet_block.py:48-64 (conv -> norm -> relu / `out += residual`),
+// models/res16unet.py:231-297 (conv{0..4} / convtr{4..7} + bn + relu), models/modules/common.py:125-188.
+#include "common.h"
+
+using namespace usc;
+
+namespace {
+
+struct WsCursor {
+  char* base; int64_t bytes; int64_t off;
+  void* take(int64_t n) {
+    n = align_up(n > 0 ? n : 16, 256);
+    if (off + n > bytes) return nullptr;
+    void* p = base + off;
+    off += n;
+    return p;
+  }
+  int64_t left() const { return bytes - off; }
+  void* rest() { return base + off; }
+};
+
+inline bool table_is_compact(int64_t n_out, int cin, int cout, int K) {
+  return (usc_spconv_plan(0, n_out, cin, cout, K) >> 12) & 1;
+}
+inline bool sorted_ok(const usc_kmap* m, int cin, int cout) {
+  return m->nbr && m->perm && m->tile_mask && m->K > 1 && m->K <= 32 && cin % 32 == 0 && cout % 32 == 0 && cin <= 4096;
+}
+
+// bytes the table-form GEMM needs (out rows n_out, W possibly to be transposed first)
+int64_t table_gemm_ws(const usc_kmap* m, int64_t n_out, int cin, int cout, int K, bool want_transposed) {
+  if (m->nbr && sorted_ok(m, cin, cout) && !table_is_compact(n_out, cin, cout, K))
+    return align_up(usc_spconv_sorted_ws_bytes(n_out, cin, cout, K), 256);
+  int64_t b = align_up(usc_spconv_gather_gemm_ws_bytes(n_out, cin, cout, K), 256);
+  if (want_transposed && !(m->nbr && table_is_compact(n_out, cin, cout, K))) b += align_up((int64_t)K * cin * cout * 4, 256);
+  return b;
+}
+
+// out[o] (+)= sum_k in[nbr[k][o]] W[k]; `wt`: W is given as the forward [K, cout, cin] and the mirrored transpose
+// W'[k][c][n] = W[K-1-k][n][c] is meant (mirror only when K > 1).  `nbr` NULL: identity rows (1x1).
+int table_gemm(const usc_kmap* m, const int32_t* nbr, const float* in, int64_t n_in, int cin, const float* W, int K,
+               int cout, int64_t n_out, const float* bias, float* out, int accumulate, int wt, WsCursor ws,
+               usc_stream_t s) {
+  if (n_out == 0) return USC_OK;
+  const bool compact = nbr && table_is_compact(n_out, cin, cout, K);
+  if (nbr && nbr == m->nbr && sorted_ok(m, cin, cout) && !compact) {
+    const int64_t b = usc_spconv_sorted_ws_bytes(n_out, cin, cout, K);
+    void* w = b > 0 ? ws.take(b) : nullptr;
+    USC_REQUIRE(b == 0 || w, "usc unit: workspace too small (sorted gemm)");
+    return usc_spconv_sorted_gemm(in, n_in, cin, W, K, cout, nbr, m->perm, m->tile_mask, n_out, bias, out, accumulate,
+                                  wt, w, b, s);
+  }
+  if (wt && !compact) {
+    float* Wt = (float*)ws.take((int64_t)K * cin * cout * 4);
+    USC_REQUIRE(Wt, "usc unit: workspace too small (weight transpose)");
+    // W is [K, cout, cin] as a forward weight; the product wants [K, cin, cout]
+    int rc = usc_weight_transpose(W, K, cout, cin, K > 1 ? 1 : 0, Wt, s);
+    if (rc) return rc;
+    W = Wt;
+    wt = 0;
+  }
+  const int64_t b = usc_spconv_gather_gemm_ws_bytes(n_out, cin, cout, K);
+  void* w = b > 0 ? ws.take(b) : nullptr;
+  USC_REQUIRE(b == 0 || w, "usc unit: workspace too small (gather gemm)");
+  return usc_spconv_gather_gemm(in, n_in, cin, W, K, cout, nbr, n_out, bias, out, accumulate, wt, w, b, s);
+}
+
+struct ConvShape { int64_t n_in, n_out; };   // rows of the convolution's input / output feature matrices
+inline ConvShape conv_shape(const usc_kmap* m, int kind) {
+  return kind == USC_CONV_UP ? ConvShape{m->n_out, m->n_in} : ConvShape{m->n_in, m->n_out};
+}
+
+int check_map(const usc_kmap* m, int kind, int cin, int cout, const char* who) {
+  USC_REQUIRE(m, "%s: null kernel map", who);
+  USC_REQUIRE(kind == USC_CONV_SAME || kind == USC_CONV_DOWN || kind == USC_CONV_UP, "%s: unknown conv kind %d", who, kind);
+  USC_REQUIRE(cin >= 1 && cout >= 1 && m->K >= 1 && m->n_in >= 0 && m->n_out >= 0, "%s: bad sizes", who);
+  USC_REQUIRE(m->nbr || (m->K == 1 && kind == USC_CONV_SAME), "%s: K>1 needs a neighbour table", who);
+  USC_REQUIRE(kind != USC_CONV_SAME || m->n_in == m->n_out, "%s: a stride-1 map has n_in == n_out", who);
+  return USC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin, int32_t cout) {
+  if (!m) return 0;
+  const int K = m->K;
+  const ConvShape sh = conv_shape(m, kind);
+  const int64_t wbytes = align_up((int64_t)K * cin * cout * 4, 256);
+  int64_t fwd, dgrad;
+  if (kind == USC_CONV_SAME) {
+    fwd = table_gemm_ws(m, sh.n_out, cin, cout, K, false);
+    dgrad = table_gemm_ws(m, sh.n_in, cout, cin, K, true);
+  } else if (kind == USC_CONV_DOWN) {
+    fwd = table_gemm_ws(m, sh.n_out, cin, cout, K, false);
+    dgrad = wbytes;                                            // transposed weights for the pair-list form
+  } else {
+    fwd = 0;                                                   // pair-list form, no scratch
+    dgrad = wbytes + table_gemm_ws(m, sh.n_in, cout, cin, K, false);
+  }
+  const int64_t rows = m->nbr ? m->pair_capacity : sh.n_in;
+  const int64_t wg = align_up(usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows), 256);
+  int64_t b = fwd > dgrad ? fwd : dgrad;
+  if (wg > b) b = wg;
+  return b + 256;
+}
+
+int usc_conv_forward(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                     const float* bias, float* y, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  int rc = check_map(m, kind, cin, cout, "usc_conv_forward");
+  if (rc) return rc;
+  const ConvShape sh = conv_shape(m, kind);
+  if (sh.n_out == 0) return USC_OK;
+  USC_REQUIRE(x && W && y, "usc_conv_forward: null pointer");
+  WsCursor cur{(char*)ws, ws ? ws_bytes : 0, 0};
+  if (kind == USC_CONV_UP) {
+    // every fine row has exactly one parent: out[fine] = in[coarse] W[k]
+    USC_REQUIRE(m->pair_in && m->pair_out && m->koff, "usc_conv_forward: transposed conv needs the pair lists");
+    USC_REQUIRE(!bias, "usc_conv_forward: bias is not supported on the pair-list form");
+    return usc_spconv_pairs_gemm(x, cin, W, m->K, cout, m->pair_out, m->pair_in, m->koff, sh.n_out, y, s);
+  }
+  return table_gemm(m, m->nbr, x, sh.n_in, cin, W, m->K, cout, sh.n_out, bias, y, 0, 0, cur, s);
+}
+
+int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                      const float* dy, float* dx, int32_t dx_accumulate, float* dW, int32_t dW_accumulate, void* ws,
+                      int64_t ws_bytes, usc_stream_t s) {
+  int rc = check_map(m, kind, cin, cout, "usc_conv_backward");
+  if (rc) return rc;
+  const ConvShape sh = conv_shape(m, kind);
+  const int K = m->K;
+  USC_REQUIRE(x && W && dy, "usc_conv_backward: null pointer");
+  WsCursor cur{(char*)ws, ws ? ws_bytes : 0, 0};
+  if (dx && sh.n_in > 0) {
+    if (kind == USC_CONV_SAME) {
+      // stride-1 map: the mirrored offset reaches the rows that read row i; transpose folded where the kernel can
+      rc = table_gemm(m, m->nbr, dy, sh.n_out, cout, W, K, cin, sh.n_in, nullptr, dx, dx_accumulate, 1, cur, s);
+    } else if (kind == USC_CONV_DOWN) {
+      USC_REQUIRE(!dx_accumulate, "usc_conv_backward: accumulate is not supported on the pair-list form");
+      USC_REQUIRE(m->pair_in && m->pair_out && m->koff, "usc_conv_backward: strided conv needs the pair lists");
+      float* Wt = (float*)cur.take((int64_t)K * cin * cout * 4);
+      USC_REQUIRE(Wt, "usc_conv_backward: workspace too small");
+      rc = usc_weight_transpose(W, K, cin, cout, 0, Wt, s);
+      if (!rc) rc = usc_spconv_pairs_gemm(dy, cout, Wt, K, cin, m->pair_out, m->pair_in, m->koff, sh.n_in, dx, s);
+    } else {
+      float* Wt = (float*)cur.take((int64_t)K * cin * cout * 4);
+      USC_REQUIRE(Wt, "usc_conv_backward: workspace too small");
+      rc = usc_weight_transpose(W, K, cin, cout, 0, Wt, s);
+      // dx[coarse] = sum_k dy[child k of coarse] W[k]^T: the child table again, gather form
+      if (!rc) rc = table_gemm(m, m->nbr, dy, sh.n_out, cout, Wt, K, cin, sh.n_in, nullptr, dx, dx_accumulate, 0, cur, s);
+    }
+    if (rc) return rc;
+  }
+  if (dW) {
+    WsCursor wc{(char*)ws, ws ? ws_bytes : 0, 0};     // the weight gradient may reuse the scratch (stream order)
+    const int64_t rows = m->nbr ? m->pair_capacity : sh.n_in;
+    const int64_t b = usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows);
+    void* w = wc.take(b);
+    USC_REQUIRE(w, "usc_conv_backward: workspace too small (weight gradient)");
+    if (!m->nbr)
+      rc = usc_spconv_wgrad(x, cin, dy, cout, 1, nullptr, nullptr, nullptr, sh.n_in, dW, dW_accumulate, w, b, s);
+    else if (kind == USC_CONV_UP)
+      rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_out, m->pair_in, m->koff, rows, dW, dW_accumulate, w, b, s);
+    else
+      rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_in, m->pair_out, m->koff, rows, dW, dW_accumulate, w, b, s);
+    if (rc) return rc;
+  }
+  return USC_OK;
+}
+
+int64_t usc_unit_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin, int32_t cout) {
+  return usc_conv_ws_bytes(m, kind, cin, cout) + align_up(usc_colstats_ws_bytes(0, cout), 256) +
+         align_up(2 * (int64_t)cout * 4, 256) + 256;
+}
+
+int usc_conv_bn_act_forward(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                            const usc_bn* bn, const float* residual, int32_t relu, float* y, float* stats, float* out,
+                            void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(bn && bn->c == cout, "usc_conv_bn_act_forward: batch-norm width must equal the conv's output width");
+  USC_REQUIRE(y && stats && out && bn->gamma && bn->beta, "usc_conv_bn_act_forward: null pointer");
+  const ConvShape sh = conv_shape(m, kind);
+  WsCursor cur{(char*)ws, ws ? ws_bytes : 0, 0};
+  const int64_t sb = usc_colstats_ws_bytes(sh.n_out, cout);
+  void* sws = cur.take(sb);                       // BN partials first: the conv's scratch takes the rest
+  USC_REQUIRE(sws, "usc_conv_bn_act_forward: workspace too small");
+  int rc = usc_conv_forward(m, kind, x, cin, W, cout, nullptr, y, cur.rest(), cur.left(), s);
+  if (rc) return rc;
+  if (sh.n_out == 0) return USC_OK;
+  float* mean = stats, *invstd = stats + cout, *scale = stats + 2 * cout, *shift = stats + 3 * cout;
+  if (bn->training) {
+    rc = usc_bn_forward_stats(y, sh.n_out, cout, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->running_mean,
+                              bn->running_var, bn->num_batches_tracked, mean, invstd, scale, shift, sws, sb, s);
+  } else {
+    USC_REQUIRE(bn->running_mean && bn->running_var, "usc_conv_bn_act_forward: eval mode needs running statistics");
+    rc = usc_bn_eval_stats(bn->gamma, bn->beta, bn->running_mean, bn->running_var, bn->eps, cout, mean, invstd, scale,
+                           shift, s);
+  }
+  if (rc) return rc;
+  return usc_bn_apply(y, scale, shift, residual, relu, out, sh.n_out, cout, s);
+}
+
+int usc_conv_bn_act_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                             const usc_bn* bn, const float* y, const float* stats, const float* out_relu,
+                             const float* dout, float* dy, float* dres, float* dx, int32_t dx_accumulate, float* dW,
+                             int32_t dW_accumulate, float* dgamma, float* dbeta, int32_t dbn_accumulate, void* ws,
+                             int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(bn && bn->c == cout, "usc_conv_bn_act_backward: batch-norm width must equal the conv's output width");
+  USC_REQUIRE(y && stats && dout && dy && dgamma && dbeta && bn->gamma, "usc_conv_bn_act_backward: null pointer");
+  const ConvShape sh = conv_shape(m, kind);
+  if (sh.n_out == 0) return USC_OK;
+  WsCursor cur{(char*)ws, ws ? ws_bytes : 0, 0};
+  const int64_t sb = usc_colstats_ws_bytes(sh.n_out, cout);
+  void* sws = cur.take(sb);
+  float* red = (float*)cur.take(2 * (int64_t)cout * 4);   // mean_g | mean_gxhat
+  USC_REQUIRE(sws && red, "usc_conv_bn_act_backward: workspace too small");
+  const float* mean = stats, *invstd = stats + cout;
+  int rc = usc_bn_backward_reduce(y, dout, out_relu, mean, invstd, sh.n_out, cout, bn->training, dbn_accumulate, dgamma,
+                                  dbeta, red, red + cout, sws, sb, s);
+  if (rc) return rc;
+  rc = usc_bn_backward_dx(y, dout, out_relu, mean, invstd, bn->gamma, red, red + cout, dy, dres, sh.n_out, cout, s);
+  if (rc) return rc;
+  return usc_conv_backward(m, kind, x, cin, W, cout, dy, dx, dx_accumulate, dW, dW_accumulate, cur.rest(), cur.left(), s);
+}
+
+}  // extern "C"

@@ -5,7 +5,8 @@ forward fuses BN + residual add + ReLU into one statistics pass and one
 elementwise pass on the device."""
 import torch.nn as nn
 
-from ...MinkowskiEngine import MinkowskiReLU
+from ... import units
+from ...MinkowskiEngine import MinkowskiBatchNorm, MinkowskiReLU, conv_bn_act
 from .common import ConvType, NormType, conv, get_norm
 
 
@@ -31,7 +32,22 @@ class BasicBlockBase(nn.Module):
         self.relu = MinkowskiReLU(inplace=True)
         self.downsample = downsample
 
+    def _native(self, x):
+        """The whole block as one autograd node (units._BasicBlock) when every piece is the plain stride-1 form."""
+        ds = self.downsample
+        convs = (self.conv1, self.conv2) + ((ds[0],) if ds is not None else ())
+        if not units.usable(x.F, *convs):
+            return False
+        if self.conv1.stride != 1 or self.conv2.stride != 1 or self.conv1.kernel_volume == 1 or \
+                self.conv1.ksize != self.conv2.ksize or not isinstance(self.norm1, MinkowskiBatchNorm):
+            return False
+        return ds is None or (len(ds) == 2 and ds[0].stride == 1 and ds[0].kernel_volume == 1
+                              and isinstance(ds[1], MinkowskiBatchNorm))
+
     def forward(self, x):
+        if self._native(x):
+            cm, ts = x.coordinate_manager, x._ts()
+            return x._like(units.basic_block(x.F, self, cm.kmap_cube(ts, self.conv1.ksize), cm.kmap_identity(ts)))
         out = self.norm1(self.conv1(x), relu=True)
         out = self.conv2(out)
         # norm2 -> `out += residual` -> relu  (reference :56-62), fused
@@ -59,10 +75,10 @@ class BottleneckBase(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        out = self.norm1(self.conv1(x), relu=True)
-        out = self.norm2(self.conv2(out), relu=True)
-        out = self.conv3(out)
-        return self.norm3(out, residual=_residual(self, x), relu=True)
+        out = conv_bn_act(self.conv1, self.norm1, x, relu=True)
+        out = conv_bn_act(self.conv2, self.norm2, out, relu=True)
+        res = x if self.downsample is None else conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
+        return conv_bn_act(self.conv3, self.norm3, out, residual=res, relu=True)
 
 
 class Bottleneck(BottleneckBase):

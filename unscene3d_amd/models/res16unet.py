@@ -74,15 +74,15 @@ class Res16UNetBase(ResNetBase):
         # all coordinate / kernel maps of the pyramid first (their host read-backs would otherwise stall the
         # convolution pipeline four times; see CoordinateManager.prepare)
         x.coordinate_manager.prepare(x.tensor_stride[0], n_down=len(self._DOWN), ksize=3)
-        skip = [self.bn0(self.conv0p1s1(x), relu=True)]          # out_p1
+        skip = [ME.conv_bn_act(self.conv0p1s1, self.bn0, x, relu=True)]          # out_p1
         out = skip[0]
         for cname, nname, bname in self._DOWN:
-            out = getattr(self, nname)(getattr(self, cname)(out), relu=True)
+            out = ME.conv_bn_act(getattr(self, cname), getattr(self, nname), out, relu=True)
             out = getattr(self, bname)(out)
             skip.append(out)                                     # out_b1p2, out_b2p4, out_b3p8, (s16)
         levels = [out]                                           # pixel_dist 16
         for j, (cname, nname, bname) in enumerate(self._UP):
-            out = getattr(self, nname)(getattr(self, cname)(out), relu=True)
+            out = ME.conv_bn_act(getattr(self, cname), getattr(self, nname), out, relu=True)
             out = me.cat(out, skip[3 - j])
             out = getattr(self, bname)(out)
             levels.append(out)                                   # pixel_dist 8, 4, 2, 1

@@ -1,0 +1,258 @@
+"""Native issue path of the backbone: "conv -> batch norm (+ residual) (+ ReLU)" units and whole residual blocks as
+ONE autograd node each, every unit one C call each way (csrc/units.hip: usc_conv_bn_act_forward / _backward).
+
+Why: the per-operator path (ops.conv_same + ops.batch_norm_act, one autograd Function and 1-3 ctypes calls per
+operator) issued ~1 000 launches per step for the backbone from the interpreter at 10-20 us each, which put host
+issue time level with device time.  Here a BasicBlock (reference models/modules/resnet_block.py:48-64)
+is one Function: 2-3 native calls forward, 2-3 backward, and the residual branch's gradient is accumulated by the
+input-gradient kernel itself (`dx_accumulate`) instead of a separate element-wise add per block.
+
+Same kernels, same kernel choice and the same arithmetic as the per-operator path; that path stays for odd cases
+(bias, non-default USC3D_CONV, an open profiler capture, CPU-side hooks on the parameters) and as the A/B
+reference of the tests (USC3D_NATIVE_UNITS=0).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import ops
+from . import profiler as _prof
+from ._lib import BNDesc, KMap, check, lib
+
+ENABLED = os.environ.get("USC3D_NATIVE_UNITS", "1") == "1"
+SAME, DOWN, UP = 0, 1, 2
+
+
+class KMapRef:
+    """A usc_kmap plus the tensors it points into (kept alive for the batch)."""
+
+    __slots__ = ("struct", "ref", "keep", "n_in", "n_out", "K")
+
+    def __init__(self, nbr, perm, tmask, rb, n_in, n_out, K):
+        s = KMap()
+        s.nbr = None if nbr is None else nbr.data_ptr()
+        s.perm = None if perm is None else perm.data_ptr()
+        s.tile_mask = None if tmask is None else tmask.data_ptr()
+        if rb is not None:
+            s.pair_in, s.pair_out, s.koff = rb.in_idx.data_ptr(), rb.out_idx.data_ptr(), rb.koff.data_ptr()
+            s.pair_capacity = rb.capacity
+        s.n_in, s.n_out, s.K = n_in, n_out, K
+        self.struct, self.ref = s, C.byref(s)
+        self.keep = (nbr, perm, tmask, None if rb is None else (rb.in_idx, rb.out_idx, rb.koff))
+        self.n_in, self.n_out, self.K = n_in, n_out, K
+
+
+def kmap_from_table(nbr, rb, n_in):
+    """Kernel map of a neighbour table i32[K, n_out] with its row order and pair lists."""
+    perm, tmask = ops.rowsort(nbr) if (1 < nbr.shape[0] <= 32 and nbr.shape[1] > 0) else (None, None)
+    return KMapRef(nbr, perm, tmask, rb, n_in, nbr.shape[1], nbr.shape[0])
+
+
+def kmap_identity(n):
+    return KMapRef(None, None, None, None, n, n, 1)
+
+
+# one grow-only scratch buffer per device for the native calls (all on the compute stream: stream order makes the
+# reuse safe; the caching allocator hands a replaced buffer only to later work of the same stream)
+_WS = {}
+
+
+def workspace(nbytes: int, device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + (1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _bn_desc(bn: torch.nn.BatchNorm1d, training: bool):
+    """usc_bn of an nn.BatchNorm1d, cached on the module while its tensors stay where they are."""
+    key = (bn.weight.data_ptr(), bn.bias.data_ptr(), 0 if bn.running_mean is None else bn.running_mean.data_ptr(),
+           training, bn.momentum, bn.eps)
+    cached = bn.__dict__.get("_usc_desc")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    d = BNDesc()
+    d.gamma, d.beta = bn.weight.data_ptr(), bn.bias.data_ptr()
+    track = bn.track_running_stats and bn.running_mean is not None
+    d.running_mean = bn.running_mean.data_ptr() if track else None
+    d.running_var = bn.running_var.data_ptr() if track else None
+    d.num_batches_tracked = bn.num_batches_tracked.data_ptr() if (track and training and
+                                                                   bn.num_batches_tracked is not None) else None
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average batch norm (momentum=None) is not on the hot path")
+    d.eps, d.momentum, d.c, d.training = float(bn.eps), float(bn.momentum), bn.num_features, int(training)
+    ref = (d, C.byref(d))
+    bn.__dict__["_usc_desc"] = (key, ref)
+    return ref
+
+
+def _training(bn):
+    return bn.training or not bn.track_running_stats
+
+
+def usable(x, conv, *more_convs):
+    """The native path covers f32 HIP features, bias-free convs, the default kernel dispatch, no open profiler capture."""
+    if not (ENABLED and ops.CONV_PATH == "sorted" and _prof._active is None):
+        return False
+    if not (x.is_cuda and x.dtype == torch.float32):
+        return False
+    for c in (conv,) + more_convs:
+        if c is not None and c.bias is not None:
+            return False
+    return True
+
+
+# --------------------------------------------------------------------------------------------------------------
+# one unit each way (plain functions: the autograd nodes below compose them)
+def unit_forward(x, W3, bn, kmap: KMapRef, kind, residual, relu):
+    """-> (y conv output, stats f32[4,c], out).  W3 f32[K,cin,cout]."""
+    dev = x.device
+    K, cin, cout = W3.shape
+    n_out = kmap.n_in if kind == UP else kmap.n_out
+    y = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    stats = torch.empty((4, cout), dtype=torch.float32, device=dev)
+    _, bref = _bn_desc(bn, _training(bn))
+    wsb = lib.usc_unit_ws_bytes(kmap.ref, kind, cin, cout)
+    ws = workspace(wsb, dev)
+    check(lib.usc_conv_bn_act_forward(kmap.ref, kind, x.data_ptr(), cin, W3.data_ptr(), cout, bref,
+                                      None if residual is None else residual.data_ptr(), int(relu), y.data_ptr(),
+                                      stats.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), ops._stream()),
+          "usc_conv_bn_act_forward")
+    return y, stats, out
+
+
+def unit_backward(x, W3, bn, kmap, kind, y, stats, out_relu, dout, dy_buf, want_dres, dx, dx_accumulate, need_dx,
+                  W_param, g_param, b_param):
+    """Backward of one unit.  dy_buf: scratch [n_out, cout] (may be shared between the units of a block).
+    -> (dx or None, dres or None, dW, dgamma, dbeta) — the last three None when written into .grad in place."""
+    dev = x.device
+    K, cin, cout = W3.shape
+    n_out, n_in = (kmap.n_in, kmap.n_out) if kind == UP else (kmap.n_out, kmap.n_in)
+    dres = torch.empty((n_out, cout), dtype=torch.float32, device=dev) if want_dres else None
+    if need_dx and dx is None:
+        dx = torch.empty((n_in, cin), dtype=torch.float32, device=dev)
+        dx_accumulate = False
+    tW = ops._grad_target(W_param)
+    tg, tb = ops._grad_target(g_param), ops._grad_target(b_param)
+    bn_in_place = tg is not None and tb is not None
+    dW = tW if tW is not None else torch.empty(W_param.shape, dtype=torch.float32, device=dev)
+    dg = tg if bn_in_place else torch.empty(cout, dtype=torch.float32, device=dev)
+    db = tb if bn_in_place else torch.empty(cout, dtype=torch.float32, device=dev)
+    _, bref = _bn_desc(bn, _training(bn))
+    wsb = lib.usc_unit_ws_bytes(kmap.ref, kind, cin, cout)
+    ws = workspace(wsb, dev)
+    check(lib.usc_conv_bn_act_backward(kmap.ref, kind, x.data_ptr(), cin, W3.data_ptr(), cout, bref, y.data_ptr(),
+                                       stats.data_ptr(), None if out_relu is None else out_relu.data_ptr(),
+                                       dout.data_ptr(), dy_buf.data_ptr(), None if dres is None else dres.data_ptr(),
+                                       dx.data_ptr() if need_dx else None, int(bool(dx_accumulate)), dW.data_ptr(),
+                                       int(tW is not None), dg.data_ptr(), db.data_ptr(), int(bn_in_place),
+                                       ws.data_ptr(), ws.numel(), ops._stream()), "usc_conv_bn_act_backward")
+    if tW is not None:
+        ops._grad_written(W_param)
+        dW = None
+    if bn_in_place:
+        ops._grad_written(g_param, b_param)
+        dg = db = None
+    return (dx if need_dx else None), dres, dW, dg, db
+
+
+def _w3(W):
+    return W if W.dim() == 3 else W[None]
+
+
+class _Unit(torch.autograd.Function):
+    """out = [relu](BN(conv(x)) [+ residual]) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, W, gamma, beta, residual, bn, kmap, kind, relu):
+        x = x.contiguous()
+        res = None if residual is None else residual.contiguous()
+        W3 = _w3(W).contiguous()
+        y, stats, out = unit_forward(x, W3, bn, kmap, kind, res, relu)
+        ctx.save_for_backward(x, W3, y, stats, out if relu else None)
+        ctx.bn, ctx.kmap, ctx.kind, ctx.has_res = bn, kmap, kind, residual is not None
+        ctx.params = (W, gamma, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W3, y, stats, out_relu = ctx.saved_tensors
+        dout = dout.contiguous()
+        W, gamma, beta = ctx.params
+        dy = torch.empty_like(y)
+        dx, dres, dW, dg, db = unit_backward(x, W3, ctx.bn, ctx.kmap, ctx.kind, y, stats, out_relu, dout, dy,
+                                             ctx.has_res, None, False, ctx.needs_input_grad[0], W, gamma, beta)
+        if dW is not None and W.dim() == 2:
+            dW = dW.view(W.shape)
+        return dx, dW, dg, db, dres, None, None, None, None
+
+
+def conv_bn_act(x, conv_weight, bn, kmap, kind, residual=None, relu=True):
+    return _Unit.apply(x, conv_weight, bn.weight, bn.bias, residual, bn, kmap, kind, relu)
+
+
+class _BasicBlock(torch.autograd.Function):
+    """relu(norm2(conv2(relu(norm1(conv1(x))))) + residual), residual = x or norm_d(conv_d(x))
+    (reference models/modules/resnet_block.py:48-64, models/resnet.py:124-146) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, W1, g1, b1, W2, g2, b2, Wd, gd, bd, bns, kmap, kmap_id):
+        x = x.contiguous()
+        bn1, bn2, bnd = bns
+        W1c, W2c = W1.contiguous(), W2.contiguous()
+        y1, st1, a1 = unit_forward(x, W1c, bn1, kmap, SAME, None, True)
+        saved_d = (None, None, None)
+        if Wd is not None:
+            Wdc = _w3(Wd).contiguous()
+            yd, std, r = unit_forward(x, Wdc, bnd, kmap_id, SAME, None, False)
+            saved_d = (Wdc, yd, std)
+        else:
+            r = x
+        y2, st2, out = unit_forward(a1, W2c, bn2, kmap, SAME, r, True)
+        ctx.save_for_backward(x, W1c, W2c, y1, st1, a1, y2, st2, out, *saved_d)
+        ctx.bns, ctx.kmap, ctx.kmap_id = bns, kmap, kmap_id
+        ctx.params = (W1, g1, b1, W2, g2, b2, Wd, gd, bd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, W1c, W2c, y1, st1, a1, y2, st2, out, Wdc, yd, std = ctx.saved_tensors
+        W1, g1, b1, W2, g2, b2, Wd, gd, bd = ctx.params
+        bn1, bn2, bnd = ctx.bns
+        dout = dout.contiguous()
+        need_dx = ctx.needs_input_grad[0]
+        dy = torch.empty_like(y2)                 # d(conv output) scratch, shared by the units (same shape)
+        # unit 2: dout -> (d a1, d residual)
+        da1, dres, dW2, dg2, db2 = unit_backward(a1, W2c, bn2, ctx.kmap, SAME, y2, st2, out, dout, dy, True, None,
+                                                 False, True, W2, g2, b2)
+        dWd = dgd = dbd = None
+        if Wdc is None:
+            # identity residual: conv1's input gradient is accumulated straight onto the residual gradient
+            dx, _, dW1, dg1, db1 = unit_backward(x, W1c, bn1, ctx.kmap, SAME, y1, st1, a1, da1, dy, False, dres, True,
+                                                 need_dx, W1, g1, b1)
+        else:
+            dx, _, dW1, dg1, db1 = unit_backward(x, W1c, bn1, ctx.kmap, SAME, y1, st1, a1, da1, dy, False, None, False,
+                                                 need_dx, W1, g1, b1)
+            dx, _, dWd, dgd, dbd = unit_backward(x, Wdc, bnd, ctx.kmap_id, SAME, yd, std, None, dres, dy, False, dx,
+                                                 True, need_dx, Wd, gd, bd)
+            if dWd is not None and Wd.dim() == 2:
+                dWd = dWd.view(Wd.shape)
+        return dx, dW1, dg1, db1, dW2, dg2, db2, dWd, dgd, dbd, None, None, None
+
+
+def basic_block(x, block, kmap, kmap_id):
+    """`block`: a BasicBlock module (conv1/norm1/conv2/norm2/downsample)."""
+    ds = block.downsample
+    if ds is not None:
+        Wd, gd, bd, bnd = ds[0].kernel, ds[1].bn.weight, ds[1].bn.bias, ds[1].bn
+    else:
+        Wd = gd = bd = bnd = None
+    bn1, bn2 = block.norm1.bn, block.norm2.bn
+    return _BasicBlock.apply(x, block.conv1.kernel, bn1.weight, bn1.bias, block.conv2.kernel, bn2.weight, bn2.bias,
+                             Wd, gd, bd, (bn1, bn2, bnd), kmap, kmap_id)
