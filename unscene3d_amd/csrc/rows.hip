@@ -27,6 +27,7 @@ struct StatArgs {
 };
 
 constexpr int kStatMaxBlocks = 1024;
+constexpr int kStatUnroll = 4;   // row loads in flight per thread
 
 template <int VEC, int MODE>
 __global__ __launch_bounds__(256) void colstats_kernel(StatArgs a, double* __restrict__ partial) {
@@ -48,36 +49,50 @@ __global__ __launch_bounds__(256) void colstats_kernel(StatArgs a, double* __res
     }
   }
   if (active) {
-    for (int64_t r = (int64_t)blockIdx.x * RP + rl; r < a.n; r += (int64_t)gridDim.x * RP) {
-      const int64_t off = r * c + cg * VEC;
-      float xv[VEC], yv[VEC], ov[VEC];
-      if (VEC == 4) {
-        float4 t = *reinterpret_cast<const float4*>(a.x + off);
-        xv[0] = t.x; xv[1] = t.y; xv[2] = t.z; xv[3] = t.w;
-        if (a.y) {
-          float4 u = *reinterpret_cast<const float4*>(a.y + off);
-          yv[0] = u.x; yv[1] = u.y; yv[2] = u.z; yv[3] = u.w;
+    const int64_t stride = (int64_t)gridDim.x * RP;
+    for (int64_t r0 = (int64_t)blockIdx.x * RP + rl; r0 < a.n; r0 += stride * kStatUnroll) {
+      // kStatUnroll rows in flight per thread: the loads are issued together (one row per thread and iteration left
+      // ~4 MB in flight chip-wide, 2.9 TB/s); the sums keep the row order, so the result is unchanged
+      float xv[kStatUnroll][VEC], yv[kStatUnroll][VEC], ov[kStatUnroll][VEC];
+#pragma unroll
+      for (int u = 0; u < kStatUnroll; ++u) {
+        const int64_t r = r0 + u * stride;
+        if (r < a.n) {
+          const int64_t off = r * c + cg * VEC;
+          if (VEC == 4) {
+            float4 t = *reinterpret_cast<const float4*>(a.x + off);
+            xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+            if (a.y) {
+              float4 w = *reinterpret_cast<const float4*>(a.y + off);
+              yv[u][0] = w.x; yv[u][1] = w.y; yv[u][2] = w.z; yv[u][3] = w.w;
+            }
+            if (MODE == STAT_BN_BWD && a.y_out) {
+              float4 w = *reinterpret_cast<const float4*>(a.y_out + off);
+              ov[u][0] = w.x; ov[u][1] = w.y; ov[u][2] = w.z; ov[u][3] = w.w;
+            }
+          } else {
+            xv[u][0] = a.x[off];
+            if (a.y) yv[u][0] = a.y[off];
+            if (MODE == STAT_BN_BWD && a.y_out) ov[u][0] = a.y_out[off];
+          }
         }
-        if (MODE == STAT_BN_BWD && a.y_out) {
-          float4 u = *reinterpret_cast<const float4*>(a.y_out + off);
-          ov[0] = u.x; ov[1] = u.y; ov[2] = u.z; ov[3] = u.w;
-        }
-      } else {
-        xv[0] = a.x[off];
-        if (a.y) yv[0] = a.y[off];
-        if (MODE == STAT_BN_BWD && a.y_out) ov[0] = a.y_out[off];
       }
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        if (MODE == STAT_XY) {
-          s1[v] += (double)xv[v];
-          s2[v] += (double)xv[v] * (double)(a.y ? yv[v] : xv[v]);
-        } else {
-          float g = yv[v];
-          if (a.y_out && !(ov[v] > 0.f)) g = 0.f;
-          const float xhat = (xv[v] - mu[v]) * is[v];
-          s1[v] += (double)g;
-          s2[v] += (double)g * (double)xhat;
+      for (int u = 0; u < kStatUnroll; ++u) {
+        if (r0 + u * stride < a.n) {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            if (MODE == STAT_XY) {
+              s1[v] += (double)xv[u][v];
+              s2[v] += (double)xv[u][v] * (double)(a.y ? yv[u][v] : xv[u][v]);
+            } else {
+              float g = yv[u][v];
+              if (a.y_out && !(ov[u][v] > 0.f)) g = 0.f;
+              const float xhat = (xv[u][v] - mu[v]) * is[v];
+              s1[v] += (double)g;
+              s2[v] += (double)g * (double)xhat;
+            }
+          }
         }
       }
     }
@@ -190,7 +205,7 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ gamma, const floa
 
 static int colstats_blocks(int64_t n, int c, int vec) {
   const int CT = c / vec, RP = 256 / CT;
-  int64_t b = ceil_div(n, (int64_t)RP * 16);
+  int64_t b = ceil_div(n, (int64_t)RP * 4 * kStatUnroll);
   if (b > kStatMaxBlocks) b = kStatMaxBlocks;
   if (b < 1) b = 1;
   return (int)b;
@@ -272,14 +287,29 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
       gv[0] = dy[e];
       if (y_out) ov[0] = y_out[e];
     }
+    // the five per-channel vectors as 16-byte loads (one dword load each per element made the kernel LSU-bound:
+    // 3.1 TB/s against 6 TB/s for the forward apply kernel with the same traffic pattern)
+    float mu[VEC], is[VEC], ga[VEC], mg[VEC], mx[VEC];
+    if (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4*>(mean + ch0);
+      mu[0] = t.x; mu[1] = t.y; mu[2] = t.z; mu[3] = t.w;
+      t = *reinterpret_cast<const float4*>(invstd + ch0);
+      is[0] = t.x; is[1] = t.y; is[2] = t.z; is[3] = t.w;
+      ga[0] = gamma[ch0]; ga[1] = gamma[ch0 + 1]; ga[2] = gamma[ch0 + 2]; ga[3] = gamma[ch0 + 3];   // a parameter: 4-byte aligned only
+      t = *reinterpret_cast<const float4*>(mean_g + ch0);
+      mg[0] = t.x; mg[1] = t.y; mg[2] = t.z; mg[3] = t.w;
+      t = *reinterpret_cast<const float4*>(mean_gx + ch0);
+      mx[0] = t.x; mx[1] = t.y; mx[2] = t.z; mx[3] = t.w;
+    } else {
+      mu[0] = mean[ch0]; is[0] = invstd[ch0]; ga[0] = gamma[ch0]; mg[0] = mean_g[ch0]; mx[0] = mean_gx[ch0];
+    }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const int ch = ch0 + v;
       float g = gv[v];
       if (y_out && !(ov[v] > 0.f)) g = 0.f;
       gv[v] = g;
-      const float xhat = (xv[v] - mean[ch]) * invstd[ch];
-      ox[v] = gamma[ch] * invstd[ch] * (g - mean_g[ch] - xhat * mean_gx[ch]);
+      const float xhat = (xv[v] - mu[v]) * is[v];
+      ox[v] = ga[v] * is[v] * (g - mg[v] - xhat * mx[v]);
     }
     if (VEC == 4) {
       *reinterpret_cast<float4*>(dx + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
