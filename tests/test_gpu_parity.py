@@ -698,7 +698,8 @@ def test_layernorm_matches_torch(device, rows, d):
 
 
 @pytest.mark.parametrize("rows,n_in,n_out", [(100, 128, 128), (100, 128, 1024), (100, 1024, 128), (1, 32, 64), (333, 96, 160),
-                                              (3200, 128, 128), (12800, 96, 128)])
+                                              (3200, 128, 128), (12800, 96, 128), (609, 128, 128), (800, 256, 128),
+                                              (2049, 128, 384)])
 def test_small_row_linear_matches_torch(device, rows, n_in, n_out):
     """ops.linear vs F.linear in float64: usc_linear_fwd/bwd for the few-row layers of the decoder; for thousands of
     rows (projections of the sampled voxels) the weight gradient goes through usc_spconv_wgrad with identity pairs."""
@@ -717,6 +718,26 @@ def test_small_row_linear_matches_torch(device, rows, n_in, n_out):
     y.backward(_dev(dy, device).view(rows, 1, n_out))
     assert rel_err(y.detach().view(rows, n_out), yr.detach()) < 1e-5
     assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("S,Q", [(609, 100), (300, 100), (1500, 64)])
+def test_mask_logits_with_padded_queries(device, S, Q):
+    """models.mask3d._mask_logits (segment features x query embeddings, Q padded to a multiple of 32 for the row GEMM
+    kernels) vs the plain product in float64: values and both gradients (reference mask3d.py:425)."""
+    from unscene3d_amd.models.mask3d import _mask_logits
+
+    g = torch.Generator().manual_seed(S + Q)
+    f = torch.randn(S, 128, generator=g)
+    e = torch.randn(Q, 128, generator=g)
+    dy = torch.randn(S, Q, generator=g)
+    fr, er = f.double().requires_grad_(), e.double().requires_grad_()
+    (fr @ er.T).backward(dy.double())
+    fd, ed = _dev(f, device).requires_grad_(), _dev(e, device).requires_grad_()
+    out = _mask_logits(fd, ed)
+    assert tuple(out.shape) == (S, Q)
+    out.backward(_dev(dy, device))
+    assert rel_err(out.detach(), (fr @ er.T).detach()) < 1e-5
+    assert rel_err(fd.grad, fr.grad) < 1e-5 and rel_err(ed.grad, er.grad) < 1e-5
 
 
 @pytest.mark.parametrize("S", [100, 3200])

@@ -85,7 +85,7 @@ class Mask3D(nn.Module):
             for hlevel in self.hlevels:
                 ca.append(CrossAttentionLayer(d_model=self.mask_dim, nhead=num_heads, dropout=dropout,
                                               normalize_before=pre_norm))
-                sq.append(nn.Linear(sizes[hlevel], self.mask_dim))
+                sq.append(Linear(sizes[hlevel], self.mask_dim))
                 sa.append(SelfAttentionLayer(d_model=self.mask_dim, nhead=num_heads, dropout=dropout,
                                              normalize_before=pre_norm))
                 ffn.append(FFNLayer(d_model=self.mask_dim, dim_feedforward=dim_feedforward, dropout=dropout,
@@ -281,7 +281,7 @@ class Mask3D(nn.Module):
         output_masks, output_segments = [], []
         if point2segment is not None:
             for i, seg_feat in enumerate(mask_segments):
-                output_segments.append(seg_feat @ mask_embed[i].T)
+                output_segments.append(_mask_logits(seg_feat, mask_embed[i]))
                 if ret_attn_mask:   # per-voxel logits only feed the (detached) attention masks
                     with torch.no_grad():
                         output_masks.append(ops.gather_rows(output_segments[-1].detach().contiguous(),
@@ -289,7 +289,7 @@ class Mask3D(nn.Module):
         else:
             per_scene = mask_features.decomposed_features
             for i in range(len(per_scene)):
-                output_masks.append(per_scene[i] @ mask_embed[i].T)
+                output_masks.append(_mask_logits(per_scene[i], mask_embed[i]))
 
         if ret_attn_mask:
             attn_mask = me.SparseTensor(features=torch.cat(output_masks).detach(),
@@ -319,6 +319,19 @@ class Linear(nn.Linear):
         if x.is_cuda and x.dtype == torch.float32:
             return ops.linear(x, self.weight, self.bias)
         return super().forward(x)
+
+
+def _mask_logits(feats, mask_embed):
+    """feats [S, d] @ mask_embed[Q, d]^T -> [S, Q] (reference mask3d.py:425,430).  On the device the Q query
+    embeddings are padded to a multiple of 32 so that the product runs on this library's row GEMM kernels (forward,
+    d feats, d mask_embed); the padded columns are cut off again as a view."""
+    Q = mask_embed.shape[0]
+    if not (feats.is_cuda and feats.dtype == torch.float32 and feats.shape[1] % 32 == 0):
+        return feats @ mask_embed.T
+    pad = (-Q) % 32
+    W = F.pad(mask_embed, (0, 0, 0, pad)) if pad else mask_embed
+    out = ops.linear(feats, W.contiguous())
+    return out[:, :Q] if pad else out
 
 
 def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None, mask_bsl=None):

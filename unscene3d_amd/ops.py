@@ -790,6 +790,12 @@ def _small_linear_ok(rows, n_in, n_out):
     return rows <= SMALL_ROWS and n_in % 32 == 0 and n_out % 32 == 0 and n_in >= 32 and n_out >= 32
 
 
+def _rows_gemm_ok(rows, n_in, n_out):
+    """Many-row linear layers (the sampled voxels of a decoder pass: 200 ... 12 800 rows; segment logits) run on the
+    1x1-convolution kernels — the library's heuristics pick 30-95 us kernels for these 0.1-0.4 GFLOP shapes."""
+    return rows > SMALL_ROWS and n_in % 32 == 0 and n_out % 32 == 0
+
+
 def _lin_fwd(x2, W, b):
     """y = x2 W^T + b for contiguous f32 x2 [M,K], W [N,K] (a contiguous row block is fine)."""
     M, K = x2.shape
@@ -798,6 +804,9 @@ def _lin_fwd(x2, W, b):
         y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
         check(lib.usc_linear_fwd(_ptr(x2), _ptr(W), _ptr(b), M, N, K, _ptr(y), _stream()), "usc_linear_fwd")
         return y
+    if _rows_gemm_ok(M, K, N) and W.is_contiguous():
+        Wt = weight_transpose(W.view(1, N, K), mirror=False)          # [1, K, N]: the conv kernels' [cin, cout]
+        return gather_gemm(x2, Wt, None, M, bias=b)
     return torch.addmm(b, x2, W.t()) if b is not None else x2 @ W.t()
 
 
@@ -810,9 +819,9 @@ def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False):
         check(lib.usc_linear_bwd(_ptr(dy2), _ptr(x2), _ptr(W), M, N, K, _ptr(dx), _ptr(dW_out), _ptr(db_out),
                                  int(accumulate), _stream()), "usc_linear_bwd")
         return dx
-    if M >= 2048 and K % 32 == 0 and N % 32 == 0 and dW_out.is_contiguous():
-        # dW[N,K] = dy^T x over thousands of rows (projections of the sampled voxels): the weight-gradient kernel with
-        # identity pairs (a = dy, b = x); the library picks a 32x32x256 tile for this shape (73 us at 12 800 rows)
+    rows_ok = _rows_gemm_ok(M, K, N) and W.is_contiguous()
+    if rows_ok and dW_out.is_contiguous():
+        # dW[N,K] = dy^T x over many rows: the weight-gradient kernel with identity pairs (a = dy, b = x)
         if accumulate:
             wgrad(dy2, x2, 1, into=dW_out)
         else:
@@ -826,7 +835,11 @@ def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False):
             db_out.add_(dy2.sum(0))
         else:
             torch.sum(dy2, 0, out=db_out)
-    return dy2 @ W if need_dx else None
+    if not need_dx:
+        return None
+    if rows_ok:
+        return gather_gemm(dy2, W.view(1, N, K), None, M)                # W [N, K] is this product's [cin, cout]
+    return dy2 @ W
 
 
 class _LinearRows(torch.autograd.Function):
