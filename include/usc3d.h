@@ -269,6 +269,12 @@ typedef struct usc_bn {
   int32_t training;
 } usc_bn;
 
+/* Optional: a second stream of the CALLER (NULL switches it off again; per device).
+ * usc_conv_backward / usc_conv_bn_act_backward then fork the weight gradient of
+ * maps with <= 24 576 rows onto it and join before returning the stream to the
+ * caller's order: on the coarse U-Net levels the input-gradient and weight-gradient
+ * launches are latency-bound and run side by side.  Results are unchanged. */
+int usc_set_side_stream(usc_stream_t side);
 /* Scratch bytes covering forward AND backward of one convolution / one unit. */
 int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin,
                           int32_t cout);

@@ -74,6 +74,23 @@ int table_gemm(const usc_kmap* m, const int32_t* nbr, const float* in, int64_t n
   return usc_spconv_gather_gemm(in, n_in, cin, W, K, cout, nbr, n_out, bias, out, accumulate, wt, w, b, s);
 }
 
+// ---- fork/join of the weight gradient onto a side stream --------------------------------------------------------
+// The input-gradient and the weight-gradient kernels of one convolution are independent.  On the coarse levels of
+// the U-Net (hundreds to a few thousand rows) both are latency-bound launches that occupy a fraction of the 256 CUs,
+// so running them side by side costs about as much as the longer of the two.  The side stream is the CALLER's
+// (usc_set_side_stream); the fork and the join are events inside the one call, so nothing outlives it: when the
+// call returns, everything it queued is ordered before whatever the caller queues next on its stream.
+struct SideStream { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+SideStream g_side[16];
+constexpr int64_t kForkMaxRows = 24576;   // larger maps fill the chip on their own (and the tile-compacted kernel
+                                          // sizes its tiles for whole rounds of 256 CUs)
+
+SideStream* side_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  return g_side[dev].st ? &g_side[dev] : nullptr;
+}
+
 struct ConvShape { int64_t n_in, n_out; };   // rows of the convolution's input / output feature matrices
 inline ConvShape conv_shape(const usc_kmap* m, int kind) {
   return kind == USC_CONV_UP ? ConvShape{m->n_out, m->n_in} : ConvShape{m->n_in, m->n_out};
@@ -92,27 +109,53 @@ int check_map(const usc_kmap* m, int kind, int cin, int cout, const char* who) {
 
 extern "C" {
 
-int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin, int32_t cout) {
-  if (!m) return 0;
+int usc_set_side_stream(usc_stream_t side) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    set_error("usc_set_side_stream: unsupported device index");
+    return USC_ERR_ARG;
+  }
+  SideStream& e = g_side[dev];
+  if (!side) {
+    e.st = nullptr;
+    return USC_OK;
+  }
+  if (!e.fork) {
+    if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) {
+      set_error("usc_set_side_stream: hipEventCreate failed");
+      return USC_ERR_LAUNCH;
+    }
+  }
+  e.st = as_stream(side);
+  return USC_OK;
+}
+
+static void conv_ws_parts(const usc_kmap* m, int kind, int cin, int cout, int64_t* fwd, int64_t* dgrad, int64_t* wg) {
   const int K = m->K;
   const ConvShape sh = conv_shape(m, kind);
   const int64_t wbytes = align_up((int64_t)K * cin * cout * 4, 256);
-  int64_t fwd, dgrad;
   if (kind == USC_CONV_SAME) {
-    fwd = table_gemm_ws(m, sh.n_out, cin, cout, K, false);
-    dgrad = table_gemm_ws(m, sh.n_in, cout, cin, K, true);
+    *fwd = table_gemm_ws(m, sh.n_out, cin, cout, K, false);
+    *dgrad = table_gemm_ws(m, sh.n_in, cout, cin, K, true);
   } else if (kind == USC_CONV_DOWN) {
-    fwd = table_gemm_ws(m, sh.n_out, cin, cout, K, false);
-    dgrad = wbytes;                                            // transposed weights for the pair-list form
+    *fwd = table_gemm_ws(m, sh.n_out, cin, cout, K, false);
+    *dgrad = wbytes;                                            // transposed weights for the pair-list form
   } else {
-    fwd = 0;                                                   // pair-list form, no scratch
-    dgrad = wbytes + table_gemm_ws(m, sh.n_in, cout, cin, K, false);
+    *fwd = 0;                                                   // pair-list form, no scratch
+    *dgrad = wbytes + table_gemm_ws(m, sh.n_in, cout, cin, K, false);
   }
+  *dgrad = align_up(*dgrad + 256, 256);
   const int64_t rows = m->nbr ? m->pair_capacity : sh.n_in;
-  const int64_t wg = align_up(usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows), 256);
-  int64_t b = fwd > dgrad ? fwd : dgrad;
-  if (wg > b) b = wg;
-  return b + 256;
+  *wg = align_up(usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows), 256);
+}
+
+int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin, int32_t cout) {
+  if (!m) return 0;
+  int64_t fwd, dgrad, wg;
+  conv_ws_parts(m, kind, cin, cout, &fwd, &dgrad, &wg);
+  const int64_t bwd = dgrad + wg;          // disjoint regions: the two may run on different streams
+  return (fwd > bwd ? fwd : bwd) + 256;
 }
 
 int usc_conv_forward(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
@@ -141,6 +184,22 @@ int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t c
   const int K = m->K;
   USC_REQUIRE(x && W && dy, "usc_conv_backward: null pointer");
   WsCursor cur{(char*)ws, ws ? ws_bytes : 0, 0};
+  // fork: the weight gradient on the side stream while this stream runs the input gradient
+  SideStream* side = (dx && dW && sh.n_in > 0 && sh.n_in <= kForkMaxRows && sh.n_out <= kForkMaxRows) ? side_for_current_device() : nullptr;
+  hipStream_t wst = as_stream(s);
+  int64_t dgrad_bytes = 0;
+  if (side) {
+    // disjoint scratch: [0, dgrad_bytes) for this stream, the rest for the side stream
+    int64_t f_, w_;
+    conv_ws_parts(m, kind, cin, cout, &f_, &dgrad_bytes, &w_);
+    if (dgrad_bytes + w_ > cur.bytes || hipEventRecord(side->fork, as_stream(s)) != hipSuccess ||
+        hipStreamWaitEvent(side->st, side->fork, 0) != hipSuccess) {
+      side = nullptr;
+      dgrad_bytes = 0;
+    } else {
+      wst = side->st;
+    }
+  }
   if (dx && sh.n_in > 0) {
     if (kind == USC_CONV_SAME) {
       // stride-1 map: the mirrored offset reaches the rows that read row i; transpose folded where the kernel can
@@ -159,23 +218,31 @@ int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t c
       // dx[coarse] = sum_k dy[child k of coarse] W[k]^T: the child table again, gather form
       if (!rc) rc = table_gemm(m, m->nbr, dy, sh.n_out, cout, Wt, K, cin, sh.n_in, nullptr, dx, dx_accumulate, 0, cur, s);
     }
-    if (rc) return rc;
+    if (rc) dW = nullptr;   // skip the weight gradient, still join below
   }
   if (dW) {
-    WsCursor wc{(char*)ws, ws ? ws_bytes : 0, 0};     // the weight gradient may reuse the scratch (stream order)
+    // same stream: the weight gradient reuses the scratch from the start (stream order); forked: its own region
+    WsCursor wc{(char*)ws, ws ? ws_bytes : 0, side ? dgrad_bytes : 0};
     const int64_t rows = m->nbr ? m->pair_capacity : sh.n_in;
     const int64_t b = usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows);
     void* w = wc.take(b);
-    USC_REQUIRE(w, "usc_conv_backward: workspace too small (weight gradient)");
-    if (!m->nbr)
-      rc = usc_spconv_wgrad(x, cin, dy, cout, 1, nullptr, nullptr, nullptr, sh.n_in, dW, dW_accumulate, w, b, s);
+    if (!w) set_error("usc_conv_backward: workspace too small (weight gradient)");
+    usc_stream_t ws_stream = (usc_stream_t)wst;
+    if (!w) rc = USC_ERR_ARG;
+    else if (!m->nbr)
+      rc = usc_spconv_wgrad(x, cin, dy, cout, 1, nullptr, nullptr, nullptr, sh.n_in, dW, dW_accumulate, w, b, ws_stream);
     else if (kind == USC_CONV_UP)
-      rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_out, m->pair_in, m->koff, rows, dW, dW_accumulate, w, b, s);
+      rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_out, m->pair_in, m->koff, rows, dW, dW_accumulate, w, b, ws_stream);
     else
-      rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_in, m->pair_out, m->koff, rows, dW, dW_accumulate, w, b, s);
-    if (rc) return rc;
+      rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_in, m->pair_out, m->koff, rows, dW, dW_accumulate, w, b, ws_stream);
   }
-  return USC_OK;
+  if (side) {   // join (also on an error above: the caller's stream must not run ahead of the side stream)
+    if (hipEventRecord(side->join, side->st) != hipSuccess || hipStreamWaitEvent(as_stream(s), side->join, 0) != hipSuccess) {
+      set_error("usc_conv_backward: joining the side stream failed");
+      return USC_ERR_LAUNCH;
+    }
+  }
+  return rc;
 }
 
 int64_t usc_unit_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin, int32_t cout) {

@@ -98,10 +98,11 @@ def freemask_voxelize(batch, ignore_label, voxel_size, mode, ignore_class_thresh
 
     target, target_full = [], []
     if tables:
-        segment2label = []
+        segment2label, n_segments = [], []
         for t in tables:
             seg = t[:, -1]
             uniq, inv = torch.unique(seg, return_inverse=True)
+            n_segments.append(int(uniq.shape[0]))           # known on the host here: saves the model a read-back
             first = torch.full((uniq.shape[0],), seg.shape[0], dtype=torch.long, device=dev)
             first.scatter_reduce_(0, inv, torch.arange(seg.shape[0], device=dev), reduce="amin")
             t[:, -1] = inv                                   # contiguous segment ids (np.unique return_inverse)
@@ -109,6 +110,7 @@ def freemask_voxelize(batch, ignore_label, voxel_size, mode, ignore_class_thresh
         target = get_instance_freemasks(tables, list_segments=segment2label)
         for i in range(len(target)):
             target[i]["point2segment"] = tables[i][:, -1].contiguous()   # a row-gather index: the kernels take dense i64
+            target[i]["num_segments"] = torch.tensor(n_segments[i])     # host scalar (a tensor like the other entries)
         full = [m if isinstance(m, torch.Tensor) else torch.as_tensor(np.asarray(m)) for m in original_freemasks]
         target_full = get_instance_freemasks(full)
         for i in range(len(target_full)):

@@ -154,7 +154,11 @@ class Mask3D(nn.Module):
             out.append([per_scene])
         return out
 
-    def forward(self, x, point2segment=None, raw_coordinates=None, is_eval=False):
+    def forward(self, x, point2segment=None, raw_coordinates=None, is_eval=False, num_segments=None):
+        """`num_segments` (optional, one int per scene): the number of segments = point2segment.max() + 1 when the
+        caller already knows it on the host (the collate does: it relabels the segments with torch.unique).  Without
+        it the count is read back from the device here, which makes the host wait for the whole backbone forward
+        before it can issue the decoder."""
         pcd_features, aux = self.backbone(x)
         n_scenes = len(x.decomposed_coordinates)
 
@@ -171,8 +175,11 @@ class Mask3D(nn.Module):
         mask_features = self.mask_features_head(pcd_features)
         mask_segments, seg_csr = None, None
         if self.train_on_segments:
-            seg_csr = [ops.segment_csr(p2s.to(torch.int64).contiguous(), int(p2s.max().item()) + 1)
-                       for p2s in point2segment]
+            if num_segments is None:
+                num_segments = [None] * len(point2segment)
+            seg_csr = [ops.segment_csr(p2s.to(torch.int64).contiguous(),
+                                       int(p2s.max().item()) + 1 if ns is None else int(ns))
+                       for p2s, ns in zip(point2segment, num_segments)]
             mask_segments = [ops.segment_mean(f, csr) for f, csr in zip(mask_features.decomposed_features, seg_csr)]
 
         sampled_coords = None

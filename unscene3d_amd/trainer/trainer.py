@@ -40,8 +40,9 @@ class InstanceSegmentation(nn.Module):
                                       class_weights=l.class_weights, directions=l.directions,
                                       use_droploss=l.use_droploss, droploss_iou_thresh=l.droploss_iou_thresh)
 
-    def forward(self, x, point2segment=None, raw_coordinates=None, is_eval=False):
-        return self.model(x, point2segment, raw_coordinates=raw_coordinates, is_eval=is_eval)
+    def forward(self, x, point2segment=None, raw_coordinates=None, is_eval=False, num_segments=None):
+        return self.model(x, point2segment, raw_coordinates=raw_coordinates, is_eval=is_eval,
+                          num_segments=num_segments)
 
     def training_step(self, batch, batch_idx=0):
         """-> (total weighted loss tensor, dict of weighted loss tensors) or None when the step is skipped."""
@@ -61,8 +62,10 @@ class InstanceSegmentation(nn.Module):
             dev = next(self.parameters()).device
             x = ME.SparseTensor(coordinates=data.coordinates, features=feats, device=dev)
         try:
+            ns = [t.get("num_segments") for t in target]
             output = self.forward(x, point2segment=[t["point2segment"] for t in target],
-                                  raw_coordinates=raw_coordinates)
+                                  raw_coordinates=raw_coordinates,
+                                  num_segments=None if any(n is None or n.is_cuda for n in ns) else ns)
         except RuntimeError as err:
             if err.args and err.args[0] == SINGLE_POINT_ERROR:
                 return None
