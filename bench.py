@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the measured configuration); gloo only to smoke-test the N>1 code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices)")
-    ap.add_argument("--cpu-sample-voxels", type=int, default=15_000)
+    ap.add_argument("--cpu-sample-voxels", type=int, default=10_000,
+                    help="scene size of the cpu_baseline leg (2 x (1 warm-up + 3 timed) passes of the CPU restatement)")
     return ap.parse_args()
 
 
@@ -187,7 +188,6 @@ def cpu_baseline(sample_voxels, mode="mask3d"):
     eu, _ = R.sparse_quantize(ec)
     coords4, feats = R.sparse_collate([ec[eu]], [sc["colors"][eu]])
     feats = torch.from_numpy(feats)
-    model = build_model("cpu") if False else None  # the device model cannot be built on CPU tensors
     from unscene3d_amd.models.res16unet import Res16UNet34C
     torch.manual_seed(1234)
     cfg = SimpleNamespace(bn_momentum=0.02, conv1_kernel_size=3, dilations=[1, 1, 1, 1])
@@ -209,8 +209,22 @@ def cpu_baseline(sample_voxels, mode="mask3d"):
     }
 
 
-def cpu_baseline_mask3d(sample_voxels):
-    """oracle/mask3d_ref.py forward + criterion + backward on one small scene, scaled by voxel count."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_mask3d(sample_voxels, runs=3):
+    """oracle/mask3d_ref.py forward + criterion + backward on one small scene (SURVEY.md §8d "Timing the reference CPU
+    path": ME cannot run, so the baseline is the CPU restatement): one warm-up + `runs` timed passes with all host
+    threads, the same with 3 threads (the reference's scripts export OMP_NUM_THREADS=3,
+    scripts/unsupervised/train_unscene3d.sh:2); median / min / max; value scaled by voxels/150000."""
     import oracle.mask3d_ref as OM
     from oracle import sparse_ref as R
     from unscene3d_amd.config import apply_overrides, default_config, instantiate_model
@@ -221,40 +235,61 @@ def cpu_baseline_mask3d(sample_voxels):
     cfg = apply_overrides(default_config(), ["general.num_targets=3"])
     sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=sample_voxels, seed=2999)[0]
     torch.manual_seed(1234)
-    sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point)
-          for k, v in instantiate_model(cfg).state_dict().items()}
-    t0 = time.perf_counter()
-    ec = R.voxel_floor(sample[0], 0.02)
-    eu, _ = R.sparse_quantize(ec)
-    coords4, feats = R.sparse_collate([ec[eu]], [sample[1][eu]])
-    table = torch.from_numpy(sample[2][eu].astype(np.int64))
-    _, p2s = np.unique(table[:, -1].numpy(), return_inverse=True)
-    p2s = torch.from_numpy(p2s.reshape(-1))
-    S = int(p2s.max()) + 1
-    masks = table[:, 1:-1].bool().T
-    masks = masks[masks.sum(1) > 0]
-    seg_mask = torch.zeros(masks.shape[0], S, dtype=torch.bool)
-    for t in range(masks.shape[0]):
-        seg_mask[t, p2s[masks[t]].unique()] = True
-    target = [{"labels": torch.ones(masks.shape[0], dtype=torch.int64), "masks": masks, "segment_mask": seg_mask,
-               "point2segment": p2s}]
-    feats = torch.from_numpy(feats)
-    out = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], [p2s],
-                            lambda n: torch.randperm(n))
+    sd0 = {k: v.detach().clone() for k, v in instantiate_model(cfg).state_dict().items()}
     m = cfg.matcher
     matcher = HungarianMatcher(m.cost_class, m.cost_mask, m.cost_dice, m.cost_noise_robust, m.num_points)
     wd = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 2.0, "loss_noise_robust": 0.0}
     wd.update({f"{k}_{i}": v for i in range(12) for k, v in list(wd.items())})
     crit = SetCriterion(3, matcher, wd, 0.1, ["labels", "masks"], -1, 3.0, 0.75, -1)
-    losses = crit(out, target, "segment_mask")
-    sum(v * wd[k] for k, v in losses.items() if k in wd).backward()
-    dt = time.perf_counter() - t0
-    nv = coords4.shape[0]
+
+    def one_pass():
+        sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd0.items()}
+        t0 = time.perf_counter()
+        ec = R.voxel_floor(sample[0], 0.02)
+        eu, _ = R.sparse_quantize(ec)
+        coords4, feats = R.sparse_collate([ec[eu]], [sample[1][eu]])
+        table = torch.from_numpy(sample[2][eu].astype(np.int64))
+        _, p2s = np.unique(table[:, -1].numpy(), return_inverse=True)
+        p2s = torch.from_numpy(p2s.reshape(-1))
+        S = int(p2s.max()) + 1
+        masks = table[:, 1:-1].bool().T
+        masks = masks[masks.sum(1) > 0]
+        seg_mask = torch.zeros(masks.shape[0], S, dtype=torch.bool)
+        for t in range(masks.shape[0]):
+            seg_mask[t, p2s[masks[t]].unique()] = True
+        target = [{"labels": torch.ones(masks.shape[0], dtype=torch.int64), "masks": masks, "segment_mask": seg_mask,
+                   "point2segment": p2s}]
+        feats = torch.from_numpy(feats)
+        out = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], [p2s], lambda n: torch.randperm(n))
+        losses = crit(out, target, "segment_mask")
+        sum(v * wd[k] for k, v in losses.items() if k in wd).backward()
+        return time.perf_counter() - t0, coords4.shape[0]
+
+    all_threads = torch.get_num_threads()
+    legs = {}
+    for name, nthr in (("all_threads", all_threads), ("omp3", 3)):
+        torch.set_num_threads(nthr)
+        one_pass()                                   # warm-up (allocator, thread pool, lazy imports)
+        ts = []
+        for _ in range(runs):
+            dt, nv = one_pass()
+            ts.append(dt)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        legs[name] = {"threads": nthr, "median_s": med, "min_s": ts[0], "max_s": ts[-1],
+                      "scenes_per_s_150k_equiv": (nv / VOXELS) / med}
+    torch.set_num_threads(all_threads)
+    a = legs["all_threads"]
     return {
-        "value": (nv / VOXELS) / dt, "unit": "scenes/s (150k-voxel-scene equivalents)",
-        "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"oracle Mask3D self-train step (voxelise+maps+Res16UNet34C+decoder+Hungarian+losses, fwd+bwd, "
-                  f"no optimizer) on one {nv}-voxel synthetic scene, {dt:.1f} s, scaled by voxels/150000",
+        "value": a["scenes_per_s_150k_equiv"],
+        "unit": "scenes/s in 150k-voxel-scene equivalents (measured on a smaller scene, scaled by voxels/150000)",
+        "cores": all_threads, "kind": "port", "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
+        "runs": runs, "legs": legs,
+        "sample": f"oracle Mask3D self-train step (voxelise + maps + Res16UNet34C + decoder + Hungarian + losses, forward "
+                  f"+ backward, no optimizer; CPU restatement, not the reference binary: MinkowskiEngine cannot run "
+                  f"here) on one {nv}-voxel synthetic scene; 1 warm-up + {runs} timed passes per leg; all threads: "
+                  f"median {a['median_s']:.2f} s (min {a['min_s']:.2f}, max {a['max_s']:.2f}); 3 threads "
+                  f"(the reference's OMP_NUM_THREADS=3): median {legs['omp3']['median_s']:.2f} s",
     }
 
 

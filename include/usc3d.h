@@ -656,6 +656,35 @@ int usc_elastic_displace(const void* xyz_in, int32_t is_f64, int64_t n, int32_t 
                          const double* axis_x, const double* axis_y, const double* axis_z,
                          double magnitude, void* xyz_out, usc_stream_t s);
 
+/* ------------------------------------------------------------------------
+ * F2  Felzenszwalb mesh over-segmentation — replaces the reference's
+ * felzenszwalb_cpp extension (utils/cpp_utils/segmentator.cpp:17-154
+ * segment_graph / segment_mesh; caller pseudo_masks/datasets/scannet.py:156-197).
+ * Device: face normals, vertex normals (the running blend of face normals in
+ * face order, :62-82), edge weights (:85-121) — bit-equal to the reference
+ * (separately rounded operations).  The caller sorts the 3F edges by weight on
+ * the device (stable) and hands the sorted lists to usc_felz_merge_host for the
+ * two sequential merge loops (:17-44, :127-139).
+ * ---------------------------------------------------------------------- */
+/* face_normals f32[F,3] = normalised cross(p2-p1, p3-p1). */
+int usc_felz_face_normals(const float* vertices, const int32_t* faces,
+                          int64_t n_faces, float* face_normals, usc_stream_t s);
+/* corner_order i64[3F]: the (face, corner) entries 3f+j sorted by their vertex,
+ * stable (usc_segment_csr over faces.reshape(-1)); vertex_off i64[V+1]. */
+int usc_felz_vertex_normals(const float* face_normals, const int64_t* corner_order,
+                            const int64_t* vertex_off, int64_t n_vertices,
+                            float* normals, usc_stream_t s);
+/* Edge 3f+0 = (i1,i2), 3f+1 = (i1,i3), 3f+2 = (i3,i2): endpoints and weight. */
+int usc_felz_edge_weights(const float* vertices, const float* colors,
+                          const float* normals, const int32_t* faces,
+                          int64_t n_faces, int32_t* edge_a, int32_t* edge_b,
+                          float* weights, usc_stream_t s);
+/* HOST pointers (the one exception in this ABI): edges sorted by weight ->
+ * comps i32[V] = union-find representative of every vertex. */
+int usc_felz_merge_host(const int32_t* edge_a, const int32_t* edge_b,
+                        const float* weights, int64_t n_edges, int32_t n_vertices,
+                        float kthr, int32_t seg_min_verts, int32_t* comps);
+
 #ifdef __cplusplus
 }
 #endif

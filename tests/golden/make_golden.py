@@ -8,6 +8,7 @@ not installed: SURVEY.md Appendix A), feeds them seeded inputs and stores inputs
     python tests/golden/make_golden.py            # criterion / posenc / decoder_layers fixtures
     python tests/golden/make_golden.py decoder_pass   # one decoder pass, head-shared mask, forward + backward
     python tests/golden/make_golden.py aggregate  # N1 aggregate_features (mean / max, zero-segment fill)
+    python tests/golden/make_golden.py felz       # Felzenszwalb over-segmentation (reference module built by oracle/Makefile)
     python tests/golden/make_golden.py ncut       # NCut fixtures (separate interpreter: different stubs)
     python tests/golden/make_golden.py export     # eval/export post-processing fixtures (trainer.eval_instance_step)
     python tests/golden/make_golden.py dataset    # self-train mask merge + validation-mode scene reader fixtures
@@ -328,6 +329,31 @@ def make_aggregate(ref):
     np.savez_compressed(os.path.join(HERE, "aggregate.npz"), **out)
 
 
+def make_felz():
+    """§8f-2: the reference's own felzenszwalb_cpp module (built from /root/reference/utils/cpp_utils/segmentator.cpp by
+    `make -C oracle ref` into oracle/_ref/) on two seeded meshes: `distinct` (continuous colours: weights equal only
+    between the two copies of one mesh edge) and `ties` (colours quantised to 1/16: thousands of equal weights, incl.
+    exact zeros).  Inputs are stored with the outputs; normals / weights come from the restatement that this same
+    script first checks against the reference's labels and connectivity."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import felz_ref as FR
+    from unscene3d_amd.synthetic import make_mesh
+    ref = FR.reference_module()
+    assert ref is not None, "run `make -C oracle ref` first"
+    out = {}
+    for name, seed, q in (("distinct", 1, False), ("ties", 2, True)):
+        v, f, c = make_mesh(seed, side=60, quantise_colours=q)
+        labels, conn = ref.segment_mesh(v, f, c, 0.005, 20)
+        ol, oc, det = FR.segment_mesh(v, f, c, 0.005, 20, stable=False, details=True)
+        assert np.array_equal(labels, ol) and np.array_equal(conn, oc), "restatement differs from the reference build"
+        out.update({f"{name}/vertices": v, f"{name}/faces": f, f"{name}/colors": c, f"{name}/labels": labels.astype(np.int32),
+                    f"{name}/connectivity": np.asarray(conn, np.int32), f"{name}/normals": det["normals"],
+                    f"{name}/weights": det["weights"]})
+        print("felz", name, "segments", int(labels.max()) + 1, "pairs", conn.shape, "distinct weights",
+              len(np.unique(det["weights"])), "of", det["weights"].shape[0])
+    np.savez_compressed(os.path.join(HERE, "felz.npz"), **out)
+
+
 def import_reference_trainer():
     stub("imageio", "pyviz3d", "pyviz3d.visualizer", "torch_scatter", "matplotlib", "matplotlib.cm", "hydra",
          "MinkowskiEngine", "MinkowskiEngine.MinkowskiOps", "MinkowskiEngine.MinkowskiPooling", "custom_cuda_utils",
@@ -589,6 +615,8 @@ if __name__ == "__main__":
         make_dataset(import_reference_dataset())
     elif len(sys.argv) > 1 and sys.argv[1] == "export":
         make_export(import_reference_trainer())
+    elif len(sys.argv) > 1 and sys.argv[1] == "felz":
+        make_felz()
     elif len(sys.argv) > 1 and sys.argv[1] == "decoder_pass":
         make_decoder_pass(import_reference_models())
     elif len(sys.argv) > 1 and sys.argv[1] == "aggregate":

@@ -11,6 +11,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  It has to be in the process BEFORE this library
+# pulls one in: with the order reversed, two runtimes coexist, this library sees the GPU and torch.cuda reports no
+# device (found in round 2 by a test module that imported the package before torch).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("USC3D_LIB", os.path.join(_HERE, "libusc3d_hip.so"))   # override: developer ablation builds
 
@@ -116,6 +121,10 @@ SIGNATURES = {
     "usc_layernorm_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _p, _p, _p, _p]),
     "usc_layernorm_bwd_ws_bytes": (_i64, [_i64, _i32]),
     "usc_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
+    "usc_felz_face_normals": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "usc_felz_vertex_normals": (C.c_int, [_p, _p, _p, _i64, _p, _p]),
+    "usc_felz_edge_weights": (C.c_int, [_p, _p, _p, _p, _i64, _p, _p, _p, _p]),
+    "usc_felz_merge_host": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _i32, _p]),
     "usc_furthest_point_sampling": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "usc_fourier_posenc": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p, _p]),
 }

@@ -238,3 +238,29 @@ def camera_views(seed, coords, n_views, dims=(40, 36, 28)):
             tgt = lo + np.asarray(dims) * rng.uniform(0.1, 0.9, 3)
             views[b, v] = look_at(eye, tgt)
     return views
+
+
+def make_mesh(seed: int, side: int = 60, n_regions: int = 9, colour_noise: float = 0.02, quantise_colours: bool = False):
+    """Synthetic triangle mesh for the over-segmentation: a `side` x `side` height field (two triangles
+    per cell) made of flat and tilted patches with creases between them, one base colour per patch plus per-vertex
+    noise.  `quantise_colours`: colours rounded to 1/16 so that many edges get EQUAL weights (ties, incl. exact zeros).
+    -> vertices f32[V,3], faces i32[F,3], colors f32[V,3] in [0,1]."""
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    cx, cy = rng.uniform(0, side, n_regions), rng.uniform(0, side, n_regions)
+    region = np.argmin((u[..., None] - cx) ** 2 + (v[..., None] - cy) ** 2, axis=-1)
+    slope = rng.uniform(-0.6, 0.6, (n_regions, 2))
+    base = rng.uniform(0, 1.5, n_regions)
+    z = base[region] + slope[region, 0] * (u - cx[region]) * 0.05 + slope[region, 1] * (v - cy[region]) * 0.05
+    z = z + rng.normal(0, 0.002, z.shape)
+    vertices = np.stack([u * 0.05, v * 0.05, z], -1).reshape(-1, 3).astype(np.float32)
+    colors = rng.uniform(0.1, 0.9, (n_regions, 3))[region] + rng.normal(0, colour_noise, (side, side, 3))
+    colors = np.clip(colors, 0, 1)
+    if quantise_colours:
+        colors = np.round(colors * 16) / 16
+    colors = colors.reshape(-1, 3).astype(np.float32)
+    idx = (u * side + v)
+    a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[:-1, 1:], idx[1:, 1:]
+    faces = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([b, d, c], -1).reshape(-1, 3)], 0)
+    faces = faces[rng.permutation(faces.shape[0])].astype(np.int32)      # face order matters (running normal blend)
+    return vertices, faces, colors
