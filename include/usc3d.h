@@ -657,6 +657,29 @@ int usc_elastic_displace(const void* xyz_in, int32_t is_f64, int64_t n, int32_t 
                          double magnitude, void* xyz_out, usc_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * F4  training-time augmentations of the scene reader — replaces the numpy /
+ * volumentations / albumentations steps of datasets/freemask_semseg.py:334-406.
+ * ---------------------------------------------------------------------- */
+/* x[:, 0:3] <- x[:, 0:3] M^T + t in place (f64 arithmetic, one rounding to the
+ * table's type): centring + random shift (:335-342), axis flips (:348-351),
+ * Scale3d and RotateAroundAxis3d of conf/augmentation/volumentations_aug.yaml.
+ * M (9, row-major) and t (3) are HOST doubles; x is f32 or f64 [n, row_stride]. */
+int usc_affine_rows(void* x, int32_t is_f64, int64_t n, int32_t row_stride,
+                    const double* M, const double* t, usc_stream_t s);
+/* out[c] = ((x[0,c] + x[1,c]) + x[2,c]) + ... in f32, c < cols <= 64: numpy's
+ * summation order for a.sum(0) / a.mean(0) of a C-contiguous table, so that
+ * `coordinates -= coordinates.mean(0)` (:335) is reproduced bit for bit. */
+int usc_colsum_sequential(const float* x, int64_t n, int32_t row_stride,
+                          int32_t cols, float* out, usc_stream_t s);
+/* out[i,c] = lut[c*256 + uint8(color[i,c])], c < 3: RandomBrightnessContrast /
+ * RGBShift of conf/augmentation/albumentations_aug.yaml and the colour
+ * normalisation (:408-409) as per-channel tables over the uint8-truncated
+ * colours.  color f32[n,row_stride], lut f32[3][256] (device), out f32. */
+int usc_color_lut(const float* color, int64_t n, int32_t row_stride,
+                  const float* lut, float* out, int32_t out_stride,
+                  usc_stream_t s);
+
+/* ------------------------------------------------------------------------
  * F2  Felzenszwalb mesh over-segmentation — replaces the reference's
  * felzenszwalb_cpp extension (utils/cpp_utils/segmentator.cpp:17-154
  * segment_graph / segment_mesh; caller pseudo_masks/datasets/scannet.py:156-197).

@@ -573,6 +573,33 @@ def make_dataset(ds):
             out[f"item/{k}"] = np.asarray(v)
     assert item[3] == "scene0001_00" and item[7] == 0 and item[8] == []
     print("item", [np.asarray(v).shape for v in item[:3]])
+
+    # (c) TRAIN mode (freemask_semseg.py:334-406): centring + random shift (numpy's global generator), axis flips and
+    # the elastic-distortion gate (python's `random`), two elastic distortions, colour drop, normalisation.  The
+    # volumentations / albumentations pipelines are third-party packages that are not installed: identity stand-ins, so
+    # the fixture pins the reference's OWN steps and their random-number consumption.
+    import random as pyrandom
+
+    class IdVolume:
+        transforms = [None]
+
+        def __call__(self, points, normals, features, labels):
+            return {"points": points, "normals": normals, "features": features, "labels": labels}
+
+    for seed in (3, 4, 11):
+        tr = Fake(**vars(me))
+        tr.mode, tr.volume_augmentations = "train", IdVolume()
+        tr.image_augmentations = lambda image: {"image": image}
+        tr.flip_in_center, tr.is_elastic_distortion, tr.point_per_cut = False, True, 0
+        tr.resample_points, tr.noise_rate, tr.color_drop, tr.max_cut_region = 0, 0, 0.3, 0
+        np.random.seed(seed)
+        pyrandom.seed(seed)
+        item = cls.__getitem__(tr, 0)
+        for k, v in zip(names, item):
+            if k in ("coordinates", "features", "freemasks"):
+                out[f"train{seed}/{k}"] = np.asarray(v)
+        out[f"train{seed}/rng_after"] = np.array([np.random.random(), pyrandom.random()])
+        print("train item", seed, np.asarray(item[0]).dtype, np.asarray(item[0])[:2], np.asarray(item[1])[0, :3])
     np.savez_compressed(os.path.join(HERE, "dataset.npz"), **out)
 
 

@@ -220,6 +220,60 @@ __global__ __launch_bounds__(256) void elastic_displace_kernel(const T* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Training-time augmentations of the scene reader (reference datasets/freemask_semseg.py:334-406): every geometric
+// step there — centring + random shift, axis flips, volumentations' per-axis scale and rotations about z / y / x — is
+// x <- x M^T + t on the first three columns of a row-major table; colours go through per-channel 256-entry tables
+// (how albumentations applies RandomBrightnessContrast / RGBShift to uint8 images).  Both are one pass over the rows.
+template <typename T>
+__global__ __launch_bounds__(256) void affine_rows_kernel(T* __restrict__ x, int64_t n, int row_stride, double m00,
+                                                          double m01, double m02, double m10, double m11, double m12,
+                                                          double m20, double m21, double m22, double t0, double t1,
+                                                          double t2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  T* r = x + i * row_stride;
+  const double a = (double)r[0], b = (double)r[1], c = (double)r[2];
+  r[0] = (T)(m00 * a + m01 * b + m02 * c + t0);
+  r[1] = (T)(m10 * a + m11 * b + m12 * c + t1);
+  r[2] = (T)(m20 * a + m21 * b + m22 * c + t2);
+}
+
+// Column sums of the first `cols` columns in numpy's order for `a.sum(0)` / `a.mean(0)` of a C-contiguous f32 table:
+// one f32 accumulator per column, rows added first to last (numpy reduces the outer axis row by row, not pairwise).
+// One lane per column walks all rows — ~1 ms for 250 k rows, off the training step's critical path — so that the
+// centred coordinates, and with them the voxel every point falls into, equal the reference's bit for bit.
+__global__ __launch_bounds__(64) void colsum_sequential_kernel(const float* __restrict__ x, int64_t n, int row_stride,
+                                                               int cols, float* __restrict__ out) {
+  const int c = threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.f;
+  int64_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[(i + u) * row_stride + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; i < n; ++i) acc += x[i * row_stride + c];
+  out[c] = acc;
+}
+
+// out[i,c] = lut[c][ (uint8) color[i,c] ]  (the reference truncates its float colours with .astype(np.uint8) first)
+__global__ __launch_bounds__(256) void color_lut_kernel(const float* __restrict__ color, int64_t n, int row_stride,
+                                                        const float* __restrict__ lut, float* __restrict__ out,
+                                                        int out_stride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = color[i * row_stride + c];
+    const int q = (int)(unsigned char)(int)v;            // C-style truncation + wrap, like numpy's astype(uint8)
+    out[i * out_stride + c] = lut[c * 256 + q];
+  }
+}
+
 }  // namespace usc
 
 using namespace usc;
@@ -315,6 +369,41 @@ int usc_elastic_displace(const void* xyz_in, int32_t is_f64, int64_t n, int32_t 
     hipLaunchKernelGGL(elastic_displace_kernel<float>, grid, dim3(256), 0, as_stream(s), (const float*)xyz_in, n,
                        row_stride, noise, dim_x, dim_y, dim_z, axis_x, axis_y, axis_z, magnitude, (float*)xyz_out);
   USC_CHECK_LAUNCH("usc_elastic_displace");
+  return USC_OK;
+}
+
+int usc_affine_rows(void* x, int32_t is_f64, int64_t n, int32_t row_stride, const double* M, const double* t,
+                    usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && row_stride >= 3, "usc_affine_rows: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(x && M && t, "usc_affine_rows: null pointer (M, t are HOST arrays of 9 and 3 doubles)");
+  const dim3 grid((unsigned)ceil_div(n, 256));
+  if (is_f64)
+    hipLaunchKernelGGL(affine_rows_kernel<double>, grid, dim3(256), 0, as_stream(s), (double*)x, n, (int)row_stride, M[0],
+                       M[1], M[2], M[3], M[4], M[5], M[6], M[7], M[8], t[0], t[1], t[2]);
+  else
+    hipLaunchKernelGGL(affine_rows_kernel<float>, grid, dim3(256), 0, as_stream(s), (float*)x, n, (int)row_stride, M[0],
+                       M[1], M[2], M[3], M[4], M[5], M[6], M[7], M[8], t[0], t[1], t[2]);
+  USC_CHECK_LAUNCH("usc_affine_rows");
+  return USC_OK;
+}
+
+int usc_colsum_sequential(const float* x, int64_t n, int32_t row_stride, int32_t cols, float* out, usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && cols >= 1 && cols <= 64 && row_stride >= cols, "usc_colsum_sequential: bad sizes");
+  USC_REQUIRE(x && out, "usc_colsum_sequential: null pointer");
+  hipLaunchKernelGGL(colsum_sequential_kernel, dim3(1), dim3(64), 0, as_stream(s), x, n, (int)row_stride, (int)cols, out);
+  USC_CHECK_LAUNCH("usc_colsum_sequential");
+  return USC_OK;
+}
+
+int usc_color_lut(const float* color, int64_t n, int32_t row_stride, const float* lut, float* out, int32_t out_stride,
+                  usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && row_stride >= 3 && out_stride >= 3, "usc_color_lut: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(color && lut && out, "usc_color_lut: null pointer");
+  hipLaunchKernelGGL(color_lut_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(s), color, n,
+                     (int)row_stride, lut, out, (int)out_stride);
+  USC_CHECK_LAUNCH("usc_color_lut");
   return USC_OK;
 }
 

@@ -2,10 +2,13 @@
 (`freemasks/{scene}_cloud.npy`, `{scene}_masks.npy`, written by trainer/postprocess.py::save_for_freemask) are merged
 into a scene's pseudo masks, filtered, and turned into the 9-tuple the collate function takes.
 
-Mirrors reference datasets/freemask_semseg.py — `load_self_train_masks` (:224-265) and the deterministic
-(validation-mode) part of `__getitem__` (:267-331, :408-437).  The train-mode augmentations (:333-406: elastic
-distortion, albumentations / volumentations pipelines, random crops) draw from numpy's global RNG and two
-third-party packages; they stay with the caller's DataLoader workers.
+Mirrors reference datasets/freemask_semseg.py — `load_self_train_masks` (:224-265) and `__getitem__` (:267-437) in
+validation mode and in TRAIN mode: centring + random shift, axis flips, two elastic distortions, the volume and colour
+augmentation pipelines, colour drop and normalisation run on the device (datasets/augment.py), drawing from numpy's and
+python's global generators with the reference's own calls and in its order, so a seeded run consumes the same streams
+(pinned by tests/golden/dataset.npz for the reference's own steps; the two third-party pipelines are restated from
+their published definitions).  Random cuboid cuts / point resampling (point_per_cut, resample_points, noise_rate: 0 in
+every shipped config) are not built.
 
 The per-point work (1-NN transfer of the exported masks, the greedy merge, the extent filter) runs on the device."""
 from __future__ import annotations
@@ -79,7 +82,9 @@ class FreeMaskSceneReader:
     def __init__(self, entries, color_mean_std=SCANNET_COLOR_MEAN_STD, add_colors=True, add_normals=True,
                  add_raw_coordinates=False, freemask_hard_threshold=0.5, freemask_extent_max_ratio=0.8,
                  max_num_gt_instances=-1, load_self_train_data=False, self_train_data_dir=None, num_self_train_data=5,
-                 device="cuda"):
+                 device="cuda", mode="validation", volume_augmentations=None, image_augmentations=None,
+                 is_elastic_distortion=True, flip_in_center=False, color_drop=0.0, point_per_cut=0, resample_points=0,
+                 noise_rate=0):
         self.data = list(entries)                      # dicts with "filepath" and "raw_filepath" (the database yaml)
         self.color_mean = np.asarray(color_mean_std[0], np.float32) * 255.0
         self.color_den = np.reciprocal(np.asarray(color_mean_std[1], np.float32) * 255.0)
@@ -91,6 +96,13 @@ class FreeMaskSceneReader:
         self.self_train_data_dir = self_train_data_dir
         self.num_self_train_data = num_self_train_data
         self.device = device
+        self.mode, self.is_elastic_distortion, self.color_drop = mode, is_elastic_distortion, color_drop
+        # objects with a `transforms` attribute, called like the reference's (volumentations / albumentations Compose);
+        # datasets.augment.VolumeAugmentations() / ColorAugmentations() are the shipped YAML pipelines
+        self.volume_augmentations, self.image_augmentations = volume_augmentations, image_augmentations
+        if flip_in_center or point_per_cut or resample_points or noise_rate:
+            raise NotImplementedError("flip_in_center / point_per_cut / resample_points / noise_rate are off in every "
+                                      "shipped config (conf/data/datasets/*.yaml) and not built")
 
     def __len__(self):
         return len(self.data)
@@ -127,6 +139,9 @@ class FreeMaskSceneReader:
         raw_coordinates, raw_color, raw_normals = coordinates.copy(), color, normals
         if not self.add_colors:
             color = np.ones((len(color), 3))
+        if "train" in self.mode and hasattr(self.volume_augmentations, "transforms"):
+            return self._train_item(idx, coordinates, color, normals, segments, freemasks, raw_coordinates, raw_color,
+                                    raw_normals)
         # albumentations.Normalize on the uint8-truncated colours (freemask_semseg.py:408-409)
         features = (color.astype(np.uint8).astype(np.float32) - self.color_mean) * self.color_den
         if self.add_normals:
@@ -137,3 +152,39 @@ class FreeMaskSceneReader:
         raw = self.data[idx]["raw_filepath"]
         scene_name = f"scene{raw.split('/')[-1].split('_')[0]}" if "arkit" in raw.lower() else raw.split("/")[-2]
         return coordinates, features, freemasks, scene_name, raw_color, raw_normals, raw_coordinates, idx, []
+
+    def _scene_name(self, idx):
+        raw = self.data[idx]["raw_filepath"]
+        return f"scene{raw.split('/')[-1].split('_')[0]}" if "arkit" in raw.lower() else raw.split("/")[-2]
+
+    def _train_item(self, idx, coordinates, color, normals, segments, freemasks, raw_coordinates, raw_color, raw_normals):
+        """freemask_semseg.py:333-437 with the per-point work on the device; coordinates / features come back as device
+        tensors (the collate takes them as they are).  Random numbers: numpy's global generator for the shift and the
+        elastic noise, python's `random` for the flips, the elastic gate and the colour drop — same calls, same order."""
+        from random import random
+
+        from . import augment as A
+
+        dev = torch.device(self.device)
+        c = torch.as_tensor(np.ascontiguousarray(coordinates), device=dev).contiguous()
+        nrm = torch.as_tensor(np.ascontiguousarray(normals), device=dev).contiguous()
+        col = torch.as_tensor(np.ascontiguousarray(color), dtype=torch.float32, device=dev).contiguous()
+        A.center_and_shift(c)
+        for i in (0, 1):
+            if random() < 0.5:
+                A.flip_axis(c, i)
+        if random() < 0.95 and self.is_elastic_distortion:
+            for granularity, magnitude in ((0.2, 0.4), (0.8, 1.6)):
+                A.elastic_distortion(c, granularity, magnitude)
+        aug = self.volume_augmentations(points=c, normals=nrm, features=col, labels=freemasks)
+        c, col, nrm, freemasks = aug["points"], aug["features"], aug["normals"], aug["labels"]
+        tables = self.image_augmentations.tables() if self.image_augmentations is not None else None
+        if random() < self.color_drop:
+            tables = np.full((3, 256), 255, np.uint8)                  # color[:] = 255
+        features = A.color_tables_to_features(col, tables, self.color_mean, self.color_den)
+        if self.add_normals:
+            features = torch.cat([features, nrm.to(features.dtype)], 1)
+        if self.add_raw_coordinates:
+            features = torch.cat([features, c.to(features.dtype)], 1)
+        freemasks = np.hstack((freemasks, segments[..., None].astype(freemasks.dtype))).astype(np.int32)
+        return c, features, freemasks, self._scene_name(idx), raw_color, raw_normals, raw_coordinates, idx, []
