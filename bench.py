@@ -43,6 +43,8 @@ def parse():
                     help="mask3d: BASELINE.json configs[2] full self-train step (the metric's config); "
                          "backbone: configs[1] Res16UNet34C fwd+bwd only; "
                          "ncut: configs[4] masked-NCut pseudo-mask loop on a 625-segment scene (secondary metric)")
+    ap.add_argument("--scenes", type=int, default=2,
+                    help="--mode ncut: scenes processed side by side on one GPU (one host thread + HIP stream each)")
     ap.add_argument("--no-graphs", action="store_true", help="do not capture the decoder passes as HIP graphs")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of the flat-buffer kernel")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -299,13 +301,24 @@ def run_ncut(args, dev):
     from unscene3d_amd.pseudo_masks import ncut
     from unscene3d_amd.synthetic import make_segment_scene
 
+    from unscene3d_amd.pseudo_masks.driver import PseudoMaskDriver
+
+    K = max(1, args.scenes)
     feats, conn, _ = make_segment_scene(75, side=25, dims=(384, 96), n_objects=16)
     S = feats[0].shape[0]
     uniq = torch.arange(S)
     conn_t = torch.from_numpy(conn)
     dfe = tuple(torch.from_numpy(f).to(dev) for f in feats)
-    run = lambda: ncut.unscene3d((dfe[0].clone(), dfe[1].clone()), uniq, conn_t, affinity_tau=0.6,
-                                 max_number_of_instances=20, min_segment_size=4)
+    # a step = one round of K scenes (the same synthetic scene K times: identical work per slot); K = 1 is the
+    # single chain of round 1
+    scenes = [{"features": (dfe[0].clone(), dfe[1].clone()), "unique_segments": uniq, "seg_connectivity": conn_t}
+              for _ in range(K)]
+    driver = PseudoMaskDriver(device=dev, concurrent=K)
+
+    def run():
+        for sc in scenes:
+            sc["features"] = (dfe[0].clone(), dfe[1].clone())
+        return driver.run(scenes)[0]
     for _ in range(args.warmup):
         masks = run()
     torch.cuda.synchronize()
@@ -313,7 +326,7 @@ def run_ncut(args, dev):
     for _ in range(args.steps):
         masks = run()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    dt = (time.perf_counter() - t0) / args.steps / K          # seconds per scene
     # eigensolver alone (device time of one usc_ncut_fiedler call)
     A, D = ncut.get_affinity_matrix((dfe[0].clone(), dfe[1].clone()), tau=0.6)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -338,6 +351,7 @@ def run_ncut(args, dev):
     flops = 4.0 / 3.0 * S ** 3
     print(json.dumps({
         "metric": "pseudo-mask scenes/sec (masked NCut, 625 segments, 20 iterations)", "value": 1.0 / dt,
+        "scenes_in_flight": K,
         "unit": "scenes/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[4]: iterative masked NCut (affinity + generalized Fiedler vector, "

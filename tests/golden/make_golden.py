@@ -354,6 +354,42 @@ def make_felz():
     np.savez_compressed(os.path.join(HERE, "felz.npz"), **out)
 
 
+def make_ncut_b(ref):
+    """A second config-5 scene for the hook-free product path (tests/golden/ncut_b.npz): 24 x 25 = 600 segments, ONE
+    modality (CSC-like 96-d), per-segment noise levels, other seed.  Records the reference's masks and the sign-carrying
+    eigenvector of every iteration (not the affinity matrices: the file stays small)."""
+    rng_seed, rows, cols, d, k = 91, 24, 25, 96, 14
+    feats, conn, seg_ids, coords, label, placed = planted_scene(rng_seed, 25, (d,), k, noise=(0.3, 1.2))
+    keep = np.arange(rows * cols)                                 # drop the last grid row: 600 segments
+    f = feats[0][keep]
+    conn = conn[(conn[:, 0] < rows * cols) & (conn[:, 1] < rows * cols)]
+    pts = np.isin(seg_ids, keep)
+    seg_ids, coords = seg_ids[pts], coords[pts]
+    S = rows * cols
+    trace = []
+    orig = ref.second_smallest_eigenvector
+
+    def logged(A, D, _orig=orig, _trace=trace):
+        res = _orig(A, D)
+        w = __import__("scipy.linalg").linalg.eigh(D - A, D, subset_by_index=[1, 2], eigvals_only=True)
+        _trace.append((np.diag(D).copy(), res[1].copy(), w, int((~(A > 0.5).any(1)).sum())))
+        return res
+
+    ref.second_smallest_eigenvector = logged
+    masks = ref.unscene3d(torch.from_numpy(f).clone(), torch.arange(S), torch.from_numpy(conn), torch.from_numpy(seg_ids),
+                          torch.from_numpy(coords), torch.from_numpy(coords), affinity_tau=0.6,
+                          max_number_of_instances=20, similarity_metric="cos", min_segment_size=4,
+                          separation_mode="max", max_extent_ratio=0.8)
+    ref.second_smallest_eigenvector = orig
+    out = {"feat0": f, "conn": conn, "tau": np.float64(0.6), "n_iter": np.int64(len(trace)),
+           "masks": np.packbits(masks.astype(bool), axis=1), "n_masks": np.int64(masks.shape[0])}
+    for it, (deg, vec, w, painted) in enumerate(trace):
+        out[f"it{it}/deg"], out[f"it{it}/vec"], out[f"it{it}/evals"], out[f"it{it}/painted"] = deg, vec, w, np.int64(painted)
+    gaps = [float((w[1] - w[0]) / max(w[1], 1e-300)) for (_, _, w, _) in trace]
+    print("ncut_b S", S, "masks", masks.shape, "rel gaps", np.round(gaps, 4))
+    np.savez_compressed(os.path.join(HERE, "ncut_b.npz"), **out)
+
+
 def import_reference_trainer():
     stub("imageio", "pyviz3d", "pyviz3d.visualizer", "torch_scatter", "matplotlib", "matplotlib.cm", "hydra",
          "MinkowskiEngine", "MinkowskiEngine.MinkowskiOps", "MinkowskiEngine.MinkowskiPooling", "custom_cuda_utils",
@@ -636,6 +672,8 @@ if __name__ == "__main__":
     cwd = os.getcwd()
     if len(sys.argv) > 1 and sys.argv[1] == "ncut":
         make_ncut(import_reference_ncut())
+    elif len(sys.argv) > 1 and sys.argv[1] == "ncut_b":
+        make_ncut_b(import_reference_ncut())
     elif len(sys.argv) > 1 and sys.argv[1] == "elastic":
         make_elastic()
     elif len(sys.argv) > 1 and sys.argv[1] == "dataset":

@@ -1,6 +1,8 @@
 """GPU parity: every HIP kernel (through the C ABI) against the CPU oracle on the same
 seeded inputs.  Integer outputs bit-exact; fp32 features within 1e-3 relative
 (BASELINE.json north_star) — in practice ~1e-6 because the MFMA path is exact fp32."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1075,3 +1077,34 @@ def test_scene_prefetcher_hands_over_prepared_batches(device):
         assert torch.equal(cm.coord_map(ts).coords, plain.coordinate_manager.coord_map(ts).coords)
         assert torch.equal(cm.cube_map(ts)["nbr"], plain.coordinate_manager.cube_map(ts)["nbr"])
     torch.cuda.synchronize()
+
+
+def test_config5_ncut_second_scene_product_path(device):
+    """A second 600-segment scene (tests/golden/ncut_b.npz: other seed, per-segment noise levels) through the PRODUCT
+    path without any hook: the reference's masks at IoU >= 0.99, and on every iteration whose eigenvalue gap is not
+    degenerate the reference's eigenvector WITH its sign."""
+    from unscene3d_amd.pseudo_masks import ncut
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ncut_b.npz"))
+    feats = [z[k] for k in ("feat0", "feat1") if k in z.files]
+    S = feats[0].shape[0]
+    assert 590 <= S <= 640
+    tf = tuple(_dev(f, device) for f in feats)
+    arg = tf if len(tf) > 1 else tf[0]
+    ref_masks = np.unpackbits(z["masks"], axis=1)[:int(z["n_masks"]), :S].astype(bool)
+    seen = []
+    masks = ncut.unscene3d(arg, torch.arange(S), torch.from_numpy(z["conn"]), affinity_tau=float(z["tau"]),
+                           max_number_of_instances=20, min_segment_size=4, separation_mode="max", max_extent_ratio=0.8,
+                           eigvec_hook=lambda it, v: (seen.append(v.copy()), v)[1])        # observes, does not alter
+    assert masks.shape[0] == ref_masks.shape[0], (masks.shape, ref_masks.shape)
+    for m, r in zip(masks, ref_masks):
+        assert (m & r).sum() / max((m | r).sum(), 1) >= 0.99
+    signed = 0
+    for it, v in enumerate(seen):
+        w = z[f"it{it}/evals"]
+        if int(z[f"it{it}/painted"]) > 0.5 * S or (w[1] - w[0]) / max(abs(w[1]), 1e-300) < 1e-2:
+            continue
+        c = float(v @ (z[f"it{it}/deg"] * z[f"it{it}/vec"]))
+        assert c > 0.9999, (it, c)
+        signed += 1
+    assert signed >= 5
