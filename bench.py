@@ -137,7 +137,8 @@ def make_mask3d_step(args, dev, rank, world):
     prefetch = None
     if not args.no_prefetch:
         from unscene3d_amd.datasets.prefetch import ScenePrefetcher
-        prefetch = ScenePrefetcher(collate, add_raw_coordinates=cfg.data.add_raw_coordinates, device=dev)
+        prefetch = ScenePrefetcher(collate, add_raw_coordinates=cfg.data.add_raw_coordinates, device=dev,
+                                   precompute=module.model.precompute_geometry)
         prefetch.submit([sample])      # the first batch, outside the timed region like the resident raw arrays
 
     def step(w):

@@ -223,12 +223,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   tile_reduce_store(acc, red, wave, lane, y, N, m0, n0, M, b);
 }
 
-// dx[M,K] = dy[M,N] W[N,K]            grid (K/32, ceil(M/32)); N % 32 == 0
-__global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ W, int M,
-                                                       int N, int K, float* __restrict__ dx) {
-  __shared__ float red[4][16][64];
+// dx[M,K] = dy[M,N] W[N,K]   for the 32x32 tile (c0, m0); N % 32 == 0.  The four waves split N; every wave keeps the
+// NEXT chunk's operands in flight while the matrix cores work on the current one (one wave per SIMD: nothing else
+// hides the ~1 us load latency, and with 8 chunks per wave for the 1024-wide FFN the loop was 8 dependent round trips).
+__device__ inline void linear_dx_tile(const float* __restrict__ dy, const float* __restrict__ W, int M, int N, int K,
+                                      float* __restrict__ dx, int c0, int m0, float (*red)[16][64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
-  const int c0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int m = m0 + i;
   const float* ya = dy + (int64_t)(m < M ? m : 0) * N + 4 * h;
   const float* wb = W + (int64_t)(4 * h) * K + c0 + i;
@@ -237,16 +237,25 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int nchunk = N >> 5;
-  for (int c = wave; c < nchunk; c += 4) {
+  float4 a[4], an[4];
+  float bv[16], bn[16];
+  auto load = [&](int c, float4* aa, float* bb) __attribute__((always_inline)) {
     const int n0 = c * 32;
-    float4 a[4];
-    float bv[16];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(ya + n0 + 8 * t);
+    for (int t = 0; t < 4; ++t) aa[t] = *reinterpret_cast<const float4*>(ya + n0 + 8 * t);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[4 * t + j] = wb[(int64_t)(n0 + 8 * t + j) * K];
+      for (int j = 0; j < 4; ++j) bb[4 * t + j] = wb[(int64_t)(n0 + 8 * t + j) * K];
+  };
+  int c = wave;
+  if (c < nchunk) load(c, an, bn);
+  for (; c < nchunk; c += 4) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = an[t];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bv[q] = bn[q];
+    if (c + 4 < nchunk) load(c + 4, an, bn);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const float av[4] = {a[t].x * keep, a[t].y * keep, a[t].z * keep, a[t].w * keep};
@@ -257,14 +266,11 @@ __global__ __launch_bounds__(256) void linear_dx_kernel(const float* __restrict_
   tile_reduce_store(acc, red, wave, lane, dx, K, m0, c0, M, nullptr);
 }
 
-// dW[N,K] = dy[M,N]^T x[M,K],  db[N] = sum_m dy[m][N]       grid (K/32, N/32)
-__global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, int M,
-                                                       int N, int K, int accumulate, float* __restrict__ dW,
-                                                       float* __restrict__ db) {
-  __shared__ float red[4][16][64];
-  __shared__ float bred[4][32];
+// dW[N,K] = dy[M,N]^T x[M,K],  db[N] = sum_m dy[m][N]   for the tile (c0, n0); the tiles with c0 == 0 also write db
+__device__ inline void linear_dw_tile(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
+                                      int accumulate, float* __restrict__ dW, float* __restrict__ db, int c0, int n0,
+                                      float (*red)[16][64], float (*bred)[32]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
-  const int c0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -283,14 +289,34 @@ __global__ __launch_bounds__(256) void linear_dw_kernel(const float* __restrict_
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc = MFMA32(av[q], bv[q], acc); bsum += av[q]; }
   }
-  if (db && blockIdx.x == 0) {
+  const bool want_b = db && c0 == 0;
+  if (want_b) {
     bsum += __shfl_xor(bsum, 32, 64);
     if (h == 0) bred[wave][i] = bsum;
   }
   tile_reduce_store(acc, red, wave, lane, dW, K, n0, c0, N, nullptr, accumulate);   // contains the __syncthreads
-  if (db && blockIdx.x == 0 && threadIdx.x < 32) {
+  if (want_b && threadIdx.x < 32) {
     const float v = bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x];
     db[n0 + threadIdx.x] = accumulate ? db[n0 + threadIdx.x] + v : v;
+  }
+}
+
+// Both gradients of a few-row linear layer in ONE launch: workgroups [0, dx_tiles) take the input-gradient tiles,
+// the rest the weight-gradient tiles (they are independent; as two launches the pair cost 9.4 + 4.5 us of a
+// latency-bound decoder pass, ~150 pairs per training step).
+__global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ W, int M, int N, int K, int dx_tiles,
+                                                        int accumulate, float* __restrict__ dx, float* __restrict__ dW,
+                                                        float* __restrict__ db) {
+  __shared__ float red[4][16][64];
+  __shared__ float bred[4][32];
+  const int kt = K / 32;
+  int b = blockIdx.x;
+  if (b < dx_tiles) {
+    linear_dx_tile(dy, W, M, N, K, dx, (b % kt) * 32, (b / kt) * 32, red);
+  } else {
+    b -= dx_tiles;
+    linear_dw_tile(dy, x, M, N, K, accumulate, dW, db, (b % kt) * 32, (b / kt) * 32, red, bred);
   }
 }
 
@@ -314,8 +340,11 @@ int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M, i
   USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_bwd: N, K must be multiples of 32");
   USC_REQUIRE(dy && x && W, "usc_linear_bwd: null pointer");
   hipStream_t st = usc::as_stream(s);
-  if (dx) hipLaunchKernelGGL(usc::linear_dx_kernel, dim3(K / 32, (M + 31) / 32), dim3(256), 0, st, dy, W, (int)M, (int)N, (int)K, dx);
-  if (dW) hipLaunchKernelGGL(usc::linear_dw_kernel, dim3(K / 32, N / 32), dim3(256), 0, st, dy, x, (int)M, (int)N, (int)K, (int)accumulate, dW, db);
+  const int dx_tiles = dx ? (K / 32) * ((M + 31) / 32) : 0;
+  const int dw_tiles = dW ? (K / 32) * (N / 32) : 0;
+  if (dx_tiles + dw_tiles > 0)
+    hipLaunchKernelGGL(usc::linear_bwd_kernel, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, x, W, (int)M, (int)N, (int)K,
+                       dx_tiles, (int)accumulate, dx, dW, db);
   USC_CHECK_LAUNCH("usc_linear_bwd");
   return USC_OK;
 }

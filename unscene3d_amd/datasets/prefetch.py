@@ -53,8 +53,12 @@ class ScenePrefetcher:
     the next batch; prefetch.take() -> (data, target, names) with `data.sparse_tensor` (maps prepared) and
     `data.raw_coordinates` attached, ready for `InstanceSegmentation.training_step`."""
 
-    def __init__(self, collate, add_raw_coordinates: bool = True, n_down: int = 4, ksize: int = 3, device="cuda"):
+    def __init__(self, collate, add_raw_coordinates: bool = True, n_down: int = 4, ksize: int = 3, device="cuda",
+                 precompute=None):
+        """precompute: optional `Mask3D.precompute_geometry` (bound method): the parameter-free, geometry-only part
+        of the model's forward pass is then issued here as well."""
         self.collate, self.add_raw, self.n_down, self.ksize = collate, add_raw_coordinates, n_down, ksize
+        self.precompute = precompute
         self.device = torch.device(device)
         self.side = torch.cuda.Stream(device=self.device)
         self._pending = None
@@ -69,6 +73,10 @@ class ScenePrefetcher:
                 feats = feats[:, :-3].contiguous()
             x = ME.SparseTensor(coordinates=data.coordinates, features=feats, device=self.device)
             x.coordinate_manager.prepare(x.tensor_stride[0], n_down=self.n_down, ksize=self.ksize)
+            if self.precompute is not None and raw is not None and len(target) > 0:
+                ns = [t.get("num_segments") for t in target]
+                self.precompute(x, raw, [t["point2segment"] for t in target],
+                                None if any(n is None or n.is_cuda for n in ns) else ns, n_levels=self.n_down + 1)
             data.sparse_tensor, data.raw_coordinates = x, raw
             done = torch.cuda.Event()
             done.record(self.side)
