@@ -183,10 +183,10 @@ class Mask3D(nn.Module):
             fps_idx = [furthest_point_sample(dec_coords[i][None].float().contiguous(), self.num_queries)
                        .squeeze(0).long() for i in range(n_scenes)]
             raw_per_scene = coordinates.decomposed_features
-            sampled_coords = torch.stack([raw_per_scene[i][fps_idx[i]] for i in range(n_scenes)])
+            sampled_coords = _stack([raw_per_scene[i][fps_idx[i]] for i in range(n_scenes)])
             mm = [_col_minmax(r) for r in raw_per_scene]
-            mins = torch.stack([m[0] for m in mm])
-            maxs = torch.stack([m[1] for m in mm])
+            mins = _stack([m[0] for m in mm])
+            maxs = _stack([m[1] for m in mm])
             geo.update(fps_idx=fps_idx, sampled_coords=sampled_coords,
                        query_pos_enc=self.pos_enc(sampled_coords.float(), input_range=[mins, maxs]))     # B, d, Q
         cm.geometry = geo
@@ -216,7 +216,7 @@ class Mask3D(nn.Module):
             fps_idx, sampled_coords = geo["fps_idx"], geo["sampled_coords"]
             query_pos = self.query_projection(geo["query_pos_enc"])
             if self.use_np_features:
-                queries = torch.stack([pcd_features.decomposed_features[i][fps_idx[i]] for i in range(n_scenes)])
+                queries = _stack([pcd_features.decomposed_features[i][fps_idx[i]] for i in range(n_scenes)])
                 queries = self.np_feature_projection(queries)
             else:
                 queries = torch.zeros_like(query_pos).permute(0, 2, 1)
@@ -265,14 +265,14 @@ class Mask3D(nn.Module):
                     rand_idx.append(idx)
                     mask_idx.append(midx)
 
-                batched_aux = torch.stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k])
+                batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k])
                                            for k in range(n_scenes)])
-                batched_attn = torch.stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
-                batched_pos_enc = torch.stack([pos_encodings_pcd[hlevel][0][k][rand_idx[k], :] for k in range(n_scenes)])
+                batched_attn = _stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
+                batched_pos_enc = _stack([pos_encodings_pcd[hlevel][0][k][rand_idx[k], :] for k in range(n_scenes)])
 
                 # a query whose sampled keys are all masked attends to everything (reference :346)
                 batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
-                batched_attn = torch.logical_or(batched_attn, torch.stack(mask_idx)[..., None])
+                batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
 
                 step_fn = self._decoder_pass(decoder_counter, dec, i)
                 if getattr(self, "_graphed_passes", None) is not None:
@@ -426,6 +426,13 @@ class _DecoderPass(nn.Module):
                          memory_key_padding_mask=None, pos=batched_pos_enc.permute(1, 0, 2), query_pos=query_pos)
         out = self.self_attn(out, tgt_mask=None, tgt_key_padding_mask=None, query_pos=query_pos)
         return self.ffn(out).permute(1, 0, 2)
+
+
+def _stack(tensors):
+    """torch.stack, except that ONE tensor (one scene per GPU, the data-parallel configuration) becomes a view instead
+    of a copy: ~60 small copy launches per training step."""
+    tensors = list(tensors)
+    return tensors[0].unsqueeze(0) if len(tensors) == 1 else torch.stack(tensors)
 
 
 def _col_minmax(x):
