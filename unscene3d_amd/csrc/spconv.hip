@@ -288,7 +288,8 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     const float* wk;    // packed weight slice of offset k for this column block (wave-uniform, lives in SGPRs)
     int pbase;          // index of this item's pair 4h in the offset's pair list (flush: local output rows)
     int npairs;         // real pairs of the item (<= 32)
-    int item;           // work item index (= flush ticket); -1 = past the end (dummy loads, no flush)
+    int item;           // work item index; -1 = past the end (dummy loads, no flush)
+    int first;          // index of the first item of this item's offset (= flushes that must have happened before)
   };
   const int nq = cin >> 3;   // quads per item (multiple of 4)
   // this lane's byte offset inside a weight slice: rows 4h.., columns n0 + NB*i..  (constant for the kernel, so
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
   auto make_item = [&](int item) -> Item {
     Item st;
     if (item >= total_items) {
-      st.item = -1; st.pbase = 0; st.npairs = 0;
+      st.item = -1; st.pbase = 0; st.npairs = 0; st.first = 0;
       st.arow = g_zero_row + 4 * h;
       st.wk = wp_cb;
       return st;
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     st.pbase = pb0 + 4 * h;
     st.npairs = npairs;
     st.item = item;
+    st.first = __builtin_amdgcn_readfirstlane(item_start[k]);
     st.arow = (i < npairs ? p.in + (int64_t)pl_in[pidx] * (int64_t)cin : g_zero_row) + 4 * h;
     st.wk = wp_cb + (int64_t)k * cin * BN;
     return st;
@@ -370,7 +372,11 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
 #ifndef USC_POLL_SLEEP
 #define USC_POLL_SLEEP 1
 #endif
-      while (*ticket3 != st.item) __builtin_amdgcn_s_sleep(USC_POLL_SLEEP);
+      // The ticket counts FLUSHED items.  Items are numbered offset-major and the items of one offset touch disjoint
+      // output rows (a row has at most one neighbour per offset), so an item only has to wait for the offsets before
+      // its own — st.first = index of the first item of its offset — not for its siblings: the ~2 items per offset of a
+      // 148-row tile flush side by side, and every output element is still summed over k ascending (bit-identical).
+      while (*ticket3 < st.first) __builtin_amdgcn_s_sleep(USC_POLL_SLEEP);
     }
     __builtin_amdgcn_wave_barrier();
 #endif
@@ -426,7 +432,8 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS updates are done before the ticket moves
 #ifndef USC_ABLATE_TICKET
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) *ticket3 = st.item + 1;
+    if (lane == 0)   // ds_add on the LDS address (a generic pointer would compile to a flat atomic and drain the load rings)
+      __hip_atomic_fetch_add((__attribute__((address_space(3))) int32_t*)ticket3, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 #ifndef USC_NO_SETPRIO
     __builtin_amdgcn_s_setprio(0);
