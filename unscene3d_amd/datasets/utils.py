@@ -6,8 +6,9 @@ raw_coordinates, idx, segment_connectivity — reference datasets/freemask_semse
 
 MI355X differences: the 2 cm voxelisation (`np.floor(xyz/voxel)` + ME.utils.sparse_quantize, reference
 :403-408) runs on the device through the hash-unique kernel instead of in CPU DataLoader workers, and
-the voxel rows may optionally be re-ordered into z-order cells (`spatial_sort`), a consistent permutation
-of every per-voxel array (inverse maps are remapped accordingly)."""
+the voxel rows may optionally be re-ordered into z-order cells (`spatial_sort`: True = 8^3-voxel cells, or the cell
+size as a power of two, e.g. 5 = 32^3 voxels), a consistent permutation of every per-voxel array (inverse maps are
+remapped accordingly)."""
 from __future__ import annotations
 
 import numpy as np
@@ -79,7 +80,7 @@ def freemask_voxelize(batch, ignore_label, voxel_size, mode, ignore_class_thresh
                                                                return_inverse=True, device=str(dev))
         if spatial_sort:
             c4 = torch.cat([torch.zeros((c3.shape[0], 1), dtype=torch.int32, device=dev), c3], 1).contiguous()
-            order = ops.spatial_order(c4)
+            order = ops.spatial_order(c4, shift=int(spatial_sort) if spatial_sort is not True else 3)
             rank = torch.empty_like(order)
             rank[order] = torch.arange(order.shape[0], device=dev)
             c3, unique_map, inverse_map = c3[order], unique_map[order], rank[inverse_map]
