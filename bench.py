@@ -287,17 +287,21 @@ def cpu_baseline_mask3d(sample_voxels, runs=3):
         legs[name] = {"threads": nthr, "median_s": med, "min_s": ts[0], "max_s": ts[-1],
                       "scenes_per_s_150k_equiv": (nv / VOXELS) / med}
     torch.set_num_threads(all_threads)
-    a = legs["all_threads"]
+    best = max(legs.values(), key=lambda l: l["scenes_per_s_150k_equiv"])
+    a, o = legs["all_threads"], legs["omp3"]
     return {
-        "value": a["scenes_per_s_150k_equiv"],
+        # the faster of the two legs is the baseline (oversubscribed hosts run the restatement's many small torch ops
+        # far slower with all hardware threads than with three); both legs are reported
+        "value": best["scenes_per_s_150k_equiv"],
         "unit": "scenes/s in 150k-voxel-scene equivalents (measured on a smaller scene, scaled by voxels/150000)",
-        "cores": all_threads, "kind": "port", "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
+        "cores": best["threads"], "kind": "port", "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
         "runs": runs, "legs": legs,
         "sample": f"oracle Mask3D self-train step (voxelise + maps + Res16UNet34C + decoder + Hungarian + losses, forward "
                   f"+ backward, no optimizer; CPU restatement, not the reference binary: MinkowskiEngine cannot run "
-                  f"here) on one {nv}-voxel synthetic scene; 1 warm-up + {runs} timed passes per leg; all threads: "
-                  f"median {a['median_s']:.2f} s (min {a['min_s']:.2f}, max {a['max_s']:.2f}); 3 threads "
-                  f"(the reference's OMP_NUM_THREADS=3): median {legs['omp3']['median_s']:.2f} s",
+                  f"here) on one {nv}-voxel synthetic scene; 1 warm-up + {runs} timed passes per leg; "
+                  f"{a['threads']} threads: median {a['median_s']:.2f} s (min {a['min_s']:.2f}, max {a['max_s']:.2f}); "
+                  f"3 threads (the reference's OMP_NUM_THREADS=3): median {o['median_s']:.2f} s "
+                  f"(min {o['min_s']:.2f}, max {o['max_s']:.2f})",
     }
 
 
