@@ -783,7 +783,9 @@ def layer_norm(x, weight, bias, eps=1e-5):
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
-SMALL_ROWS = 512   # linear layers with at most this many rows go to the wave-per-tile kernels
+# linear layers with at most this many rows go to the tile-per-workgroup kernels of decoder.hip (the 100 queries; the
+# few hundred to a thousand segments of the mask logits: 5 us per launch against 11-21 us on the many-row kernels)
+SMALL_ROWS = 1024
 
 
 def _small_linear_ok(rows, n_in, n_out):
