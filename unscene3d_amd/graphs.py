@@ -86,6 +86,9 @@ class _GraphedFn(torch.autograd.Function):
 class GraphedPass:
     def __init__(self, runner):
         self._runner = runner
+        # the static input buffers as plain (detached) tensors: a producer may write its result straight into them —
+        # an input whose data pointer equals its buffer's is not copied at replay
+        self.input_buffers = [s.detach() for s in runner.static_in]
 
     def __call__(self, *inputs):
         return _GraphedFn.apply(self._runner, *inputs)

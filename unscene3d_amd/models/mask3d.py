@@ -9,6 +9,8 @@ kernels, as planned in SURVEY.md §7.6.
 Randomness: the reference sub-samples cross-attention keys with `torch.randperm` (mask3d.py:325);
 `self.randperm` can be replaced to inject fixed indices (parity tests do that).
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.nn import functional as F
@@ -23,6 +25,7 @@ from .modules.helpers_3detr import GenericMLP
 from .position_embedding import PositionEmbeddingCoordsSine
 
 SINGLE_POINT_ERROR = "only a single point gives nans in cross-attention"   # trainer.py:125 string-matches this
+_GATHER_INTO_GRAPH_INPUTS = os.environ.get("USC3D_GATHER_INTO_GRAPH_INPUTS", "1") == "1"
 
 
 class Mask3D(nn.Module):
@@ -265,22 +268,35 @@ class Mask3D(nn.Module):
                     rand_idx.append(idx)
                     mask_idx.append(midx)
 
-                batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k])
-                                           for k in range(n_scenes)])
-                batched_attn = _stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
-                batched_pos_enc = _stack([pos_encodings_pcd[hlevel][0][k][rand_idx[k], :] for k in range(n_scenes)])
+                step_fn = self._decoder_pass(decoder_counter, dec, i)
+                bufs = None
+                if getattr(self, "_graphed_passes", None) is not None:
+                    want = self._graph_shapes[decoder_counter * self.num_levels + i]
+                    have = (queries.shape, query_pos.shape, (n_scenes, curr_sample_size, decomposed_aux[0].shape[1]),
+                            (n_scenes, curr_sample_size, decomposed_attn[0].shape[1]),
+                            (n_scenes, curr_sample_size, pos_encodings_pcd[hlevel][0][0].shape[1]))
+                    if tuple(tuple(h) for h in have) != tuple(tuple(w) for w in want):
+                        step_fn = self._eager_pass(dec, i)
+                    elif n_scenes == 1 and _GATHER_INTO_GRAPH_INPUTS:
+                        bufs = step_fn.input_buffers        # gather straight into the captured pass's input buffers
+                if bufs is not None:
+                    batched_aux = ops.gather_rows(decomposed_aux[0].contiguous(), rand_idx[0], out=bufs[2][0]).unsqueeze(0)
+                    batched_attn = torch.index_select(decomposed_attn[0], 0, rand_idx[0], out=bufs[3][0]).unsqueeze(0)
+                    batched_pos_enc = torch.index_select(pos_encodings_pcd[hlevel][0][0], 0, rand_idx[0],
+                                                         out=bufs[4][0]).unsqueeze(0)
+                else:
+                    batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k])
+                                          for k in range(n_scenes)])
+                    batched_attn = _stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
+                    batched_pos_enc = _stack([pos_encodings_pcd[hlevel][0][k][rand_idx[k], :] for k in range(n_scenes)])
 
                 # a query whose sampled keys are all masked attends to everything (reference :346)
                 batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
-                batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
+                if bufs is not None:
+                    torch.logical_or(batched_attn, mask_idx[0][None, :, None], out=batched_attn)
+                else:
+                    batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
 
-                step_fn = self._decoder_pass(decoder_counter, dec, i)
-                if getattr(self, "_graphed_passes", None) is not None:
-                    want = self._graph_shapes[decoder_counter * self.num_levels + i]
-                    have = (queries.shape, query_pos.shape, batched_aux.shape, batched_attn.shape,
-                            batched_pos_enc.shape)
-                    if tuple(have) != tuple(want):
-                        step_fn = self._eager_pass(dec, i)
                 queries = step_fn(queries, query_pos, batched_aux.contiguous(), batched_attn.contiguous(),
                                   batched_pos_enc.contiguous())
 

@@ -586,10 +586,14 @@ def avgpool_down2(feats, nbr2):
 
 class _GatherRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, idx):
+    def forward(ctx, src, idx, out=None):
         src = src.contiguous()
         idx = idx.contiguous()
-        out = torch.empty((idx.shape[0], src.shape[1]), dtype=torch.float32, device=src.device)
+        if out is None:
+            out = torch.empty((idx.shape[0], src.shape[1]), dtype=torch.float32, device=src.device)
+        elif tuple(out.shape) != (idx.shape[0], src.shape[1]) or out.dtype != torch.float32 or not out.is_contiguous() \
+                or out.requires_grad:
+            raise RuntimeError("gather_rows: `out` must be a contiguous f32 [len(idx), C] tensor that does not require grad")
         check(lib.usc_gather_rows(_ptr(src), src.shape[1], _ptr(idx), idx.shape[0], _ptr(out), _stream()),
               "usc_gather_rows")
         ctx.save_for_backward(idx)
@@ -603,13 +607,14 @@ class _GatherRows(torch.autograd.Function):
         dsrc = torch.zeros((ctx.n_src, dout.shape[1]), dtype=torch.float32, device=dout.device)
         check(lib.usc_scatter_add_rows(_ptr(dout), dout.shape[1], _ptr(idx), idx.shape[0], _ptr(dsrc), _stream()),
               "usc_scatter_add_rows")
-        return dsrc, None
+        return dsrc, None, None
 
 
-def gather_rows(src, idx):
+def gather_rows(src, idx, out=None):
+    """out[j] = src[idx[j]]; `out` (optional): the caller's buffer (e.g. a HIP-graph input) instead of a new tensor."""
     _chk(src, torch.float32, "src")
     _chk(idx, torch.int64, "idx")
-    return _GatherRows.apply(src, idx)
+    return _GatherRows.apply(src, idx, out)
 
 
 def gather_rows_i32(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
