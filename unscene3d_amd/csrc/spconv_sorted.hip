@@ -364,7 +364,10 @@ SortedPlan plan_sorted(int64_t n_out, int cin, int cout, int K) {
   SortedPlan pl{nb, nb == 4 ? 4 : 8, 1};
   const int64_t ntiles = ceil_div(n_out, 32);
   const int64_t waves = ntiles * (cb / nb);
-  constexpr int64_t kTarget = 2048;   // two waves per SIMD
+  // two waves per SIMD; four on the mid-size maps (measured on the bench scene's 9 402-row level: 64->64 43 -> 37 us,
+  // 128->128 104 -> 100, 192->128 147 -> 138; on the 2 222-row level the finer offset split costs more in partial
+  // sums than it gains: 256->256 82 -> 114 us)
+  const int64_t kTarget = n_out >= 4096 ? 4096 : 2048;
   if (waves > 0 && waves < kTarget) {   // (an empty map plans to nothing)
     int64_t G = ceil_div(kTarget, waves);
     if (G > K) G = K;
