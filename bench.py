@@ -33,7 +33,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 den
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -61,7 +61,7 @@ def parse():
                          "with fewer GPUs than ranks (ranks then share devices)")
     ap.add_argument("--cpu-sample-voxels", type=int, default=10_000,
                     help="scene size of the cpu_baseline leg (2 x (1 warm-up + 3 timed) passes of the CPU restatement)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def build_model(device):

@@ -121,7 +121,10 @@ def test_conv3_forward_backward(device, cin, cout):
 
 
 @pytest.mark.parametrize("n,extent,cin,cout", [(37, 3, 32, 32), (700, 6, 64, 96), (3000, 10, 128, 128),
-                                               (9000, 16, 96, 192), (60000, 40, 96, 96), (60000, 40, 32, 64)])
+                                               (9000, 16, 96, 192), (60000, 40, 96, 96), (60000, 40, 32, 64),
+                                               # ~3 100 rows x 64 and ~6 900 rows x 32 channels: offset splits whose
+                                               # rounded slice width used to leave slices past offset 31
+                                               (6000, 10, 64, 64), (9000, 20, 32, 32)])
 def test_mask_sorted_conv_equals_row_order_conv(device, n, extent, cin, cout, monkeypatch):
     """usc_rowsort_build invariants (perm is a permutation, tile masks are the OR of their rows' neighbour masks)
     and usc_spconv_sorted_gemm vs the row-order kernels and the CPU oracle; permutation independence BIT FOR BIT

@@ -170,7 +170,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void gather_gemm_so
   const int Kg = (K + p.G - 1) / p.G;
   const int k_begin = blockIdx.z * Kg;
   const int k_end = k_begin + Kg < K ? k_begin + Kg : K;
-  const uint32_t range = (k_end >= 32 ? 0xffffffffu : ((1u << k_end) - 1u)) & ~((1u << k_begin) - 1u);
+  // (a slice past the last offset has an empty range; the shifts are only taken below 32)
+  const uint32_t lo = k_begin >= 32 ? 0xffffffffu : ((1u << k_begin) - 1u);
+  const uint32_t hi = k_end >= 32 ? 0xffffffffu : ((1u << k_end) - 1u);
+  const uint32_t range = k_begin < k_end ? (hi & ~lo) : 0u;
 
   const int64_t srow = tile * 32 + i;
   const int my_row = (tile < ntiles && srow < p.n_out) ? p.perm[srow] : -1;
@@ -371,7 +374,9 @@ SortedPlan plan_sorted(int64_t n_out, int cin, int cout, int K) {
   if (waves > 0 && waves < kTarget) {   // (an empty map plans to nothing)
     int64_t G = ceil_div(kTarget, waves);
     if (G > K) G = K;
-    pl.G = (int)G;
+    // no empty slices: G = 20 on 27 offsets means 2 per slice, which 14 slices cover
+    const int64_t Kg = ceil_div((int64_t)K, G);
+    pl.G = (int)ceil_div((int64_t)K, Kg);
   }
   return pl;
 }
