@@ -1,0 +1,40 @@
+import sys, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from unscene3d_amd.config import apply_overrides, default_config
+from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+from unscene3d_amd.trainer.trainer import InstanceSegmentation
+from test_gpu_parity import _PermSource
+device = torch.device("cuda:0")
+cfg = apply_overrides(default_config(), ["general.num_targets=3", "model.sample_sizes=[200,800,3200,12800,51200]"])
+ds = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=12000, seed=3300)
+collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device))
+torch.manual_seed(3)
+mods = [InstanceSegmentation(cfg).to(device).train() for _ in range(4)]
+for m in mods[1:]:
+    m.load_state_dict(mods[0].state_dict())
+mods[2].model.enable_decoder_graphs(batch_size=1, device=device)
+mods[3].model.enable_decoder_graphs(batch_size=1, device=device)
+names = ["eager A", "eager B", "graph A", "graph B"]
+res = []
+for module in mods:
+    module.model.randperm = _PermSource()
+    total, weighted = module.training_step(collate([ds[0]]))
+    total.backward()
+    torch.cuda.synchronize()
+    res.append({n: p.grad.clone() for n, p in module.named_parameters() if p.grad is not None and "backbone" not in n})
+def cmp(i, j):
+    rows = []
+    for n in res[i]:
+        a, b = res[i][n], res[j][n]
+        rows.append((float((a - b).abs().max() / (a.abs().max() + 1e-12)), n))
+    rows.sort(reverse=True)
+    print(names[i], "vs", names[j], [(f"{r:.1e}", n.replace("model.", "")) for r, n in rows[:5]])
+cmp(0, 1); cmp(2, 3); cmp(0, 2); cmp(1, 3)
+for n in ("model.cross_attention.0.3.multihead_attn.in_proj_bias", "model.lin_squeeze.0.3.bias", "model.lin_squeeze.0.2.bias"):
+    vals = [r[n] for r in res]
+    d = (vals[0] - vals[2]).abs()
+    idx = torch.nonzero(d > 1e-3 * vals[0].abs().max()).flatten().tolist()
+    print(n, "entries off:", len(idx), idx[:20])
+    for i in idx[:4]:
+        print("   ", i, [float(v[i]) for v in vals])

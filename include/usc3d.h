@@ -454,6 +454,15 @@ int usc_linear_fwd(const float* x, const float* W, const float* b, int32_t M,
 int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M,
                    int32_t N, int32_t K, float* dx, float* dW, float* db,
                    int32_t accumulate, usc_stream_t s);
+/* out[c] (+)= sum over the n rows of x f32[n, c]: the bias gradient of a linear
+ * layer over many rows (the 3 200 / 12 800 sampled voxels of a decoder pass,
+ * models/mask3d.py:351-352 lin_squeeze and the key / value projections of
+ * :547-605).  Fixed summation order (256-row partials, then ascending): the same
+ * bits on every launch, also when replayed from a captured graph.
+ * ws: usc_col_sum_ws_bytes(n, c). */
+int64_t usc_col_sum_ws_bytes(int64_t n, int32_t c);
+int usc_col_sum(const float* x, int64_t n, int32_t c, float* out,
+                int32_t accumulate, void* ws, int64_t ws_bytes, usc_stream_t s);
 
 /* LayerNorm over the last dimension of x f32[rows, d] (d in 64*{1,2,3,4,6,8}):
  *   y = (x - mean) * rstd * gamma + beta,  rstd = 1/sqrt(var + eps)  (biased var);

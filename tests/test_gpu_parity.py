@@ -800,6 +800,24 @@ def test_fused_masked_cross_attention(device, L, S, B):
     assert rel_err(qd.grad, qr.grad) < 1e-5 and rel_err(kd.grad, kr.grad) < 1e-5 and rel_err(vd.grad, vr.grad) < 1e-5
 
 
+@pytest.mark.parametrize("n,c", [(1, 128), (255, 96), (257, 128), (3260, 128), (12800, 128), (5000, 19)])
+def test_col_sum_fixed_order(device, n, c):
+    """usc_col_sum (bias gradient of the many-row linear layers) vs a float64 column sum; accumulate adds; two launches
+    give identical bits."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g)
+    xd = _dev(x, device)
+    ref = x.double().sum(0)
+    out = ops.col_sum(xd, torch.empty(c, device=device))
+    assert rel_err(out, ref.float()) < 1e-5
+    assert torch.equal(ops.col_sum(xd, torch.empty(c, device=device)), out)
+    base = torch.randn(c, generator=g)
+    acc = ops.col_sum(xd, _dev(base.clone(), device), accumulate=True)
+    assert rel_err(acc, (ref + base.double()).float()) < 1e-5
+
+
 def test_edge_sizes_of_the_decoder_and_sorted_kernels(device):
     """Empty and tiny inputs: zero output rows, a map smaller than one tile, fewer keys than one chunk, a single
     query, LayerNorm / linear on one row."""
@@ -917,17 +935,20 @@ def test_triplane_projection_loss(device):
     assert float(exp_grad.abs().sum()) > 0 and rel_err(lg.grad, exp_grad) < 1e-4, rel_err(lg.grad, exp_grad)
 
 
-@pytest.mark.parametrize("level_embed", [False, True])
-def test_decoder_graph_capture_equals_eager(device, level_embed):
+@pytest.mark.parametrize("level_embed,sample_sizes", [(False, "[20,50,100,200,800]"), (True, "[20,50,100,200,800]"),
+                                                      (False, "[200,800,3200,12800,51200]")])
+def test_decoder_graph_capture_equals_eager(device, level_embed, sample_sizes):
     """The HIP-graph captured decoder passes give the same loss and gradients as the eager path.
     (Two module instances with identical weights: capture must happen before the module's first backward.)
-    With use_level_embed the embedding weight must receive its gradient from the captured passes too."""
+    With use_level_embed the embedding weight must receive its gradient from the captured passes too.
+    Third case: the reference's own sample sizes on a 12 k-voxel scene — every level is SMALLER than its captured key
+    count, so the graphed module pads the keys (masked) up to it while the eager one attends over the level as is."""
     from unscene3d_amd.config import apply_overrides, default_config
     from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
     from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
     from unscene3d_amd.trainer.trainer import InstanceSegmentation
 
-    cfg = apply_overrides(default_config(), ["general.num_targets=3", "model.sample_sizes=[20,50,100,200,800]",
+    cfg = apply_overrides(default_config(), ["general.num_targets=3", f"model.sample_sizes={sample_sizes}",
                                              f"model.use_level_embed={level_embed}"])
     ds = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=12000, seed=3300)
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device))

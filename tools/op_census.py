@@ -1,24 +1,56 @@
-"""Which host-side ATen operators (adds, copies, fills ...) one ungraphed training step issues, and from where.
+"""Which ATen operators (adds, copies, fills ...) one ungraphed training step issues: per phase (forward / loss /
+backward / optimizer), per operator and operand shapes, with the python call site for the forward ones.
 
-    python tools/op_census.py [--voxels 150000] [--top 60] > gpurun_out/op_census.txt
+    python tools/op_census.py [--voxels 150000] [--top 80] > gpurun_out/op_census.txt
 
-CPU-activity profile only (operator names + python call sites; no device tracing): the counts are what the captured
-decoder graphs replay as nodes and what the backbone path issues through ATen each step."""
+A TorchDispatchMode counts every operator that reaches the dispatcher (the autograd engine's threads inherit the mode);
+the counts are what the captured decoder graphs replay as nodes and what the rest of the step issues through ATen."""
 import argparse
 import collections
 import os
 import sys
+import traceback
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, HERE)
 import bench  # noqa: E402
+
+SKIP = ("aten.view", "aten.detach", "aten.t.", "aten.permute", "aten.transpose", "aten.unsqueeze", "aten.squeeze",
+        "aten.expand", "aten.select", "aten.slice", "aten.alias", "aten.as_strided", "aten._unsafe_view",
+        "aten.reshape", "aten.unbind", "aten.split", "aten.empty", "aten.new_empty", "aten.lift_fresh",
+        "aten._local_scalar_dense", "aten.is_pinned", "aten.unflatten", "aten.narrow", "aten.chunk")
+
+
+class Census(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.phase = "forward"
+        self.rows = collections.Counter()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            shapes = tuple(tuple(a.shape) for a in args if isinstance(a, torch.Tensor))[:3]
+            on_dev = any(isinstance(a, torch.Tensor) and a.is_cuda for a in args)
+            site = ""
+            if self.phase != "backward":
+                for fr in reversed(traceback.extract_stack(limit=14)):
+                    if fr.filename.startswith(HERE) and "tools/op_census" not in fr.filename \
+                            and not fr.filename.endswith("bench.py"):
+                        site = f"{os.path.relpath(fr.filename, HERE)}:{fr.lineno}"
+                        break
+            if on_dev or not args:
+                self.rows[(self.phase, name, shapes, site)] += 1
+        return func(*args, **(kwargs or {}))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--voxels", type=int, default=150_000)
-    ap.add_argument("--top", type=int, default=70)
+    ap.add_argument("--top", type=int, default=120)
     a = ap.parse_args()
     args = bench.parse(["--voxels", str(a.voxels), "--no-graphs", "--no-prefetch"])
     dev = torch.device("cuda:0")
@@ -26,40 +58,35 @@ def main():
     for _ in range(3):
         step(1)
     torch.cuda.synchronize()
-    from torch.profiler import ProfilerActivity, profile
-    with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+    census = Census()
+    orig_backward = torch.Tensor.backward
+
+    def backward(self, *aa, **kw):
+        census.phase = "backward"
+        try:
+            return orig_backward(self, *aa, **kw)
+        finally:
+            census.phase = "optimizer"
+
+    torch.Tensor.backward = backward
+    with census:
         step(1)
         torch.cuda.synchronize()
-    want = ("aten::add", "aten::add_", "aten::copy_", "aten::fill_", "aten::zero_", "aten::mul", "aten::mul_",
-            "aten::clone", "aten::contiguous", "aten::sum", "aten::index_select", "aten::cat", "aten::stack",
-            "aten::where", "aten::masked_fill_", "aten::div", "aten::div_", "aten::sub", "aten::neg", "aten::relu",
-            "aten::threshold_backward", "aten::_softmax", "aten::bmm", "aten::mm", "aten::addmm", "aten::index",
-            "aten::index_put_", "aten::scatter_add_", "aten::gather", "aten::empty_like", "aten::zeros",
-            "aten::zeros_like", "aten::sigmoid", "aten::exp", "aten::log", "aten::clamp", "aten::clamp_min")
-    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    by_site = collections.Counter()
-    by_op = collections.Counter()
-    for ev in prof.events():
-        if ev.name not in want:
-            continue
-        site = "?"
-        for fr in ev.stack:
-            if here in fr and "tools/op_census" not in fr and "bench.py" not in fr:
-                site = fr.replace(here + "/", "")
-                break
-        else:
-            for fr in ev.stack:
-                if "autograd" in fr or "Backward" in fr:
-                    site = "autograd engine: " + fr[-80:]
-                    break
-        by_site[(ev.name, site)] += 1
-        by_op[ev.name] += 1
-    print("# operator totals (one step, graphs off)")
-    for k, v in by_op.most_common():
+    torch.Tensor.backward = orig_backward
+    per_phase = collections.Counter()
+    per_op = collections.Counter()
+    for (phase, name, shapes, site), v in census.rows.items():
+        per_phase[phase] += v
+        per_op[(phase, name)] += v
+    print("# device operators per phase (views / metadata ops excluded)")
+    for k, v in per_phase.most_common():
         print(f"{v:6d}  {k}")
-    print("# by call site")
-    for (name, site), v in by_site.most_common(a.top):
-        print(f"{v:6d}  {name:24s} {site}")
+    print("# per phase and operator")
+    for (phase, name), v in per_op.most_common(60):
+        print(f"{v:6d}  {phase:9s} {name}")
+    print("# per phase, operator, operand shapes, call site")
+    for (phase, name, shapes, site), v in census.rows.most_common(a.top):
+        print(f"{v:6d}  {phase:9s} {name:34s} {str(shapes):60s} {site}")
 
 
 if __name__ == "__main__":

@@ -123,6 +123,8 @@ SIGNATURES = {
     "usc_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
     "usc_affine_rows": (C.c_int, [_p, _i32, _i64, _i32, _p, _p, _p]),
     "usc_colsum_sequential": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
+    "usc_col_sum_ws_bytes": (_i64, [_i64, _i32]),
+    "usc_col_sum": (C.c_int, [_p, _i64, _i32, _p, _i32, _p, _i64, _p]),
     "usc_color_lut": (C.c_int, [_p, _i64, _i32, _p, _p, _i32, _p]),
     "usc_felz_face_normals": (C.c_int, [_p, _p, _i64, _p, _p]),
     "usc_felz_vertex_normals": (C.c_int, [_p, _p, _p, _i64, _p, _p]),

@@ -320,6 +320,35 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
   }
 }
 
+
+// Column sums of a many-row table (the bias gradient of a linear layer over 3 200 / 12 800 sampled voxels), in a fixed
+// order: 256-row partial sums, then one thread per column adds the partials ascending.  No atomics, no
+// last-block semaphores: the same bits on every launch and inside captured graphs.
+constexpr int kColSumRows = 256;
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int64_t n, int c,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.x * kColSumRows;
+  const int64_t r1 = r0 + kColSumRows < n ? r0 + kColSumRows : n;
+  float s = 0.f;
+  if (col < c)
+    for (int64_t r = r0 + ty; r < r1; r += 4) s += x[r * c + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < c) partial[(int64_t)blockIdx.x * c + col] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+}
+
+__global__ __launch_bounds__(64) void col_sum_final_kernel(const float* __restrict__ partial, int64_t parts, int c,
+                                                          int accumulate, float* __restrict__ out) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col >= c) return;
+  float s = 0.f;
+  for (int64_t p = 0; p < parts; ++p) s += partial[p * c + col];
+  out[col] = accumulate ? out[col] + s : s;
+}
+
 }  // namespace
 }  // namespace usc
 
@@ -346,6 +375,27 @@ int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M, i
     hipLaunchKernelGGL(usc::linear_bwd_kernel, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, x, W, (int)M, (int)N, (int)K,
                        dx_tiles, (int)accumulate, dx, dW, db);
   USC_CHECK_LAUNCH("usc_linear_bwd");
+  return USC_OK;
+}
+
+int64_t usc_col_sum_ws_bytes(int64_t n, int32_t c) {
+  const int64_t parts = n > 0 ? (n + usc::kColSumRows - 1) / usc::kColSumRows : 0;
+  return parts * (c > 0 ? c : 0) * 4;
+}
+
+int usc_col_sum(const float* x, int64_t n, int32_t c, float* out, int32_t accumulate, void* ws, int64_t ws_bytes,
+                usc_stream_t s) {
+  USC_REQUIRE(n >= 0 && c >= 1, "usc_col_sum: bad sizes");
+  USC_REQUIRE(out && (n == 0 || (x && ws)), "usc_col_sum: null pointer");
+  USC_REQUIRE(ws_bytes >= usc_col_sum_ws_bytes(n, c), "usc_col_sum: workspace too small");
+  hipStream_t st = usc::as_stream(s);
+  const int64_t parts = n > 0 ? (n + usc::kColSumRows - 1) / usc::kColSumRows : 0;
+  const unsigned cg = (unsigned)((c + 63) / 64);
+  if (parts > 0)
+    hipLaunchKernelGGL(usc::col_sum_partial_kernel, dim3((unsigned)parts, cg), dim3(256), 0, st, x, n, (int)c, (float*)ws);
+  hipLaunchKernelGGL(usc::col_sum_final_kernel, dim3(cg), dim3(64), 0, st, (const float*)ws, parts, (int)c, (int)accumulate,
+                     out);
+  USC_CHECK_LAUNCH("usc_col_sum");
   return USC_OK;
 }
 

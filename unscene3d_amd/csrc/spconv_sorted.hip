@@ -358,19 +358,33 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void gather_gemm_so
 
 struct SortedPlan { int NB, WAVES, G; };
 
+// Tile width (NB blocks of 32 output columns per wave) and offset split (G partial-sum slices) of one launch.
+// Measured on the bench scene's 507 ... 40 421-row levels (tools/sorted_plan_sweep.py -> profiles/r02_sorted_plan.txt):
+// the tile width hardly matters at a given G; what matters is (a) enough waves that every SIMD holds two or three
+// (a lone wave runs its chain of matrix-core steps at ~60 %: nothing overlaps its barriers and LDS reads) against
+// (b) one more [n_out, cout] slice written and read back per extra G.  (a) wins up to ~2 waves per SIMD on the
+// <= 2 222-row levels and ~3 on the larger ones, where a slice is cheap relative to the chain.
 SortedPlan plan_sorted(int64_t n_out, int cin, int cout, int K) {
   const int cb = cout / 32;
   int nb = 1;
   if (cb % 4 == 0) nb = 4;
   else if (cb % 3 == 0) nb = 3;
   else if (cb % 2 == 0) nb = 2;
+  // USC3D_SORTED_TUNE=1: tools/sorted_plan_sweep.py forces (NB, G) per launch through the environment
+  static const bool tune = getenv("USC3D_SORTED_TUNE") != nullptr;
+  if (tune) {
+    const char* e_nb = getenv("USC3D_SORTED_NB");
+    const char* e_g = getenv("USC3D_SORTED_G");
+    const int f_nb = e_nb ? atoi(e_nb) : 0, f_g = e_g ? atoi(e_g) : 0;
+    if (f_nb >= 1 && f_nb <= 4 && cb % f_nb == 0 && f_g >= 1) {
+      const int64_t Kg = ceil_div((int64_t)K, (int64_t)(f_g < K ? f_g : K));
+      return SortedPlan{f_nb, f_nb == 4 ? 4 : 8, (int)ceil_div((int64_t)K, Kg)};
+    }
+  }
   SortedPlan pl{nb, nb == 4 ? 4 : 8, 1};
   const int64_t ntiles = ceil_div(n_out, 32);
   const int64_t waves = ntiles * (cb / nb);
-  // two waves per SIMD; four on the mid-size maps (measured on the bench scene's 9 402-row level: 64->64 43 -> 37 us,
-  // 128->128 104 -> 100, 192->128 147 -> 138; on the 2 222-row level the finer offset split costs more in partial
-  // sums than it gains: 256->256 82 -> 114 us)
-  const int64_t kTarget = n_out >= 4096 ? 4096 : 2048;
+  const int64_t kTarget = n_out >= 4096 ? 3072 : 2048;
   if (waves > 0 && waves < kTarget) {   // (an empty map plans to nothing)
     int64_t G = ceil_div(kTarget, waves);
     if (G > K) G = K;

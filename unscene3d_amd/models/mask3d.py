@@ -254,6 +254,14 @@ class Mask3D(nn.Module):
                 curr_sample_size = max(sizes)
                 if not (self.max_sample_size or is_eval):
                     curr_sample_size = min(curr_sample_size, self.sample_sizes[hlevel])
+                graph_shapes = (self._graph_shapes[decoder_counter * self.num_levels + i]
+                                if getattr(self, "_graphed_passes", None) is not None else None)
+                if graph_shapes is not None and curr_sample_size < graph_shapes[2][1]:
+                    # a level smaller than the captured key count: pad up to it (row 0, masked like the padding of a
+                    # ragged batch below) so the captured pass still applies.  Masked keys carry softmax weight 0:
+                    # the pass output is that of the unpadded keys, and the all-masked-row rule below is unchanged
+                    # because the padding repeats row 0's mask bits.
+                    curr_sample_size = graph_shapes[2][1]
 
                 rand_idx, mask_idx = [], []
                 for k, pcd_size in enumerate(sizes):
@@ -270,8 +278,8 @@ class Mask3D(nn.Module):
 
                 step_fn = self._decoder_pass(decoder_counter, dec, i)
                 bufs = None
-                if getattr(self, "_graphed_passes", None) is not None:
-                    want = self._graph_shapes[decoder_counter * self.num_levels + i]
+                if graph_shapes is not None:
+                    want = graph_shapes
                     have = (queries.shape, query_pos.shape, (n_scenes, curr_sample_size, decomposed_aux[0].shape[1]),
                             (n_scenes, curr_sample_size, decomposed_attn[0].shape[1]),
                             (n_scenes, curr_sample_size, pos_encodings_pcd[hlevel][0][0].shape[1]))

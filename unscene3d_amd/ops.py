@@ -817,6 +817,20 @@ def _lin_fwd(x2, W, b):
     return torch.addmm(b, x2, W.t()) if b is not None else x2 @ W.t()
 
 
+def col_sum(x2, out, accumulate=False):
+    """out[c] (+)= sum_r x2[r, c] in a fixed order (usc_col_sum).  Not torch.sum: replayed from the captured decoder
+    graphs, ATen's multi-block reduction left the bias gradients of the 3 200 / 12 800-row projections at the value
+    of the previous reduction that had used the same scratch block (found by the padded-level graph test)."""
+    _chk(x2, torch.float32, "x2")
+    if not out.is_contiguous() or out.dtype != torch.float32 or out.numel() != x2.shape[1]:
+        raise RuntimeError("col_sum: `out` must be a contiguous f32 vector with one entry per column")
+    wsb = lib.usc_col_sum_ws_bytes(x2.shape[0], x2.shape[1])
+    ws = _ws(wsb, x2.device)
+    check(lib.usc_col_sum(_ptr(x2), x2.shape[0], x2.shape[1], _ptr(out), int(accumulate), _ptr(ws), wsb, _stream()),
+          "usc_col_sum")
+    return out
+
+
 def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False):
     """-> dx (or None); writes (accumulate: adds) dW_out [N,K] and db_out [N] (row-block views are fine)."""
     M, N = dy2.shape
@@ -838,10 +852,7 @@ def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False):
     else:
         torch.mm(dy2.t(), x2, out=dW_out)
     if db_out is not None:
-        if accumulate:
-            db_out.add_(dy2.sum(0))
-        else:
-            torch.sum(dy2, 0, out=db_out)
+        col_sum(dy2, db_out, accumulate)
     if not need_dx:
         return None
     if rows_ok:
