@@ -375,6 +375,17 @@ int usc_relu_bwd(const float* y, const float* dy, float* dx, int64_t numel,
  * ---------------------------------------------------------------------- */
 int usc_avgpool_down2(const float* in, int32_t c, const int32_t* nbr2,
                       int64_t n_coarse, float* out, usc_stream_t s);
+/* The attention-mask chain of the mask module (models/mask3d.py:418-439: per-voxel
+ * logits = segment logits gathered through point2segment, pooled
+ * num_pooling_steps times, then sigmoid < 0.5) without the [voxels, Q] table:
+ *   row_of (optional, i64[n_fine]): child ch reads row row_of[ch] of `in`
+ *          (leading dimension ld >= c) — first step, `in` = the [segments, Q] logits;
+ *   mask_out (optional, u8[n_coarse, c]): last step writes
+ *          sigmoid(mean) < 0.5 instead of the means (`out` may then be NULL). */
+int usc_avgpool_down2_ex(const float* in, int32_t c, int32_t ld,
+                         const int64_t* row_of, const int32_t* nbr2,
+                         int64_t n_coarse, float* out, uint8_t* mask_out,
+                         usc_stream_t s);
 
 /* ------------------------------------------------------------------------
  * gather / scatter rows (D1 mask-module row gather mask3d.py:418-419, feature

@@ -800,6 +800,38 @@ def test_fused_masked_cross_attention(device, L, S, B):
     assert rel_err(qd.grad, qr.grad) < 1e-5 and rel_err(kd.grad, kr.grad) < 1e-5 and rel_err(vd.grad, vr.grad) < 1e-5
 
 
+def test_attention_mask_chain_without_the_voxel_table(device):
+    """avgpool_down2(row_of=..., threshold=...) — the mask module's gather -> pool x steps -> sigmoid < 0.5 chain read
+    straight from the [segments, Q] logits (a column slice of a wider table) — equals the materialised chain bit for
+    bit, for 1..3 pooling steps; and the plain pooling against the CPU oracle."""
+    from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd import ops
+
+    c, cmap = _maps(device, seed=11, n=9000, extent=20)
+    x = ME.SparseTensor(coordinates=_dev(c, device), features=torch.zeros(len(c), 3, device=device), device=device)
+    cm = x.coordinate_manager
+    g = torch.Generator().manual_seed(5)
+    S, Q = 37, 100
+    table = _dev(torch.randn(S, 128, generator=g) * 0.2, device)
+    seg = table[:, :Q]                                   # leading dimension 128, 100 columns
+    p2s = _dev(torch.randint(0, S, (len(c),), generator=g), device)
+    for steps in (1, 2, 3):
+        ref = ops.gather_rows(seg.contiguous(), p2s)
+        ts = 1
+        for _ in range(steps):
+            ref = ops.avgpool_down2(ref, cm.stride_map(ts)["nbr2"])
+            ts *= 2
+        ref_mask = ref.sigmoid() < 0.5
+        out, ts = seg, 1
+        for k in range(steps):
+            out = ops.avgpool_down2(out, cm.stride_map(ts)["nbr2"], row_of=p2s if k == 0 else None,
+                                    threshold=k == steps - 1)
+            ts *= 2
+        assert out.dtype == torch.bool and out.shape == ref_mask.shape
+        assert torch.equal(out, ref_mask)
+        assert 0.2 < float(out.float().mean()) < 0.8
+
+
 @pytest.mark.parametrize("n,c", [(1, 128), (255, 96), (257, 128), (3260, 128), (12800, 128), (5000, 19)])
 def test_col_sum_fixed_order(device, n, c):
     """usc_col_sum (bias gradient of the many-row linear layers) vs a float64 column sum; accumulate adds; two launches

@@ -84,6 +84,7 @@ SIGNATURES = {
     "usc_relu_fwd": (C.c_int, [_p, _p, _i64, _p]),
     "usc_relu_bwd": (C.c_int, [_p, _p, _p, _i64, _p]),
     "usc_avgpool_down2": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
+    "usc_avgpool_down2_ex": (C.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _p, _p]),
     "usc_gather_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_scatter_add_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_segment_csr_ws_bytes": (_i64, [_i64, _i64]),

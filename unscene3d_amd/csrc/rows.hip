@@ -349,10 +349,14 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------
+// row_of (optional): child `ch` reads row row_of[ch] of `in` (leading dimension ld) — the mask module's per-voxel
+// logits are rows of the [segments, Q] table, never materialised per voxel.  mask_out (optional): instead of the
+// means, sigmoid(mean) < 0.5 as bytes (the attention mask of models/mask3d.py:436).
 template <int VEC>
-__global__ __launch_bounds__(256) void avgpool_down2_kernel(const float* __restrict__ in, int c,
+__global__ __launch_bounds__(256) void avgpool_down2_kernel(const float* __restrict__ in, int c, int ld,
+                                                           const int64_t* __restrict__ row_of,
                                                            const int32_t* __restrict__ nbr2, int64_t n_coarse,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, uint8_t* __restrict__ mask_out) {
   const int CT = c / VEC;
   const int64_t total = n_coarse * CT;
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
@@ -367,16 +371,20 @@ __global__ __launch_bounds__(256) void avgpool_down2_kernel(const float* __restr
       const int ch = nbr2[(int64_t)k * n_coarse + p];
       if (ch >= 0) {
         ++cnt;
+        const int64_t row = row_of ? row_of[ch] : (int64_t)ch;
         if (VEC == 4) {
-          const float4 t = *reinterpret_cast<const float4*>(in + (int64_t)ch * c + cg * 4);
+          const float4 t = *reinterpret_cast<const float4*>(in + row * ld + cg * 4);
           acc[0] += t.x; acc[1] += t.y; acc[2] += t.z; acc[3] += t.w;
         } else {
-          acc[0] += in[(int64_t)ch * c + cg];
+          acc[0] += in[row * ld + cg];
         }
       }
     }
     const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
-    if (VEC == 4) {
+    if (mask_out) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) mask_out[p * c + cg * VEC + v] = (1.f / (1.f + expf(-(acc[v] * inv)))) < 0.5f;
+    } else if (VEC == 4) {
       *reinterpret_cast<float4*>(out + p * c + cg * 4) =
           make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
     } else {
@@ -730,15 +738,20 @@ int usc_relu_bwd(const float* y, const float* dy, float* dx, int64_t numel, usc_
 }
 
 int usc_avgpool_down2(const float* in, int32_t c, const int32_t* nbr2, int64_t n_coarse, float* out, usc_stream_t s) {
-  USC_REQUIRE(c >= 1 && n_coarse >= 0, "usc_avgpool_down2: bad sizes");
+  return usc_avgpool_down2_ex(in, c, c, nullptr, nbr2, n_coarse, out, nullptr, s);
+}
+
+int usc_avgpool_down2_ex(const float* in, int32_t c, int32_t ld, const int64_t* row_of, const int32_t* nbr2,
+                         int64_t n_coarse, float* out, uint8_t* mask_out, usc_stream_t s) {
+  USC_REQUIRE(c >= 1 && ld >= c && n_coarse >= 0, "usc_avgpool_down2: bad sizes");
   if (n_coarse == 0) return USC_OK;
-  USC_REQUIRE(in && nbr2 && out, "usc_avgpool_down2: null pointer");
-  if (c % 4 == 0)
+  USC_REQUIRE(in && nbr2 && (out || mask_out), "usc_avgpool_down2: null pointer");
+  if (c % 4 == 0 && ld % 4 == 0)
     hipLaunchKernelGGL((avgpool_down2_kernel<4>), dim3(stream_grid(n_coarse * (c / 4), 256)), dim3(256), 0,
-                       as_stream(s), in, (int)c, nbr2, n_coarse, out);
+                       as_stream(s), in, (int)c, (int)ld, row_of, nbr2, n_coarse, out, mask_out);
   else
     hipLaunchKernelGGL((avgpool_down2_kernel<1>), dim3(stream_grid(n_coarse * c, 256)), dim3(256), 0, as_stream(s), in,
-                       (int)c, nbr2, n_coarse, out);
+                       (int)c, (int)ld, row_of, nbr2, n_coarse, out, mask_out);
   USC_CHECK_LAUNCH("usc_avgpool_down2");
   return USC_OK;
 }

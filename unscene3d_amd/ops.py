@@ -574,13 +574,22 @@ def relu(x):
 
 
 # ------------------------------------------------------------------ pooling / gather / segments
-def avgpool_down2(feats, nbr2):
-    """MinkowskiAvgPooling(kernel_size=2, stride=2) forward: mean over present children."""
-    _chk(feats, torch.float32, "feats")
-    nc = nbr2.shape[1]
-    out = torch.empty((nc, feats.shape[1]), dtype=torch.float32, device=feats.device)
-    check(lib.usc_avgpool_down2(_ptr(feats), feats.shape[1], _ptr(nbr2), nc, _ptr(out), _stream()),
-          "usc_avgpool_down2")
+def avgpool_down2(feats, nbr2, row_of=None, threshold=False):
+    """MinkowskiAvgPooling(kernel_size=2, stride=2) forward: mean over present children.
+    row_of (i64[n_fine]): the fine rows are feats[row_of[i]] (feats may be a column slice of a wider table);
+    threshold: return sigmoid(mean) < 0.5 as bool instead of the means."""
+    if feats.dtype != torch.float32 or not feats.is_cuda or feats.dim() != 2 or feats.stride(1) != 1:
+        raise RuntimeError("avgpool_down2: feats must be an f32 HIP matrix with unit column stride")
+    if row_of is None and not feats.is_contiguous():
+        raise RuntimeError("avgpool_down2: feats must be contiguous")
+    if row_of is not None:
+        _chk(row_of, torch.int64, "row_of")
+    nc, c = nbr2.shape[1], feats.shape[1]
+    ld = feats.stride(0) if feats.shape[0] > 1 else c
+    out = torch.empty((nc, c), dtype=torch.bool if threshold else torch.float32, device=feats.device)
+    check(lib.usc_avgpool_down2_ex(_ptr(feats), c, ld, _ptr(row_of), _ptr(nbr2), nc,
+                                   None if threshold else _ptr(out), _ptr(out) if threshold else None, _stream()),
+          "usc_avgpool_down2_ex")
     return out
 
 

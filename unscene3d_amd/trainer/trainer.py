@@ -76,7 +76,11 @@ class InstanceSegmentation(nn.Module):
         # ordered sum over the stacked scalars instead of ~50 scalar multiplies and ~50 scalar adds (and their
         # backward nodes); the per-key weighted losses are views of the product.
         keys = [k for k in losses if k in wd]
-        vals = torch.stack([losses[k] for k in keys])
+        flat = getattr(losses, "flat", None)
+        if flat is not None and len(keys) == len(losses) == flat.numel():
+            vals = flat                                   # the criterion's own table, already in key order
+        else:
+            vals = torch.stack([losses[k] for k in keys])
         wkey = (tuple(keys), vals.device)
         if getattr(self, "_wvec_key", None) != wkey:
             self._wvec = torch.tensor([float(wd[k]) for k in keys], dtype=vals.dtype, device=vals.device)
