@@ -341,6 +341,24 @@ int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamm
                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
                          float* invstd, float* scale, float* shift, void* ws,
                          int64_t ws_bytes, usc_stream_t s);
+/* Small maps (n <= usc_bn_fused_max_rows(), c % 8 == 0): usc_bn_forward_stats +
+ * usc_bn_apply in ONE launch, and usc_bn_backward_reduce + usc_bn_backward_dx in
+ * one — the 507 ... 2 222-row levels of Res16UNet34C, where each launch is a
+ * round trip with the chip idle.  Same formulas; the f64 column sums are
+ * associated differently (128 row lanes, fixed order).  gamma is read 4 bytes
+ * at a time (parameter views need no 16-byte alignment). */
+int64_t usc_bn_fused_max_rows(void);
+int usc_bn_forward_fused(const float* x, int64_t n, int32_t c, const float* gamma,
+                         const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, float* mean, float* invstd,
+                         float* scale, float* shift, const float* residual,
+                         int32_t relu, float* y, usc_stream_t s);
+int usc_bn_backward_fused(const float* x, const float* dy, const float* y_out,
+                          const float* mean, const float* invstd,
+                          const float* gamma, int64_t n, int32_t c,
+                          int32_t training, int32_t accumulate, float* dgamma,
+                          float* dbeta, float* dx, float* dres, usc_stream_t s);
 /* y = [relu]( x*scale[c] + shift[c] (+ residual) ); mask-free (backward uses y>0). */
 int usc_bn_apply(const float* x, const float* scale, const float* shift,
                  const float* residual, int32_t relu, float* y, int64_t n,
@@ -465,10 +483,24 @@ int usc_linear_fwd(const float* x, const float* W, const float* b, int32_t M,
 int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M,
                    int32_t N, int32_t K, float* dx, float* dW, float* db,
                    int32_t accumulate, usc_stream_t s);
+/* The same two launches with what surrounds the layer in the decoder folded in
+ * (every extra pointer optional):
+ *   x2      the layer's input is x + x2 (query / key positional encodings,
+ *           models/mask3d.py:485,517) — forward and weight gradient;
+ *   relu    y = max(y, 0) (FFN activation, :542); y_relu = that output: the
+ *           gradients count dy only where it is > 0;
+ *   dx_add  [M,K] added to dx (a second gradient path into the same input). */
+int usc_linear_fwd_ex(const float* x, const float* x2, const float* W,
+                      const float* b, int32_t M, int32_t N, int32_t K,
+                      int32_t relu, float* y, usc_stream_t s);
+int usc_linear_bwd_ex(const float* dy, const float* y_relu, const float* x,
+                      const float* x2, const float* W, int32_t M, int32_t N,
+                      int32_t K, float* dx, const float* dx_add, float* dW,
+                      float* db, int32_t accumulate, usc_stream_t s);
 /* out[c] (+)= sum over the n rows of x f32[n, c]: the bias gradient of a linear
  * layer over many rows (the 3 200 / 12 800 sampled voxels of a decoder pass,
  * models/mask3d.py:351-352 lin_squeeze and the key / value projections of
- * :547-605).  Fixed summation order (256-row partials, then ascending): the same
+ * :547-605).  Fixed summation order (64-row partials, then 16 interleaved ascending chains): the same
  * bits on every launch, also when replayed from a captured graph.
  * ws: usc_col_sum_ws_bytes(n, c). */
 int64_t usc_col_sum_ws_bytes(int64_t n, int32_t c);
@@ -485,6 +517,13 @@ int usc_col_sum(const float* x, int64_t n, int32_t c, float* out,
 int usc_layernorm_fwd(const float* x, const float* gamma, const float* beta,
                       int64_t rows, int32_t d, float eps, float* y, float* mean,
                       float* rstd, usc_stream_t s);
+/* y = LayerNorm(x + res): the post-norm residual of the decoder layers
+ * (models/mask3d.py:523-524, 493-494, 543-544) in the same launch; the sum is
+ * written to sum_out f32[rows, d], which the backward takes as its `x`. */
+int usc_add_layernorm_fwd(const float* x, const float* res, const float* gamma,
+                          const float* beta, int64_t rows, int32_t d, float eps,
+                          float* y, float* sum_out, float* mean, float* rstd,
+                          usc_stream_t s);
 int64_t usc_layernorm_bwd_ws_bytes(int64_t rows, int32_t d);
 int usc_layernorm_bwd(const float* dy, const float* x, const float* mean,
                       const float* rstd, const float* gamma, int64_t rows,

@@ -725,6 +725,137 @@ def test_small_row_linear_matches_torch(device, rows, n_in, n_out):
     assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("rows,n_in,n_out", [(100, 128, 1024), (37, 96, 64), (3000, 128, 128)])
+def test_linear_with_fused_relu(device, rows, n_in, n_out):
+    """ops.linear(relu=True) — FFN linear1 + activation in one launch, the ReLU mask applied inside the gradient
+    launches — vs relu(F.linear) in float64 (few-row kernels, and the separate fallback of the many-row path)."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(rows + n_out)
+    x = torch.randn(rows, n_in, generator=g)
+    W = torch.randn(n_out, n_in, generator=g) / np.sqrt(n_in)
+    b = torch.randn(n_out, generator=g) * 0.3
+    dy = torch.randn(rows, n_out, generator=g)
+    xr, Wr, br = (t.double().requires_grad_() for t in (x, W, b))
+    yr = torch.relu(torch.nn.functional.linear(xr, Wr, br))
+    yr.backward(dy.double())
+    xd, Wd, bd = (_dev(t, device).requires_grad_() for t in (x, W, b))
+    y = ops.linear(xd, Wd, bd, relu=True)
+    y.backward(_dev(dy, device))
+    assert rel_err(y.detach(), yr.detach()) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,c,relu,with_res", [(507, 256, True, True), (2222, 128, True, False), (1, 32, False, False),
+                                               (4000, 96, False, True)])
+def test_one_launch_batch_norm_for_small_maps(device, n, c, relu, with_res):
+    """usc_bn_forward_fused / usc_bn_backward_fused (statistics + normalise in one launch, <= 4096 rows) vs
+    BatchNorm1d(+residual)(+ReLU) in float64: output, saved statistics, running statistics, counter, dx, dres,
+    dgamma / dbeta (overwrite and accumulate)."""
+    from unscene3d_amd._lib import check, lib
+
+    g = torch.Generator().manual_seed(n + c)
+    x = torch.randn(n, c, generator=g) * 1.7 + 0.3
+    res = torch.randn(n, c, generator=g) if with_res else None
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
+    dout = torch.randn(n, c, generator=g)
+    eps, mom = 1e-5, 0.02
+    xr, gr, br = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    rr = res.double().requires_grad_() if with_res else None
+    m = xr.mean(0)
+    var = xr.var(0, unbiased=False)
+    yr = (xr - m) / torch.sqrt(var + eps) * gr + br
+    if with_res:
+        yr = yr + rr
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dout.double())
+
+    P = lambda t: None if t is None else t.data_ptr()
+    xd, resd, gd, bd, rmd, rvd, doutd = (None if t is None else _dev(t, device) for t in (x, res, gamma, beta, rm, rv, dout))
+    cnt = torch.zeros(1, dtype=torch.int64, device=device)
+    stats = torch.empty(4 * c, device=device)
+    y = torch.empty(n, c, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.usc_bn_forward_fused(P(xd), n, c, P(gd), P(bd), eps, mom, P(rmd), P(rvd), P(cnt), P(stats), P(stats) + 4 * c,
+                                   P(stats) + 8 * c, P(stats) + 12 * c, P(resd), int(relu), P(y), st), "fwd")
+    assert rel_err(y, yr.detach().float()) < 1e-5
+    assert rel_err(stats[:c], m.detach().float()) < 1e-5
+    assert rel_err(stats[c:2 * c], (1 / torch.sqrt(var + eps)).detach().float()) < 1e-5
+    assert int(cnt) == 1
+    unb = var.detach() * (n / max(n - 1, 1))
+    assert rel_err(rmd, ((1 - mom) * rm.double() + mom * m.detach()).float()) < 1e-5
+    assert rel_err(rvd, ((1 - mom) * rv.double() + mom * unb).float()) < 1e-5
+    dx, dres = torch.empty(n, c, device=device), torch.empty(n, c, device=device)
+    base = torch.randn(2, c, generator=g)
+    for acc in (0, 1):
+        dg, db = _dev(base[0].clone(), device), _dev(base[1].clone(), device)
+        check(lib.usc_bn_backward_fused(P(xd), P(doutd), P(y) if relu else None, P(stats), P(stats) + 4 * c, P(gd), n, c, 1,
+                                        acc, P(dg), P(db), P(dx), P(dres) if with_res else None, st), "bwd")
+        if n > 1:
+            assert rel_err(dx, xr.grad.float()) < 2e-5
+        assert rel_err(dg, (gr.grad + acc * base[0].double()).float()) < 2e-5
+        assert rel_err(db, (br.grad + acc * base[1].double()).float()) < 2e-5
+        if with_res:
+            assert rel_err(dres, rr.grad.float()) < 1e-5
+
+
+@pytest.mark.parametrize("rows,d", [(100, 128), (3, 64), (1500, 256)])
+def test_add_layer_norm_matches_torch(device, rows, d):
+    """ops.add_layer_norm(x, res) = LayerNorm(x + res) in one launch; both addends get the LayerNorm input gradient."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(rows * 3 + d)
+    x, r = torch.randn(rows, d, generator=g), torch.randn(rows, d, generator=g) * 0.5
+    w, b, dy = torch.randn(d, generator=g), torch.randn(d, generator=g), torch.randn(rows, d, generator=g)
+    xr, rr, wr, br = (t.double().requires_grad_() for t in (x, r, w, b))
+    yr = torch.nn.functional.layer_norm(xr + rr, (d,), wr, br, 1e-5)
+    yr.backward(dy.double())
+    xd, rd, wd, bd = (_dev(t, device).requires_grad_() for t in (x, r, w, b))
+    y = ops.add_layer_norm(xd.view(rows, 1, d), rd.view(rows, 1, d), wd, bd, 1e-5)
+    y.backward(_dev(dy, device).view(rows, 1, d))
+    assert rel_err(y.detach().view(rows, d), yr.detach()) < 1e-5
+    assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(rd.grad, rr.grad) < 1e-5
+    assert rel_err(wd.grad, wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("style,S", [("self", 100), ("cross", 800), ("cross", 3200)])
+def test_in_proj_with_positional_terms_and_shared_inputs(device, style, S):
+    """ops.in_proj(pos_q=, pos_k=): q = (xq + pos_q) Wq, k = (xk + pos_k) Wk, v = xv Wv with the adds inside the
+    projection launches and ONE summed gradient per distinct input (self attention: the same tensor three times and
+    the same positional term twice; cross attention: the memory twice) vs float64 autograd; few-row and many-row keys."""
+    from unscene3d_amd import ops
+
+    E, L = 128, 100
+    g = torch.Generator().manual_seed(S + len(style))
+    W = torch.randn(3 * E, E, generator=g) / np.sqrt(E)
+    b = torch.randn(3 * E, generator=g)
+    x = torch.randn(L, 1, E, generator=g)
+    mem = torch.randn(S, 1, E, generator=g)
+    pq, pk = torch.randn(L, 1, E, generator=g), torch.randn(S, 1, E, generator=g)
+    dq, dk, dv = (torch.randn(n, 1, E, generator=g) for n in ((L, L, L) if style == "self" else (L, S, S)))
+
+    def run(dt, dev):
+        Wt, bt, xt, mt, pqt, pkt = (t.to(dt).to(dev).requires_grad_() for t in (W, b, x, mem, pq, pk))
+        if dev == "cpu":
+            kin, vin, pkk = (xt, xt, pqt) if style == "self" else (mt, mt, pkt)
+            q = torch.nn.functional.linear(xt + pqt, Wt[:E], bt[:E])
+            k = torch.nn.functional.linear(kin + pkk, Wt[E:2 * E], bt[E:2 * E])
+            v = torch.nn.functional.linear(vin, Wt[2 * E:], bt[2 * E:])
+        elif style == "self":
+            q, k, v = ops.in_proj(xt, xt, xt, Wt, bt, pos_q=pqt, pos_k=pqt)
+        else:
+            q, k, v = ops.in_proj(xt, mt, mt, Wt, bt, pos_q=pqt, pos_k=pkt)
+        torch.autograd.backward([q, k, v], [t.to(dt).to(dev) for t in (dq, dk, dv)])
+        return [q.detach(), k.detach(), v.detach(), Wt.grad, bt.grad, xt.grad, pqt.grad] + \
+            ([] if style == "self" else [mt.grad, pkt.grad])
+
+    ref, got = run(torch.float64, "cpu"), run(torch.float32, device)
+    for a, r in zip(got, ref):
+        assert rel_err(a, r) < 1e-5
+
+
 @pytest.mark.parametrize("S,Q", [(609, 100), (300, 100), (1500, 64)])
 def test_mask_logits_with_padded_queries(device, S, Q):
     """models.mask3d._mask_logits (segment features x query embeddings, Q padded to a multiple of 32 for the row GEMM
@@ -967,14 +1098,18 @@ def test_triplane_projection_loss(device):
     assert float(exp_grad.abs().sum()) > 0 and rel_err(lg.grad, exp_grad) < 1e-4, rel_err(lg.grad, exp_grad)
 
 
-@pytest.mark.parametrize("level_embed,sample_sizes", [(False, "[20,50,100,200,800]"), (True, "[20,50,100,200,800]"),
-                                                      (False, "[200,800,3200,12800,51200]")])
-def test_decoder_graph_capture_equals_eager(device, level_embed, sample_sizes):
+@pytest.mark.parametrize("level_embed,sample_sizes,voxels", [(False, "[20,50,100,200,800]", 12000),
+                                                             (True, "[20,50,100,200,800]", 12000),
+                                                             (False, "[200,800,3200,12800,51200]", 12000),
+                                                             (False, "[200,800,3200,12800,51200]", 150000)])
+def test_decoder_graph_capture_equals_eager(device, level_embed, sample_sizes, voxels):
     """The HIP-graph captured decoder passes give the same loss and gradients as the eager path.
     (Two module instances with identical weights: capture must happen before the module's first backward.)
     With use_level_embed the embedding weight must receive its gradient from the captured passes too.
     Third case: the reference's own sample sizes on a 12 k-voxel scene — every level is SMALLER than its captured key
-    count, so the graphed module pads the keys (masked) up to it while the eager one attends over the level as is."""
+    count, so the graphed module pads the keys (masked) up to it while the eager one attends over the level as is.
+    Fourth case: the bench configuration itself (150 k voxels, 3 200 / 12 800 sampled keys per level: the many-row
+    projections inside the captured graphs)."""
     from unscene3d_amd.config import apply_overrides, default_config
     from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
     from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
@@ -982,7 +1117,7 @@ def test_decoder_graph_capture_equals_eager(device, level_embed, sample_sizes):
 
     cfg = apply_overrides(default_config(), ["general.num_targets=3", f"model.sample_sizes={sample_sizes}",
                                              f"model.use_level_embed={level_embed}"])
-    ds = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=12000, seed=3300)
+    ds = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=voxels, seed=3300)
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device))
     torch.manual_seed(3)
     eager = InstanceSegmentation(cfg).to(device).train()

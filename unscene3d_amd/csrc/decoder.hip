@@ -11,18 +11,28 @@ namespace {
 constexpr int kLnMaxPerLane = 8;    // d <= 512
 
 // one wave per row; lane l holds columns l, l + 64, ...
+// res (optional): the normalised row is x + res (post-norm residual, models/mask3d.py:523,543), written to sum_out
+// for the backward pass
 template <int PER>
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                           const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int64_t rows, int d, float eps,
-                                                           float* __restrict__ y, float* __restrict__ mean,
-                                                           float* __restrict__ rstd) {
+                                                           float* __restrict__ y, float* __restrict__ sum_out,
+                                                           float* __restrict__ mean, float* __restrict__ rstd) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   float v[PER];
   float s = 0.f;
 #pragma unroll
-  for (int j = 0; j < PER; ++j) { v[j] = x[r * d + lane + 64 * j]; s += v[j]; }
+  for (int j = 0; j < PER; ++j) {
+    v[j] = x[r * d + lane + 64 * j];
+    if (res) {
+      v[j] += res[r * d + lane + 64 * j];
+      sum_out[r * d + lane + 64 * j] = v[j];
+    }
+    s += v[j];
+  }
   const float mu = wave_reduce_addf(s) / (float)d;
   float q = 0.f;
 #pragma unroll
@@ -112,12 +122,17 @@ extern "C" {
 
 int usc_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, int32_t d, float eps, float* y,
                       float* mean, float* rstd, usc_stream_t s) {
+  return usc_add_layernorm_fwd(x, nullptr, gamma, beta, rows, d, eps, y, nullptr, mean, rstd, s);
+}
+
+int usc_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, int64_t rows, int32_t d,
+                          float eps, float* y, float* sum_out, float* mean, float* rstd, usc_stream_t s) {
   USC_REQUIRE(rows >= 0 && d >= 64 && d % 64 == 0 && d <= 64 * kLnMaxPerLane, "usc_layernorm_fwd: d must be a multiple of 64, <= 512");
   if (rows == 0) return USC_OK;
-  USC_REQUIRE(x && gamma && beta && y && mean && rstd, "usc_layernorm_fwd: null pointer");
+  USC_REQUIRE(x && gamma && beta && y && mean && rstd && (!res || sum_out), "usc_layernorm_fwd: null pointer");
   const dim3 grid((unsigned)ceil_div(rows, 4));
   hipStream_t st = as_stream(s);
-#define USC_LN_F(P) hipLaunchKernelGGL((layernorm_fwd_kernel<P>), grid, dim3(256), 0, st, x, gamma, beta, rows, (int)d, eps, y, mean, rstd)
+#define USC_LN_F(P) hipLaunchKernelGGL((layernorm_fwd_kernel<P>), grid, dim3(256), 0, st, x, res, gamma, beta, rows, (int)d, eps, y, sum_out, mean, rstd)
   switch (d / 64) {
     case 1: USC_LN_F(1); break;  case 2: USC_LN_F(2); break;  case 3: USC_LN_F(3); break;  case 4: USC_LN_F(4); break;
     case 6: USC_LN_F(6); break;  case 8: USC_LN_F(8); break;
@@ -175,7 +190,7 @@ __device__ inline int acc_row16(int reg, int half) { return (reg & 3) + 8 * (reg
 // summed through LDS in wave order (deterministic), each wave finalising four of the sixteen accumulator rows.
 __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int wave, int lane, float* __restrict__ out,
                                          int64_t ld, int row0, int col0, int max_row, const float* __restrict__ bias,
-                                         int accumulate = 0) {
+                                         int accumulate = 0, int relu = 0, const float* __restrict__ add = nullptr) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
@@ -187,20 +202,24 @@ __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int w
     const int row = row0 + acc_row16(r, h);
     if (row < max_row) {
       float* dst = out + (int64_t)row * ld + col0 + i;
-      *dst = v + (bias ? bias[col0 + i] : 0.f) + (accumulate ? *dst : 0.f);
+      float o = v + (bias ? bias[col0 + i] : 0.f) + (accumulate ? *dst : 0.f);
+      if (add) o += add[(int64_t)row * ld + col0 + i];
+      *dst = relu ? fmaxf(o, 0.f) : o;
     }
   }
 }
 
 // y[M,N] = x[M,K] W[N,K]^T (+ b)      grid (N/32, ceil(M/32)); K % 32 == 0
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                        const float* __restrict__ b, int M, int N, int K,
-                                                        float* __restrict__ y) {
+// x2 (optional): the input rows are x + x2 (positional encodings, models/mask3d.py:485,517); relu: y = max(y, 0)
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2,
+                                                        const float* __restrict__ W, const float* __restrict__ b, int M,
+                                                        int N, int K, int relu, float* __restrict__ y) {
   __shared__ float red[4][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int m = m0 + i;
   const float* xa = x + (int64_t)(m < M ? m : 0) * K + 4 * h;
+  const float* xa2 = x2 ? x2 + (int64_t)(m < M ? m : 0) * K + 4 * h : nullptr;
   const float* wb = W + (int64_t)(n0 + i) * K + 4 * h;
   const float keep = m < M ? 1.f : 0.f;
   f32x16 acc;
@@ -212,6 +231,13 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     float4 a[4], bb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { a[t] = *reinterpret_cast<const float4*>(xa + k0 + 8 * t); bb[t] = *reinterpret_cast<const float4*>(wb + k0 + 8 * t); }
+    if (xa2) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 e = *reinterpret_cast<const float4*>(xa2 + k0 + 8 * t);
+        a[t].x += e.x; a[t].y += e.y; a[t].z += e.z; a[t].w += e.w;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const float av[4] = {a[t].x * keep, a[t].y * keep, a[t].z * keep, a[t].w * keep};
@@ -220,17 +246,21 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
       for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[j], acc);
     }
   }
-  tile_reduce_store(acc, red, wave, lane, y, N, m0, n0, M, b);
+  tile_reduce_store(acc, red, wave, lane, y, N, m0, n0, M, b, 0, relu);
 }
 
 // dx[M,K] = dy[M,N] W[N,K]   for the 32x32 tile (c0, m0); N % 32 == 0.  The four waves split N; every wave keeps the
 // NEXT chunk's operands in flight while the matrix cores work on the current one (one wave per SIMD: nothing else
 // hides the ~1 us load latency, and with 8 chunks per wave for the 1024-wide FFN the loop was 8 dependent round trips).
-__device__ inline void linear_dx_tile(const float* __restrict__ dy, const float* __restrict__ W, int M, int N, int K,
-                                      float* __restrict__ dx, int c0, int m0, float (*red)[16][64]) {
+// ymask (optional): the layer's forward output after its fused ReLU — dy counts only where it is > 0;
+// dx_add (optional, [M,K]): added to the result (the other gradient path into the same input).
+__device__ inline void linear_dx_tile(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                      const float* __restrict__ W, int M, int N, int K, float* __restrict__ dx,
+                                      const float* __restrict__ dx_add, int c0, int m0, float (*red)[16][64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int m = m0 + i;
   const float* ya = dy + (int64_t)(m < M ? m : 0) * N + 4 * h;
+  const float* ym = ymask ? ymask + (int64_t)(m < M ? m : 0) * N + 4 * h : nullptr;
   const float* wb = W + (int64_t)(4 * h) * K + c0 + i;
   const float keep = m < M ? 1.f : 0.f;
   f32x16 acc;
@@ -243,6 +273,14 @@ __device__ inline void linear_dx_tile(const float* __restrict__ dy, const float*
     const int n0 = c * 32;
 #pragma unroll
     for (int t = 0; t < 4; ++t) aa[t] = *reinterpret_cast<const float4*>(ya + n0 + 8 * t);
+    if (ym) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 o = *reinterpret_cast<const float4*>(ym + n0 + 8 * t);
+        aa[t].x = o.x > 0.f ? aa[t].x : 0.f; aa[t].y = o.y > 0.f ? aa[t].y : 0.f;
+        aa[t].z = o.z > 0.f ? aa[t].z : 0.f; aa[t].w = o.w > 0.f ? aa[t].w : 0.f;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -263,11 +301,13 @@ __device__ inline void linear_dx_tile(const float* __restrict__ dy, const float*
       for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[4 * t + j], acc);
     }
   }
-  tile_reduce_store(acc, red, wave, lane, dx, K, m0, c0, M, nullptr);
+  tile_reduce_store(acc, red, wave, lane, dx, K, m0, c0, M, nullptr, 0, 0, dx_add);
 }
 
 // dW[N,K] = dy[M,N]^T x[M,K],  db[N] = sum_m dy[m][N]   for the tile (c0, n0); the tiles with c0 == 0 also write db
-__device__ inline void linear_dw_tile(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
+// ymask as above; x2 (optional): the layer's input rows were x + x2
+__device__ inline void linear_dw_tile(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                      const float* __restrict__ x, const float* __restrict__ x2, int M, int N, int K,
                                       int accumulate, float* __restrict__ dW, float* __restrict__ db, int c0, int n0,
                                       float (*red)[16][64], float (*bred)[32]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
@@ -283,8 +323,12 @@ __device__ inline void linear_dw_tile(const float* __restrict__ dy, const float*
       for (int j = 0; j < 4; ++j) {
         const int m = mb + 8 * t + 4 * h + j;
         const bool ok = m < M;
-        av[4 * t + j] = ok ? dy[(int64_t)m * N + n0 + i] : 0.f;
-        bv[4 * t + j] = ok ? x[(int64_t)m * K + c0 + i] : 0.f;
+        float g = ok ? dy[(int64_t)m * N + n0 + i] : 0.f;
+        if (ymask && ok && !(ymask[(int64_t)m * N + n0 + i] > 0.f)) g = 0.f;
+        av[4 * t + j] = g;
+        float xv = ok ? x[(int64_t)m * K + c0 + i] : 0.f;
+        if (x2 && ok) xv += x2[(int64_t)m * K + c0 + i];
+        bv[4 * t + j] = xv;
       }
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc = MFMA32(av[q], bv[q], acc); bsum += av[q]; }
@@ -304,49 +348,69 @@ __device__ inline void linear_dw_tile(const float* __restrict__ dy, const float*
 // Both gradients of a few-row linear layer in ONE launch: workgroups [0, dx_tiles) take the input-gradient tiles,
 // the rest the weight-gradient tiles (they are independent; as two launches the pair cost 9.4 + 4.5 us of a
 // latency-bound decoder pass, ~150 pairs per training step).
-__global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
+                                                        const float* __restrict__ x, const float* __restrict__ x2,
                                                         const float* __restrict__ W, int M, int N, int K, int dx_tiles,
-                                                        int accumulate, float* __restrict__ dx, float* __restrict__ dW,
+                                                        int accumulate, float* __restrict__ dx,
+                                                        const float* __restrict__ dx_add, float* __restrict__ dW,
                                                         float* __restrict__ db) {
   __shared__ float red[4][16][64];
   __shared__ float bred[4][32];
   const int kt = K / 32;
   int b = blockIdx.x;
   if (b < dx_tiles) {
-    linear_dx_tile(dy, W, M, N, K, dx, (b % kt) * 32, (b / kt) * 32, red);
+    linear_dx_tile(dy, ymask, W, M, N, K, dx, dx_add, (b % kt) * 32, (b / kt) * 32, red);
   } else {
     b -= dx_tiles;
-    linear_dw_tile(dy, x, M, N, K, accumulate, dW, db, (b % kt) * 32, (b / kt) * 32, red, bred);
+    linear_dw_tile(dy, ymask, x, x2, M, N, K, accumulate, dW, db, (b % kt) * 32, (b / kt) * 32, red, bred);
   }
 }
 
 
 // Column sums of a many-row table (the bias gradient of a linear layer over 3 200 / 12 800 sampled voxels), in a fixed
-// order: 256-row partial sums, then one thread per column adds the partials ascending.  No atomics, no
+// order: 64-row partial sums, then per column 16 lanes add the partials ascending and their sums are added ascending.  No atomics, no
 // last-block semaphores: the same bits on every launch and inside captured graphs.
-constexpr int kColSumRows = 256;
+constexpr int kColSumRows = 64;
 __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, int64_t n, int c,
                                                              float* __restrict__ partial) {
+  // 64 columns x 4 row lanes; a lane adds its 16 rows in four independent chains (rows r, r+16, r+32, r+48 of the
+  // block), combined in a fixed order
   __shared__ float red[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int col = blockIdx.y * 64 + tx;
   const int64_t r0 = (int64_t)blockIdx.x * kColSumRows;
-  const int64_t r1 = r0 + kColSumRows < n ? r0 + kColSumRows : n;
-  float s = 0.f;
-  if (col < c)
-    for (int64_t r = r0 + ty; r < r1; r += 4) s += x[r * c + col];
-  red[ty][tx] = s;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col < c) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = r0 + 16 * u + 4 * q + ty;
+        if (r < n) a[u] += x[r * c + col];
+      }
+  }
+  red[ty][tx] = (a[0] + a[1]) + (a[2] + a[3]);
   __syncthreads();
   if (ty == 0 && col < c) partial[(int64_t)blockIdx.x * c + col] = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
 }
 
-__global__ __launch_bounds__(64) void col_sum_final_kernel(const float* __restrict__ partial, int64_t parts, int c,
-                                                          int accumulate, float* __restrict__ out) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col >= c) return;
+__global__ __launch_bounds__(256) void col_sum_final_kernel(const float* __restrict__ partial, int64_t parts, int c,
+                                                           int accumulate, float* __restrict__ out) {
+  // 16 columns x 16 lanes; lane l adds partials l, l+16, ... ascending, then the 16 lane sums ascending
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + tx;
   float s = 0.f;
-  for (int64_t p = 0; p < parts; ++p) s += partial[p * c + col];
-  out[col] = accumulate ? out[col] + s : s;
+  if (col < c)
+    for (int64_t p = ty; p < parts; p += 16) s += partial[p * c + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) t += red[l][tx];
+    out[col] = accumulate ? out[col] + t : t;
+  }
 }
 
 }  // namespace
@@ -356,24 +420,35 @@ extern "C" {
 
 int usc_linear_fwd(const float* x, const float* W, const float* b, int32_t M, int32_t N, int32_t K, float* y,
                    usc_stream_t s) {
+  return usc_linear_fwd_ex(x, nullptr, W, b, M, N, K, 0, y, s);
+}
+
+int usc_linear_fwd_ex(const float* x, const float* x2, const float* W, const float* b, int32_t M, int32_t N, int32_t K,
+                      int32_t relu, float* y, usc_stream_t s) {
   USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_fwd: N, K must be multiples of 32");
   USC_REQUIRE(x && W && y, "usc_linear_fwd: null pointer");
-  hipLaunchKernelGGL(usc::linear_fwd_kernel, dim3(N / 32, (M + 31) / 32), dim3(256), 0, usc::as_stream(s), x, W, b, (int)M,
-                     (int)N, (int)K, y);
+  hipLaunchKernelGGL(usc::linear_fwd_kernel, dim3(N / 32, (M + 31) / 32), dim3(256), 0, usc::as_stream(s), x, x2, W, b,
+                     (int)M, (int)N, (int)K, (int)relu, y);
   USC_CHECK_LAUNCH("usc_linear_fwd");
   return USC_OK;
 }
 
 int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M, int32_t N, int32_t K, float* dx, float* dW,
                    float* db, int32_t accumulate, usc_stream_t s) {
+  return usc_linear_bwd_ex(dy, nullptr, x, nullptr, W, M, N, K, dx, nullptr, dW, db, accumulate, s);
+}
+
+int usc_linear_bwd_ex(const float* dy, const float* y_relu, const float* x, const float* x2, const float* W, int32_t M,
+                      int32_t N, int32_t K, float* dx, const float* dx_add, float* dW, float* db, int32_t accumulate,
+                      usc_stream_t s) {
   USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_bwd: N, K must be multiples of 32");
   USC_REQUIRE(dy && x && W, "usc_linear_bwd: null pointer");
   hipStream_t st = usc::as_stream(s);
   const int dx_tiles = dx ? (K / 32) * ((M + 31) / 32) : 0;
   const int dw_tiles = dW ? (K / 32) * (N / 32) : 0;
   if (dx_tiles + dw_tiles > 0)
-    hipLaunchKernelGGL(usc::linear_bwd_kernel, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, x, W, (int)M, (int)N, (int)K,
-                       dx_tiles, (int)accumulate, dx, dW, db);
+    hipLaunchKernelGGL(usc::linear_bwd_kernel, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, y_relu, x, x2, W, (int)M,
+                       (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dW, db);
   USC_CHECK_LAUNCH("usc_linear_bwd");
   return USC_OK;
 }
@@ -393,8 +468,8 @@ int usc_col_sum(const float* x, int64_t n, int32_t c, float* out, int32_t accumu
   const unsigned cg = (unsigned)((c + 63) / 64);
   if (parts > 0)
     hipLaunchKernelGGL(usc::col_sum_partial_kernel, dim3((unsigned)parts, cg), dim3(256), 0, st, x, n, (int)c, (float*)ws);
-  hipLaunchKernelGGL(usc::col_sum_final_kernel, dim3(cg), dim3(64), 0, st, (const float*)ws, parts, (int)c, (int)accumulate,
-                     out);
+  hipLaunchKernelGGL(usc::col_sum_final_kernel, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, st, (const float*)ws, parts,
+                     (int)c, (int)accumulate, out);
   USC_CHECK_LAUNCH("usc_col_sum");
   return USC_OK;
 }

@@ -329,7 +329,11 @@ class Mask3D(nn.Module):
     def mask_module(self, query_feat, mask_features, mask_segments, num_pooling_steps, ret_attn_mask=True,
                     point2segment=None, coords=None, defer_class=False):
         query_feat = self.decoder_norm(query_feat)
-        mask_embed = self.mask_embed_head(query_feat)
+        head = self.mask_embed_head
+        if query_feat.is_cuda and query_feat.dtype == torch.float32:      # Linear + ReLU in one launch
+            mask_embed = head[2](ops.linear(query_feat, head[0].weight, head[0].bias, relu=True))
+        else:
+            mask_embed = head(query_feat)
         # defer_class: hand back the normalised queries; forward() runs the class head ONCE over all 13 calls' queries
         # (row-wise linear: same numbers; 12 fewer head launches and 24 fewer gradient accumulations per step)
         outputs_class = query_feat if defer_class else self.class_embed_head(query_feat)
@@ -406,15 +410,17 @@ def _mask_logits(feats, mask_embed):
     return out[:, :Q] if pad else out
 
 
-def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None, mask_bsl=None):
-    """nn.MultiheadAttention.forward(query, key, value, attn_mask=…, need_weights=False)[0] for the
+def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None, mask_bsl=None, pos_q=None,
+                        pos_k=None):
+    """nn.MultiheadAttention.forward(query + pos_q, key + pos_k, value, attn_mask=…, need_weights=False)[0] for the
     sequence-first layout, dropout 0 and a boolean mask (True = masked), with the input / output projections
-    through ops.in_proj / ops.linear (same parameters, same state_dict)."""
+    through ops.in_proj / ops.linear (same parameters, same state_dict); the positional adds of the reference
+    (`with_pos_embed`, :485 / :517) happen inside the projection launches."""
     L, B, E = query.shape
     S = key.shape[0]
     H = mha.num_heads
     hd = E // H
-    q, k, v = ops.in_proj(query, key, value, mha.in_proj_weight, mha.in_proj_bias)
+    q, k, v = ops.in_proj(query, key, value, mha.in_proj_weight, mha.in_proj_bias, pos_q=pos_q, pos_k=pos_k)
     if mask_bsl is not None and hd == 16 and L <= 128:
         # `mask_bsl` = the decoder's bool[B, S, L] mask (same for every head): fused HIP kernels, no score tensor
         out = ops.masked_cross_attention(q, k, v, mask_bsl, H)
@@ -489,6 +495,19 @@ def _col_minmax(x):
     return mn, mx
 
 
+def _residual_norm(layer, tgt, upd):
+    """tgt + dropout(upd), then the layer's post-norm (reference :493-494, :523-524, :543-544); with dropout 0 on the
+    device the add and the LayerNorm are one launch."""
+    norm = layer.norm
+    if (not layer.normalize_before and (layer.dropout.p == 0.0 or not layer.training) and tgt.is_cuda and tgt.dtype == torch.float32
+            and isinstance(norm, LayerNorm) and norm.elementwise_affine and norm.bias is not None
+            and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] in ops._LN_DIMS
+            and tgt.shape == upd.shape):
+        return ops.add_layer_norm(tgt, upd, norm.weight, norm.bias, norm.eps)
+    out = tgt + layer.dropout(upd)
+    return out if layer.normalize_before else norm(out)
+
+
 def _with_pos(t, pos):
     return t if pos is None else t + pos
 
@@ -513,16 +532,16 @@ class SelfAttentionLayer(nn.Module):
 
     def forward(self, tgt, tgt_mask=None, tgt_key_padding_mask=None, query_pos=None):
         src = self.norm(tgt) if self.normalize_before else tgt
-        q = k = _with_pos(src, query_pos)
         # need_weights=False: same output; skips materialising/averaging the [B,Q,K] attention weights the
         # reference computes and discards (`[0]`), and lets PyTorch take its fused SDPA path
-        if tgt_key_padding_mask is None and self.self_attn.dropout == 0.0 and q.is_cuda:
-            upd = multihead_attention(self.self_attn, q, k, src, attn_mask=tgt_mask)
+        if tgt_key_padding_mask is None and self.self_attn.dropout == 0.0 and src.is_cuda:
+            upd = multihead_attention(self.self_attn, src, src, src, attn_mask=tgt_mask, pos_q=query_pos,
+                                      pos_k=query_pos)
         else:
+            q = k = _with_pos(src, query_pos)
             upd = self.self_attn(q, k, value=src, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask,
                                  need_weights=False)[0]
-        out = tgt + self.dropout(upd)
-        return out if self.normalize_before else self.norm(out)
+        return _residual_norm(self, tgt, upd)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -545,14 +564,13 @@ class CrossAttentionLayer(nn.Module):
         if memory_mask is None and memory_mask_bsl is not None and not src.is_cuda:
             memory_mask = memory_mask_bsl.repeat_interleave(self.multihead_attn.num_heads, dim=0).permute(0, 2, 1)
         if memory_key_padding_mask is None and self.multihead_attn.dropout == 0.0 and src.is_cuda:
-            upd = multihead_attention(self.multihead_attn, _with_pos(src, query_pos), _with_pos(memory, pos), memory,
-                                      attn_mask=memory_mask, mask_bsl=memory_mask_bsl)
+            upd = multihead_attention(self.multihead_attn, src, memory, memory, attn_mask=memory_mask,
+                                      mask_bsl=memory_mask_bsl, pos_q=query_pos, pos_k=pos)
         else:
             upd = self.multihead_attn(query=_with_pos(src, query_pos), key=_with_pos(memory, pos), value=memory,
                                       attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask,
                                       need_weights=False)[0]
-        out = tgt + self.dropout(upd)
-        return out if self.normalize_before else self.norm(out)
+        return _residual_norm(self, tgt, upd)
 
 
 class FFNLayer(nn.Module):
@@ -570,9 +588,12 @@ class FFNLayer(nn.Module):
 
     def forward(self, tgt):
         src = self.norm(tgt) if self.normalize_before else tgt
-        upd = self.linear2(self.dropout(self.activation(self.linear1(src))))
-        out = tgt + self.dropout(upd)
-        return out if self.normalize_before else self.norm(out)
+        if src.is_cuda and src.dtype == torch.float32 and self.activation is F.relu and (self.dropout.p == 0.0
+                                                                                          or not self.training):
+            hidden = ops.linear(src, self.linear1.weight, self.linear1.bias, relu=True)   # ReLU in the same launch
+        else:
+            hidden = self.dropout(self.activation(self.linear1(src)))
+        return _residual_norm(self, tgt, self.linear2(hidden))
 
 
 def _get_activation_fn(activation):

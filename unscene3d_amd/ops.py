@@ -788,6 +788,40 @@ class _LayerNorm(torch.autograd.Function):
         return dx.view(ctx.shape), dgamma, dbeta, None
 
 
+class _AddLayerNorm(torch.autograd.Function):
+    """LayerNorm(x + res) in one launch; both addends receive the same input gradient (no extra kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        d = x.shape[-1]
+        x2 = x.contiguous().view(-1, d)
+        r2 = res.contiguous().view(-1, d)
+        rows = x2.shape[0]
+        y, ssum = torch.empty_like(x2), torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(lib.usc_add_layernorm_fwd(_ptr(x2), _ptr(r2), _ptr(weight), _ptr(bias), rows, d, float(eps), _ptr(y),
+                                        _ptr(ssum), _ptr(mean), _ptr(rstd), _stream()), "usc_add_layernorm_fwd")
+        ctx.save_for_backward(ssum, weight, mean, rstd)
+        ctx.shape = x.shape
+        ctx.w_param, ctx.b_param = weight, bias
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, dgamma, dbeta, _ = _LayerNorm.backward(ctx, dy)
+        return dx, dx, dgamma, dbeta, None
+
+
+def add_layer_norm(x, res, weight, bias, eps=1e-5):
+    """F.layer_norm(x + res) (the post-norm residual of the decoder layers, reference models/mask3d.py:523-524)."""
+    _chk(weight, torch.float32, "weight")
+    _chk(bias, torch.float32, "bias")
+    if x.dtype != torch.float32 or not x.is_cuda or x.shape[-1] not in _LN_DIMS or x.shape != res.shape:
+        raise RuntimeError(f"add_layer_norm: needs two equal-shape f32 HIP tensors with last dim in {sorted(_LN_DIMS)}")
+    return _AddLayerNorm.apply(x, res, weight, bias, eps)
+
+
 def layer_norm(x, weight, bias, eps=1e-5):
     """F.layer_norm over the last dimension through the HIP kernels (f32, contiguous weight/bias, d in _LN_DIMS)."""
     _chk(weight, torch.float32, "weight")
@@ -812,14 +846,20 @@ def _rows_gemm_ok(rows, n_in, n_out):
     return rows > SMALL_ROWS and n_in % 32 == 0 and n_out % 32 == 0
 
 
-def _lin_fwd(x2, W, b):
-    """y = x2 W^T + b for contiguous f32 x2 [M,K], W [N,K] (a contiguous row block is fine)."""
+def _lin_fwd(x2, W, b, add=None, relu=False):
+    """y = (x2 [+ add]) W^T + b [then ReLU] for contiguous f32 x2 [M,K], W [N,K] (a contiguous row block is fine);
+    `add` / `relu` are folded into the launch on the few-row kernels and applied separately elsewhere."""
     M, K = x2.shape
     N = W.shape[0]
     if _small_linear_ok(M, K, N):
         y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
-        check(lib.usc_linear_fwd(_ptr(x2), _ptr(W), _ptr(b), M, N, K, _ptr(y), _stream()), "usc_linear_fwd")
+        check(lib.usc_linear_fwd_ex(_ptr(x2), _ptr(add), _ptr(W), _ptr(b), M, N, K, int(relu), _ptr(y), _stream()),
+              "usc_linear_fwd")
         return y
+    if add is not None:
+        x2 = x2 + add
+    if relu:
+        return torch.relu_(_lin_fwd(x2, W, b))
     if _rows_gemm_ok(M, K, N) and W.is_contiguous():
         Wt = weight_transpose(W.view(1, N, K), mirror=False)          # [1, K, N]: the conv kernels' [cin, cout]
         return gather_gemm(x2, Wt, None, M, bias=b)
@@ -840,15 +880,24 @@ def col_sum(x2, out, accumulate=False):
     return out
 
 
-def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False):
-    """-> dx (or None); writes (accumulate: adds) dW_out [N,K] and db_out [N] (row-block views are fine)."""
+def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False, add=None, y_relu=None, dx_add=None):
+    """-> dx (or None); writes (accumulate: adds) dW_out [N,K] and db_out [N] (row-block views are fine).
+    add: the layer's input was x2 + add; y_relu: its output after the fused ReLU; dx_add: added to dx."""
     M, N = dy2.shape
     K = x2.shape[1]
     if _small_linear_ok(M, K, N):
         dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device) if need_dx else None
-        check(lib.usc_linear_bwd(_ptr(dy2), _ptr(x2), _ptr(W), M, N, K, _ptr(dx), _ptr(dW_out), _ptr(db_out),
-                                 int(accumulate), _stream()), "usc_linear_bwd")
+        check(lib.usc_linear_bwd_ex(_ptr(dy2), _ptr(y_relu), _ptr(x2), _ptr(add), _ptr(W), M, N, K, _ptr(dx),
+                                    _ptr(dx_add) if need_dx else None, _ptr(dW_out), _ptr(db_out), int(accumulate),
+                                    _stream()), "usc_linear_bwd")
         return dx
+    if y_relu is not None:
+        dy2 = dy2 * (y_relu > 0)
+    if add is not None:
+        x2 = x2 + add
+    if dx_add is not None:
+        dx = _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx, accumulate)
+        return None if dx is None else dx.add_(dx_add)
     rows_ok = _rows_gemm_ok(M, K, N) and W.is_contiguous()
     if rows_ok and dW_out.is_contiguous():
         # dW[N,K] = dy^T x over many rows: the weight-gradient kernel with identity pairs (a = dy, b = x)
@@ -871,16 +920,17 @@ def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False):
 
 class _LinearRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, relu=False):
         x2 = x.contiguous().view(-1, x.shape[-1])
-        ctx.save_for_backward(x2, W)
+        y = _lin_fwd(x2, W, b, relu=relu)
+        ctx.save_for_backward(x2, W, y if relu else None)
         ctx.has_bias, ctx.shape = b is not None, x.shape
         ctx.w_param, ctx.b_param = W, b
-        return _lin_fwd(x2, W, b).view(*x.shape[:-1], W.shape[0])
+        return y.view(*x.shape[:-1], W.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
-        x2, W = ctx.saved_tensors
+        x2, W, y_relu = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
         tw = _grad_target(ctx.w_param)
         tb = _grad_target(ctx.b_param) if ctx.has_bias else None
@@ -890,38 +940,52 @@ class _LinearRows(torch.autograd.Function):
         else:
             dW = torch.empty_like(W)
             db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_bias else None
-        dx = _lin_bwd(dy2, x2, W, dW, db, need_dx=ctx.needs_input_grad[0], accumulate=in_place)
+        dx = _lin_bwd(dy2, x2, W, dW, db, need_dx=ctx.needs_input_grad[0], accumulate=in_place, y_relu=y_relu)
         if in_place:
             dW = db = None
             _grad_written(ctx.w_param, ctx.b_param if ctx.has_bias else None)
-        return (None if dx is None else dx.view(ctx.shape)), dW, db
+        return (None if dx is None else dx.view(ctx.shape)), dW, db, None
 
 
-def linear(x, W, b=None):
-    """F.linear(x, W, b) for f32 HIP tensors; few-row inputs run on the wave-per-tile MFMA kernels of decoder.hip."""
+def linear(x, W, b=None, relu=False):
+    """F.linear(x, W, b) (relu: followed by ReLU, in the same launch on the few-row kernels) for f32 HIP tensors;
+    few-row inputs run on the wave-per-tile MFMA kernels of decoder.hip."""
     _chk(W, torch.float32, "W")
-    return _LinearRows.apply(x, W, b)
+    return _LinearRows.apply(x, W, b, relu)
 
 
 class _InProj(torch.autograd.Function):
     """q, k, v = the three input projections of nn.MultiheadAttention from its packed in_proj_weight [3E,E] /
     in_proj_bias [3E] (reference: nn.MultiheadAttention inside models/mask3d.py:491-605).  One Function so that the
-    three weight gradients are written into ONE [3E,E] tensor instead of three sliced ones summed by autograd."""
+    three weight gradients are written into ONE [3E,E] tensor instead of three sliced ones summed by autograd.
+    pos_q / pos_k (optional): q = (xq + pos_q) Wq, k = (xk + pos_k) Wk — the `with_pos_embed` adds of the reference
+    (:485, :517) folded into the projection launches.  Inputs that are the SAME tensor (self attention: xq, xk, xv;
+    cross attention: xk, xv) get one summed gradient, chained through the input-gradient launches (dx_add) instead of
+    separate tensors added by autograd."""
 
     @staticmethod
-    def forward(ctx, xq, xk, xv, W, b):
+    def forward(ctx, xq, xk, xv, W, b, pos_q, pos_k):
         E = W.shape[1]
         xs = [t.contiguous().view(-1, E) for t in (xq, xk, xv)]
-        outs = [_lin_fwd(xs[j], W[j * E:(j + 1) * E], b[j * E:(j + 1) * E]) for j in range(3)]
-        ctx.save_for_backward(xs[0], xs[1], xs[2], W)
+        ps = [None if t is None else t.contiguous().view(-1, E) for t in (pos_q, pos_k, None)]
+        for j in range(2):     # many-row inputs (the sampled voxels): no fused add on those kernels, keep the sum
+            if ps[j] is not None and not _small_linear_ok(xs[j].shape[0], E, E):
+                xs[j], ps[j] = xs[j] + ps[j], None
+        outs = [_lin_fwd(xs[j], W[j * E:(j + 1) * E], b[j * E:(j + 1) * E], add=ps[j]) for j in range(3)]
+        ctx.save_for_backward(xs[0], xs[1], xs[2], W, ps[0], ps[1])
         ctx.shapes = (xq.shape, xk.shape, xv.shape)
+        ctx.pos_shapes = (None if pos_q is None else pos_q.shape, None if pos_k is None else pos_k.shape)
         ctx.w_param, ctx.b_param = W, b
-        ctx.same_qk = xq.data_ptr() == xk.data_ptr() and xq.shape == xk.shape
+
+        def same(a, c):
+            return a is not None and c is not None and a.data_ptr() == c.data_ptr() and a.shape == c.shape \
+                and a.stride() == c.stride()
+        ctx.same_qk, ctx.same_kv, ctx.same_pos = same(xq, xk), same(xk, xv), same(pos_q, pos_k)
         return tuple(o.view(*shp[:-1], E) for o, shp in zip(outs, ctx.shapes))
 
     @staticmethod
     def backward(ctx, dq, dk, dv):
-        x0, x1, x2, W = ctx.saved_tensors
+        x0, x1, x2, W, p0, p1 = ctx.saved_tensors
         E = W.shape[1]
         tw, tb = _grad_target(ctx.w_param), _grad_target(ctx.b_param)
         in_place = tw is not None and tb is not None
@@ -930,21 +994,43 @@ class _InProj(torch.autograd.Function):
         else:
             dW = torch.empty_like(W)
             db = torch.empty(3 * E, dtype=torch.float32, device=W.device)
-        dxs = []
-        for j, (dyj, xj) in enumerate(zip((dq, dk, dv), (x0, x1, x2))):
-            dy2 = dyj.contiguous().view(-1, E)
-            dxs.append(_lin_bwd(dy2, xj, W[j * E:(j + 1) * E], dW[j * E:(j + 1) * E], db[j * E:(j + 1) * E],
-                                need_dx=ctx.needs_input_grad[j], accumulate=in_place))
+        need = list(ctx.needs_input_grad[:3])
+        need_pq, need_pk = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
+
+        def bwd(j, dyj, xj, pj, need_dx, dx_add=None):
+            return _lin_bwd(dyj.contiguous().view(-1, E), xj, W[j * E:(j + 1) * E], dW[j * E:(j + 1) * E],
+                            db[j * E:(j + 1) * E], need_dx=need_dx, accumulate=in_place, add=pj, dx_add=dx_add)
+
+        # k first, then q on top of it when they share the input (and the positional term); v last on top of both
+        # when it shares the input too: one summed tensor per distinct input
+        gk = bwd(1, dk, x1, p1, need[1] or need_pk)
+        chain_q = ctx.same_qk and gk is not None and (p0 is None or ctx.same_pos)
+        gq = bwd(0, dq, x0, p0, need[0] or need_pq, dx_add=gk if chain_q else None)
+        if chain_q:                       # gq = d(xq + pos) summed over the q and k paths
+            gx, gpos = gq, gq
+            gv = bwd(2, dv, x2, None, need[2], dx_add=gx if ctx.same_kv else None)
+            if ctx.same_kv:
+                out_x = (gv, None, None)
+            else:
+                out_x = (gx, None, gv)
+            out_p = (gpos if need_pq else None, None)
+        else:
+            chain_v = ctx.same_kv and gk is not None
+            gv = bwd(2, dv, x2, None, need[2], dx_add=gk if chain_v else None)
+            out_x = (gq, gv, None) if chain_v else (gq, gk, gv)
+            out_p = (gq if need_pq else None, gk if need_pk else None)
         if in_place:
             dW = db = None
             _grad_written(ctx.w_param, ctx.b_param)
-        return tuple(None if d is None else d.view(shp) for d, shp in zip(dxs, ctx.shapes)) + (dW, db)
+        gx = tuple(None if (g is None or not n) else g.view(shp) for g, n, shp in zip(out_x, need, ctx.shapes))
+        gp = tuple(None if g is None else g.view(shp) for g, shp in zip(out_p, ctx.pos_shapes))
+        return gx + (dW, db) + gp
 
 
-def in_proj(xq, xk, xv, W, b):
+def in_proj(xq, xk, xv, W, b, pos_q=None, pos_k=None):
     _chk(W, torch.float32, "in_proj_weight")
     _chk(b, torch.float32, "in_proj_bias")
-    return _InProj.apply(xq, xk, xv, W, b)
+    return _InProj.apply(xq, xk, xv, W, b, pos_q, pos_k)
 
 
 class _MaskedCrossAttention(torch.autograd.Function):
