@@ -341,24 +341,6 @@ int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamm
                          float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean,
                          float* invstd, float* scale, float* shift, void* ws,
                          int64_t ws_bytes, usc_stream_t s);
-/* Small maps (n <= usc_bn_fused_max_rows(), c % 8 == 0): usc_bn_forward_stats +
- * usc_bn_apply in ONE launch, and usc_bn_backward_reduce + usc_bn_backward_dx in
- * one — the 507 ... 2 222-row levels of Res16UNet34C, where each launch is a
- * round trip with the chip idle.  Same formulas; the f64 column sums are
- * associated differently (128 row lanes, fixed order).  gamma is read 4 bytes
- * at a time (parameter views need no 16-byte alignment). */
-int64_t usc_bn_fused_max_rows(void);
-int usc_bn_forward_fused(const float* x, int64_t n, int32_t c, const float* gamma,
-                         const float* beta, float eps, float momentum,
-                         float* running_mean, float* running_var,
-                         int64_t* num_batches_tracked, float* mean, float* invstd,
-                         float* scale, float* shift, const float* residual,
-                         int32_t relu, float* y, usc_stream_t s);
-int usc_bn_backward_fused(const float* x, const float* dy, const float* y_out,
-                          const float* mean, const float* invstd,
-                          const float* gamma, int64_t n, int32_t c,
-                          int32_t training, int32_t accumulate, float* dgamma,
-                          float* dbeta, float* dx, float* dres, usc_stream_t s);
 /* y = [relu]( x*scale[c] + shift[c] (+ residual) ); mask-free (backward uses y>0). */
 int usc_bn_apply(const float* x, const float* scale, const float* shift,
                  const float* residual, int32_t relu, float* y, int64_t n,

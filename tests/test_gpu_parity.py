@@ -746,61 +746,6 @@ def test_linear_with_fused_relu(device, rows, n_in, n_out):
     assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
 
 
-@pytest.mark.parametrize("n,c,relu,with_res", [(507, 256, True, True), (2222, 128, True, False), (1, 32, False, False),
-                                               (4000, 96, False, True)])
-def test_one_launch_batch_norm_for_small_maps(device, n, c, relu, with_res):
-    """usc_bn_forward_fused / usc_bn_backward_fused (statistics + normalise in one launch, <= 4096 rows) vs
-    BatchNorm1d(+residual)(+ReLU) in float64: output, saved statistics, running statistics, counter, dx, dres,
-    dgamma / dbeta (overwrite and accumulate)."""
-    from unscene3d_amd._lib import check, lib
-
-    g = torch.Generator().manual_seed(n + c)
-    x = torch.randn(n, c, generator=g) * 1.7 + 0.3
-    res = torch.randn(n, c, generator=g) if with_res else None
-    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
-    rm, rv = torch.randn(c, generator=g), torch.rand(c, generator=g) + 0.5
-    dout = torch.randn(n, c, generator=g)
-    eps, mom = 1e-5, 0.02
-    xr, gr, br = x.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
-    rr = res.double().requires_grad_() if with_res else None
-    m = xr.mean(0)
-    var = xr.var(0, unbiased=False)
-    yr = (xr - m) / torch.sqrt(var + eps) * gr + br
-    if with_res:
-        yr = yr + rr
-    if relu:
-        yr = torch.relu(yr)
-    yr.backward(dout.double())
-
-    P = lambda t: None if t is None else t.data_ptr()
-    xd, resd, gd, bd, rmd, rvd, doutd = (None if t is None else _dev(t, device) for t in (x, res, gamma, beta, rm, rv, dout))
-    cnt = torch.zeros(1, dtype=torch.int64, device=device)
-    stats = torch.empty(4 * c, device=device)
-    y = torch.empty(n, c, device=device)
-    st = torch.cuda.current_stream().cuda_stream
-    check(lib.usc_bn_forward_fused(P(xd), n, c, P(gd), P(bd), eps, mom, P(rmd), P(rvd), P(cnt), P(stats), P(stats) + 4 * c,
-                                   P(stats) + 8 * c, P(stats) + 12 * c, P(resd), int(relu), P(y), st), "fwd")
-    assert rel_err(y, yr.detach().float()) < 1e-5
-    assert rel_err(stats[:c], m.detach().float()) < 1e-5
-    assert rel_err(stats[c:2 * c], (1 / torch.sqrt(var + eps)).detach().float()) < 1e-5
-    assert int(cnt) == 1
-    unb = var.detach() * (n / max(n - 1, 1))
-    assert rel_err(rmd, ((1 - mom) * rm.double() + mom * m.detach()).float()) < 1e-5
-    assert rel_err(rvd, ((1 - mom) * rv.double() + mom * unb).float()) < 1e-5
-    dx, dres = torch.empty(n, c, device=device), torch.empty(n, c, device=device)
-    base = torch.randn(2, c, generator=g)
-    for acc in (0, 1):
-        dg, db = _dev(base[0].clone(), device), _dev(base[1].clone(), device)
-        check(lib.usc_bn_backward_fused(P(xd), P(doutd), P(y) if relu else None, P(stats), P(stats) + 4 * c, P(gd), n, c, 1,
-                                        acc, P(dg), P(db), P(dx), P(dres) if with_res else None, st), "bwd")
-        if n > 1:
-            assert rel_err(dx, xr.grad.float()) < 2e-5
-        assert rel_err(dg, (gr.grad + acc * base[0].double()).float()) < 2e-5
-        assert rel_err(db, (br.grad + acc * base[1].double()).float()) < 2e-5
-        if with_res:
-            assert rel_err(dres, rr.grad.float()) < 1e-5
-
-
 @pytest.mark.parametrize("rows,d", [(100, 128), (3, 64), (1500, 256)])
 def test_add_layer_norm_matches_torch(device, rows, d):
     """ops.add_layer_norm(x, res) = LayerNorm(x + res) in one launch; both addends get the LayerNorm input gradient."""

@@ -83,9 +83,6 @@ SIGNATURES = {
     "usc_bn_forward_stats": (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
     "usc_relu_fwd": (C.c_int, [_p, _p, _i64, _p]),
     "usc_relu_bwd": (C.c_int, [_p, _p, _p, _i64, _p]),
-    "usc_bn_fused_max_rows": (_i64, []),
-    "usc_bn_forward_fused": (C.c_int, [_p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p]),
-    "usc_bn_backward_fused": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p]),
     "usc_avgpool_down2": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_avgpool_down2_ex": (C.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _p, _p]),
     "usc_gather_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),

@@ -254,13 +254,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 // hides the ~1 us load latency, and with 8 chunks per wave for the 1024-wide FFN the loop was 8 dependent round trips).
 // ymask (optional): the layer's forward output after its fused ReLU — dy counts only where it is > 0;
 // dx_add (optional, [M,K]): added to the result (the other gradient path into the same input).
+template <bool EX>
 __device__ inline void linear_dx_tile(const float* __restrict__ dy, const float* __restrict__ ymask,
                                       const float* __restrict__ W, int M, int N, int K, float* __restrict__ dx,
                                       const float* __restrict__ dx_add, int c0, int m0, float (*red)[16][64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int m = m0 + i;
   const float* ya = dy + (int64_t)(m < M ? m : 0) * N + 4 * h;
-  const float* ym = ymask ? ymask + (int64_t)(m < M ? m : 0) * N + 4 * h : nullptr;
+  const float* ym = (EX && ymask) ? ymask + (int64_t)(m < M ? m : 0) * N + 4 * h : nullptr;
   const float* wb = W + (int64_t)(4 * h) * K + c0 + i;
   const float keep = m < M ? 1.f : 0.f;
   f32x16 acc;
@@ -273,7 +274,7 @@ __device__ inline void linear_dx_tile(const float* __restrict__ dy, const float*
     const int n0 = c * 32;
 #pragma unroll
     for (int t = 0; t < 4; ++t) aa[t] = *reinterpret_cast<const float4*>(ya + n0 + 8 * t);
-    if (ym) {
+    if (EX && ym) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float4 o = *reinterpret_cast<const float4*>(ym + n0 + 8 * t);
@@ -301,11 +302,12 @@ __device__ inline void linear_dx_tile(const float* __restrict__ dy, const float*
       for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[4 * t + j], acc);
     }
   }
-  tile_reduce_store(acc, red, wave, lane, dx, K, m0, c0, M, nullptr, 0, 0, dx_add);
+  tile_reduce_store(acc, red, wave, lane, dx, K, m0, c0, M, nullptr, 0, 0, EX ? dx_add : nullptr);
 }
 
 // dW[N,K] = dy[M,N]^T x[M,K],  db[N] = sum_m dy[m][N]   for the tile (c0, n0); the tiles with c0 == 0 also write db
 // ymask as above; x2 (optional): the layer's input rows were x + x2
+template <bool EX>
 __device__ inline void linear_dw_tile(const float* __restrict__ dy, const float* __restrict__ ymask,
                                       const float* __restrict__ x, const float* __restrict__ x2, int M, int N, int K,
                                       int accumulate, float* __restrict__ dW, float* __restrict__ db, int c0, int n0,
@@ -323,13 +325,33 @@ __device__ inline void linear_dw_tile(const float* __restrict__ dy, const float*
       for (int j = 0; j < 4; ++j) {
         const int m = mb + 8 * t + 4 * h + j;
         const bool ok = m < M;
-        float g = ok ? dy[(int64_t)m * N + n0 + i] : 0.f;
-        if (ymask && ok && !(ymask[(int64_t)m * N + n0 + i] > 0.f)) g = 0.f;
-        av[4 * t + j] = g;
-        float xv = ok ? x[(int64_t)m * K + c0 + i] : 0.f;
-        if (x2 && ok) xv += x2[(int64_t)m * K + c0 + i];
-        bv[4 * t + j] = xv;
+        av[4 * t + j] = ok ? dy[(int64_t)m * N + n0 + i] : 0.f;
+        bv[4 * t + j] = ok ? x[(int64_t)m * K + c0 + i] : 0.f;
       }
+    if (EX && ymask) {        // (uniform branches, all 16 loads of a block in flight together)
+      float ov[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = mb + 8 * t + 4 * h + j;
+          ov[4 * t + j] = m < M ? ymask[(int64_t)m * N + n0 + i] : 1.f;
+        }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) av[q] = ov[q] > 0.f ? av[q] : 0.f;
+    }
+    if (EX && x2) {
+      float ev[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int m = mb + 8 * t + 4 * h + j;
+          ev[4 * t + j] = m < M ? x2[(int64_t)m * K + c0 + i] : 0.f;
+        }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) bv[q] += ev[q];
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) { acc = MFMA32(av[q], bv[q], acc); bsum += av[q]; }
   }
@@ -348,21 +370,24 @@ __device__ inline void linear_dw_tile(const float* __restrict__ dy, const float*
 // Both gradients of a few-row linear layer in ONE launch: workgroups [0, dx_tiles) take the input-gradient tiles,
 // the rest the weight-gradient tiles (they are independent; as two launches the pair cost 9.4 + 4.5 us of a
 // latency-bound decoder pass, ~150 pairs per training step).
+template <bool EX>
 __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ymask,
                                                         const float* __restrict__ x, const float* __restrict__ x2,
                                                         const float* __restrict__ W, int M, int N, int K, int dx_tiles,
                                                         int accumulate, float* __restrict__ dx,
                                                         const float* __restrict__ dx_add, float* __restrict__ dW,
                                                         float* __restrict__ db) {
+  // EX = false: the plain layer (no ymask / x2 / dx_add) — the extra operands cost 50 % in this latency-bound kernel
+  // when merely tested per element, so the plain form is its own instantiation
   __shared__ float red[4][16][64];
   __shared__ float bred[4][32];
   const int kt = K / 32;
   int b = blockIdx.x;
   if (b < dx_tiles) {
-    linear_dx_tile(dy, ymask, W, M, N, K, dx, dx_add, (b % kt) * 32, (b / kt) * 32, red);
+    linear_dx_tile<EX>(dy, ymask, W, M, N, K, dx, dx_add, (b % kt) * 32, (b / kt) * 32, red);
   } else {
     b -= dx_tiles;
-    linear_dw_tile(dy, ymask, x, x2, M, N, K, accumulate, dW, db, (b % kt) * 32, (b / kt) * 32, red, bred);
+    linear_dw_tile<EX>(dy, ymask, x, x2, M, N, K, accumulate, dW, db, (b % kt) * 32, (b / kt) * 32, red, bred);
   }
 }
 
@@ -446,9 +471,14 @@ int usc_linear_bwd_ex(const float* dy, const float* y_relu, const float* x, cons
   hipStream_t st = usc::as_stream(s);
   const int dx_tiles = dx ? (K / 32) * ((M + 31) / 32) : 0;
   const int dw_tiles = dW ? (K / 32) * (N / 32) : 0;
-  if (dx_tiles + dw_tiles > 0)
-    hipLaunchKernelGGL(usc::linear_bwd_kernel, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, y_relu, x, x2, W, (int)M,
-                       (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dW, db);
+  if (dx_tiles + dw_tiles > 0) {
+    if (y_relu || x2 || dx_add)
+      hipLaunchKernelGGL(usc::linear_bwd_kernel<true>, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, y_relu, x, x2, W,
+                         (int)M, (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dW, db);
+    else
+      hipLaunchKernelGGL(usc::linear_bwd_kernel<false>, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, y_relu, x, x2, W,
+                         (int)M, (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dW, db);
+  }
   USC_CHECK_LAUNCH("usc_linear_bwd");
   return USC_OK;
 }

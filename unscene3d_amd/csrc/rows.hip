@@ -188,163 +188,6 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __res
   }
 }
 
-// ---------------------------------------------------------------------------
-// Small maps (the 507 ... 2 222-row levels of the U-Net: the feature map sits in L2): statistics, finalisation and the
-// element-wise pass of a training-mode batch norm in ONE launch instead of three (each a ~5 us round trip with the
-// chip idle).  One workgroup per 8 channels: 2 float4 columns x 128 row lanes; f64 sums per lane, combined in LDS in a
-// fixed order (16 lanes ascending, then the 8 group sums ascending); the second sweep re-reads the rows from L1/L2.
-constexpr int kBnFusedLanes = 128;
-__device__ inline void bn_fused_reduce(double (*sh)[8][2], int rl, int cq, const double* s1, const double* s2,
-                                       double (*part)[8][2], double* tot /* [8][2] in LDS */) {
-#pragma unroll
-  for (int v = 0; v < 4; ++v) { sh[rl][cq * 4 + v][0] = s1[v]; sh[rl][cq * 4 + v][1] = s2[v]; }
-  __syncthreads();
-  if (threadIdx.x < 128) {                 // (channel, which sum, group of 16 lanes)
-    const int ch = threadIdx.x & 7, w = (threadIdx.x >> 3) & 1, grp = threadIdx.x >> 4;
-    double t = 0.0;
-#pragma unroll
-    for (int l = 0; l < 16; ++l) t += sh[grp * 16 + l][ch][w];
-    part[grp][ch][w] = t;
-  }
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    const int ch = threadIdx.x & 7, w = threadIdx.x >> 3;
-    double t = 0.0;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) t += part[g][ch][w];
-    tot[ch * 2 + w] = t;
-  }
-  __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const float* __restrict__ x, int c, BnFwdOut o,
-                                                          const float* __restrict__ res, int relu,
-                                                          float* __restrict__ y) {
-  __shared__ double sh[kBnFusedLanes][8][2];
-  __shared__ double part[8][8][2];
-  __shared__ double tot[16];
-  __shared__ float coef[2][8];
-  const int cq = threadIdx.x & 1, rl = threadIdx.x >> 1;
-  const int ch0 = blockIdx.x * 8 + cq * 4;
-  const int64_t n = o.n;
-  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t r = rl; r < n; r += kBnFusedLanes) {
-    const float4 t = *reinterpret_cast<const float4*>(x + r * c + ch0);
-    const float tv[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-    for (int v = 0; v < 4; ++v) { s1[v] += (double)tv[v]; s2[v] += (double)tv[v] * (double)tv[v]; }
-  }
-  bn_fused_reduce(sh, rl, cq, s1, s2, part, tot);
-  if (threadIdx.x < 8) {
-    const int ch = blockIdx.x * 8 + threadIdx.x;
-    const double nn = (double)n;
-    const double m = tot[threadIdx.x * 2] / nn;
-    double var = tot[threadIdx.x * 2 + 1] / nn - m * m;
-    if (var < 0.0) var = 0.0;
-    const float mean = (float)m;
-    const float invstd = (float)(1.0 / sqrt(var + (double)o.eps));
-    const float sc = o.gamma[ch] * invstd;
-    const float sf = o.beta[ch] - mean * sc;
-    o.mean[ch] = mean; o.invstd[ch] = invstd; o.scale[ch] = sc; o.shift[ch] = sf;
-    coef[0][threadIdx.x] = sc; coef[1][threadIdx.x] = sf;
-    if (o.running_mean) {
-      const double unbiased = var * (nn / (nn > 1.0 ? nn - 1.0 : 1.0));
-      o.running_mean[ch] = (1.f - o.momentum) * o.running_mean[ch] + o.momentum * mean;
-      o.running_var[ch] = (1.f - o.momentum) * o.running_var[ch] + o.momentum * (float)unbiased;
-    }
-    if (ch == 0 && o.num_batches_tracked) *o.num_batches_tracked += 1;
-  }
-  __syncthreads();
-  float sc[4], sf[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) { sc[v] = coef[0][cq * 4 + v]; sf[v] = coef[1][cq * 4 + v]; }
-  for (int64_t r = rl; r < n; r += kBnFusedLanes) {
-    const int64_t e = r * c + ch0;
-    float4 v = *reinterpret_cast<const float4*>(x + e);
-    v.x = v.x * sc[0] + sf[0]; v.y = v.y * sc[1] + sf[1]; v.z = v.z * sc[2] + sf[2]; v.w = v.w * sc[3] + sf[3];
-    if (res) {
-      const float4 q = *reinterpret_cast<const float4*>(res + e);
-      v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-    }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    *reinterpret_cast<float4*>(y + e) = v;
-  }
-}
-
-// backward of the same: sums of g and g*xhat, the parameter gradients, then dx (and dres = g) in one launch
-__global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          const float* __restrict__ y_out,
-                                                          const float* __restrict__ mean,
-                                                          const float* __restrict__ invstd,
-                                                          const float* __restrict__ gamma, int64_t n, int c,
-                                                          int training, int accumulate, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, float* __restrict__ dx,
-                                                          float* __restrict__ dres) {
-  __shared__ double sh[kBnFusedLanes][8][2];
-  __shared__ double part[8][8][2];
-  __shared__ double tot[16];
-  __shared__ float coef[2][8];
-  const int cq = threadIdx.x & 1, rl = threadIdx.x >> 1;
-  const int ch0 = blockIdx.x * 8 + cq * 4;
-  float mu[4], is[4], ga[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) { mu[v] = mean[ch0 + v]; is[v] = invstd[ch0 + v]; ga[v] = gamma[ch0 + v]; }
-  double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int64_t r = rl; r < n; r += kBnFusedLanes) {
-    const int64_t e = r * c + ch0;
-    const float4 t = *reinterpret_cast<const float4*>(x + e);
-    const float4 g4 = *reinterpret_cast<const float4*>(dy + e);
-    const float xv[4] = {t.x, t.y, t.z, t.w};
-    float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-    if (y_out) {
-      const float4 o4 = *reinterpret_cast<const float4*>(y_out + e);
-      const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-      for (int v = 0; v < 4; ++v) if (!(ov[v] > 0.f)) gv[v] = 0.f;
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float xhat = (xv[v] - mu[v]) * is[v];
-      s1[v] += (double)gv[v];
-      s2[v] += (double)gv[v] * (double)xhat;
-    }
-  }
-  bn_fused_reduce(sh, rl, cq, s1, s2, part, tot);
-  if (threadIdx.x < 8) {
-    const int ch = blockIdx.x * 8 + threadIdx.x;
-    const double sg = tot[threadIdx.x * 2], sgx = tot[threadIdx.x * 2 + 1];
-    dbeta[ch] = accumulate ? dbeta[ch] + (float)sg : (float)sg;
-    dgamma[ch] = accumulate ? dgamma[ch] + (float)sgx : (float)sgx;
-    coef[0][threadIdx.x] = training ? (float)(sg / (double)n) : 0.f;
-    coef[1][threadIdx.x] = training ? (float)(sgx / (double)n) : 0.f;
-  }
-  __syncthreads();
-  float mg[4], mx[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) { mg[v] = coef[0][cq * 4 + v]; mx[v] = coef[1][cq * 4 + v]; }
-  for (int64_t r = rl; r < n; r += kBnFusedLanes) {
-    const int64_t e = r * c + ch0;
-    const float4 t = *reinterpret_cast<const float4*>(x + e);
-    const float4 g4 = *reinterpret_cast<const float4*>(dy + e);
-    const float xv[4] = {t.x, t.y, t.z, t.w};
-    float gv[4] = {g4.x, g4.y, g4.z, g4.w};
-    if (y_out) {
-      const float4 o4 = *reinterpret_cast<const float4*>(y_out + e);
-      const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-      for (int v = 0; v < 4; ++v) if (!(ov[v] > 0.f)) gv[v] = 0.f;
-    }
-    float ox[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float xhat = (xv[v] - mu[v]) * is[v];
-      ox[v] = ga[v] * is[v] * (gv[v] - mg[v] - xhat * mx[v]);
-    }
-    *reinterpret_cast<float4*>(dx + e) = make_float4(ox[0], ox[1], ox[2], ox[3]);
-    if (dres) *reinterpret_cast<float4*>(dres + e) = make_float4(gv[0], gv[1], gv[2], gv[3]);
-  }
-}
-
 // eval-mode batch norm: the same four vectors from the running statistics
 __global__ void bn_eval_stats_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps, int c,
@@ -815,36 +658,6 @@ int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamm
   BnFwdOut o{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n, num_batches_tracked};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c, o);
   USC_CHECK_LAUNCH("usc_bn_forward_stats");
-  return USC_OK;
-}
-
-int64_t usc_bn_fused_max_rows(void) {
-  static const int64_t v = [] { const char* e = getenv("USC3D_BN_FUSED_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)4096; }();
-  return v;
-}
-
-int usc_bn_forward_fused(const float* x, int64_t n, int32_t c, const float* gamma, const float* beta, float eps,
-                         float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                         float* mean, float* invstd, float* scale, float* shift, const float* residual, int32_t relu,
-                         float* y, usc_stream_t s) {
-  USC_REQUIRE(x && gamma && beta && mean && invstd && scale && shift && y && n >= 1, "usc_bn_forward_fused: bad argument");
-  USC_REQUIRE(c >= 8 && c % 8 == 0, "usc_bn_forward_fused: the width must be a multiple of 8");
-  USC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "usc_bn_forward_fused: running stats mismatch");
-  BnFwdOut o{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n, num_batches_tracked};
-  hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3((unsigned)(c / 8)), dim3(256), 0, as_stream(s), x, (int)c, o, residual,
-                     (int)relu, y);
-  USC_CHECK_LAUNCH("usc_bn_forward_fused");
-  return USC_OK;
-}
-
-int usc_bn_backward_fused(const float* x, const float* dy, const float* y_out, const float* mean, const float* invstd,
-                          const float* gamma, int64_t n, int32_t c, int32_t training, int32_t accumulate, float* dgamma,
-                          float* dbeta, float* dx, float* dres, usc_stream_t s) {
-  USC_REQUIRE(x && dy && mean && invstd && gamma && dgamma && dbeta && dx && n >= 1, "usc_bn_backward_fused: bad argument");
-  USC_REQUIRE(c >= 8 && c % 8 == 0, "usc_bn_backward_fused: the width must be a multiple of 8");
-  hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3((unsigned)(c / 8)), dim3(256), 0, as_stream(s), x, dy, y_out, mean, invstd,
-                     gamma, n, (int)c, (int)training, (int)accumulate, dgamma, dbeta, dx, dres);
-  USC_CHECK_LAUNCH("usc_bn_backward_fused");
   return USC_OK;
 }
 

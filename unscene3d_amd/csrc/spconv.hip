@@ -636,6 +636,8 @@ struct WgradParams {
   int64_t n_rows;  // identity form
   float* partial;  // [S, K, cin, cout]
   int cin, cout, K, S;
+  float* direct;   // wgrad_full_kernel, S == 1: dW itself (no partial slice, no reduction launch)
+  int accumulate;  //   ... added into it when set
 };
 
 // ALIGNED: cin % 32 == 0 and cout % (32*NB) == 0 -> unconditional vector loads; the lane's NB
@@ -849,7 +851,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
     __syncthreads();
   }
   if (wave == 0) {
-    float* dst = p.partial + ((int64_t)s * p.K + k) * cin * cout;
+    float* dst = p.direct ? p.direct + (int64_t)k * cin * cout : p.partial + ((int64_t)s * p.K + k) * cin * cout;
+    const bool add = p.direct && p.accumulate;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -857,7 +860,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ci = ci0 + CT * acc_row(r, h) + ct;
-          dst[(int64_t)ci * cout + co0 + NB * i + nb] = acc[ct * NB + nb][r] + red[((ct * NB + nb) * 16 + r) * 64 + lane];
+          float* d = dst + (int64_t)ci * cout + co0 + NB * i + nb;
+          const float v = acc[ct * NB + nb][r] + red[((ct * NB + nb) * 16 + r) * 64 + lane];
+          *d = add ? *d + v : v;
         }
   }
 }
@@ -1173,6 +1178,7 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
     const int64_t S = wgrad_full_splits(K, ctiles, cb, CT, NBf, n_rows);
     USC_REQUIRE(ws_bytes >= S * numel * 4, "usc_spconv_wgrad: workspace too small");
     p.S = (int)S;
+    if (S == 1) { p.direct = dW; p.accumulate = accumulate; }   // one slice: written (added) straight into dW
     dim3 grid((unsigned)(K * S), (unsigned)(ctiles / CT), (unsigned)(cb / NBf));
     const size_t lds = (size_t)CT * NBf * 16 * 64 * sizeof(float);
 #define USC_WF(C, N) if (CT == C && NBf == N) { \
@@ -1181,8 +1187,9 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
       hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p); }
     USC_WF(3, 3) USC_WF(2, 3) USC_WF(1, 3) USC_WF(2, 4) USC_WF(1, 4) USC_WF(4, 2) USC_WF(3, 2) USC_WF(2, 2) USC_WF(1, 2) USC_WF(4, 1) USC_WF(3, 1) USC_WF(2, 1) USC_WF(1, 1)
 #undef USC_WF
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, (int)S, numel,
-                       (int)accumulate, dW);
+    if (S > 1)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, (int)S,
+                         numel, (int)accumulate, dW);
     USC_CHECK_LAUNCH("usc_spconv_wgrad");
     return USC_OK;
   }

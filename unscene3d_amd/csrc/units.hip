@@ -264,12 +264,6 @@ int usc_conv_bn_act_forward(const usc_kmap* m, int32_t kind, const float* x, int
   if (rc) return rc;
   if (sh.n_out == 0) return USC_OK;
   float* mean = stats, *invstd = stats + cout, *scale = stats + 2 * cout, *shift = stats + 3 * cout;
-  if (bn->training && sh.n_out <= usc_bn_fused_max_rows() && cout % 8 == 0) {
-    // small map: statistics + normalise (+residual)(+ReLU) in one launch
-    return usc_bn_forward_fused(y, sh.n_out, cout, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->running_mean,
-                                bn->running_var, bn->num_batches_tracked, mean, invstd, scale, shift, residual, relu, out,
-                                s);
-  }
   if (bn->training) {
     rc = usc_bn_forward_stats(y, sh.n_out, cout, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->running_mean,
                               bn->running_var, bn->num_batches_tracked, mean, invstd, scale, shift, sws, sb, s);
@@ -297,16 +291,10 @@ int usc_conv_bn_act_backward(const usc_kmap* m, int32_t kind, const float* x, in
   float* red = (float*)cur.take(2 * (int64_t)cout * 4);   // mean_g | mean_gxhat
   USC_REQUIRE(sws && red, "usc_conv_bn_act_backward: workspace too small");
   const float* mean = stats, *invstd = stats + cout;
-  int rc;
-  if (sh.n_out <= usc_bn_fused_max_rows() && cout % 8 == 0) {
-    rc = usc_bn_backward_fused(y, dout, out_relu, mean, invstd, bn->gamma, sh.n_out, cout, bn->training, dbn_accumulate,
-                               dgamma, dbeta, dy, dres, s);
-  } else {
-    rc = usc_bn_backward_reduce(y, dout, out_relu, mean, invstd, sh.n_out, cout, bn->training, dbn_accumulate, dgamma,
-                                dbeta, red, red + cout, sws, sb, s);
-    if (rc) return rc;
-    rc = usc_bn_backward_dx(y, dout, out_relu, mean, invstd, bn->gamma, red, red + cout, dy, dres, sh.n_out, cout, s);
-  }
+  int rc = usc_bn_backward_reduce(y, dout, out_relu, mean, invstd, sh.n_out, cout, bn->training, dbn_accumulate, dgamma,
+                                  dbeta, red, red + cout, sws, sb, s);
+  if (rc) return rc;
+  rc = usc_bn_backward_dx(y, dout, out_relu, mean, invstd, bn->gamma, red, red + cout, dy, dres, sh.n_out, cout, s);
   if (rc) return rc;
   return usc_conv_backward(m, kind, x, cin, W, cout, dy, dx, dx_accumulate, dW, dW_accumulate, cur.rest(), cur.left(), s);
 }
