@@ -169,6 +169,7 @@ def make_mask3d_step(args, dev, rank, world):
         return total.detach(), batch[0].coordinates.shape[0]
 
     step.reducer = reducer
+    step.module = module
     return step
 
 

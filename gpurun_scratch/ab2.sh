@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-echo "== tests"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-for rep in 1 2; do timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"; done
+timeout 1500 python gpurun_scratch/stress_mr.py 2>&1 | tail -60

@@ -851,19 +851,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
     __syncthreads();
   }
   if (wave == 0) {
-    float* dst = p.direct ? p.direct + (int64_t)k * cin * cout : p.partial + ((int64_t)s * p.K + k) * cin * cout;
-    const bool add = p.direct && p.accumulate;
+    if (p.direct && p.accumulate) {       // one split: added straight into dW (no partial slice, no reduction launch)
+      float* dst = p.direct + (int64_t)k * cin * cout;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+      for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ci = ci0 + CT * acc_row(r, h) + ct;
-          float* d = dst + (int64_t)ci * cout + co0 + NB * i + nb;
-          const float v = acc[ct * NB + nb][r] + red[((ct * NB + nb) * 16 + r) * 64 + lane];
-          *d = add ? *d + v : v;
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + CT * acc_row(r, h) + ct;
+            dst[(int64_t)ci * cout + co0 + NB * i + nb] += acc[ct * NB + nb][r] + red[((ct * NB + nb) * 16 + r) * 64 + lane];
+          }
+    } else {
+      float* dst = p.direct ? p.direct + (int64_t)k * cin * cout : p.partial + ((int64_t)s * p.K + k) * cin * cout;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + CT * acc_row(r, h) + ct;
+            dst[(int64_t)ci * cout + co0 + NB * i + nb] = acc[ct * NB + nb][r] + red[((ct * NB + nb) * 16 + r) * 64 + lane];
+          }
+    }
   }
 }
 
