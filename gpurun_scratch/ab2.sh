@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python gpurun_scratch/stress_mr.py 2>&1 | tail -60
+timeout 1700 python gpurun_scratch/stress_mr4.py 2>&1 | tail -8
