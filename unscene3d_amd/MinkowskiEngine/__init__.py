@@ -472,4 +472,17 @@ def conv_bn_act(conv, norm, x: SparseTensor, residual: SparseTensor = None, relu
     return norm(conv(x), residual=residual, relu=relu)
 
 
-from . import MinkowskiOps, MinkowskiPooling  # noqa: E402,F401
+# The two submodule paths the reference imports — `import MinkowskiEngine.MinkowskiOps as me` (models/res16unet.py:1,
+# models/mask3d.py:4: `me.cat`, `me.SparseTensor`) and `from MinkowskiEngine.MinkowskiPooling import MinkowskiAvgPooling`
+# (models/mask3d.py:5) — are views of this module, registered as importable submodules.
+def _submodule(name, **members):
+    import sys
+    import types
+    m = types.ModuleType(f"{__name__}.{name}")
+    m.__dict__.update(members)
+    sys.modules[m.__name__] = m
+    return m
+
+
+MinkowskiOps = _submodule("MinkowskiOps", SparseTensor=SparseTensor, cat=cat)
+MinkowskiPooling = _submodule("MinkowskiPooling", MinkowskiAvgPooling=MinkowskiAvgPooling)
