@@ -1,4 +1,10 @@
 cd $GRAFT_REPO_ROOT
-echo "== tests"; timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 300 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
+for rep in 1 2 3; do
+for at in end sync; do
+  echo "== bench 150k prefetch_at=$at"; USC3D_PREFETCH_AT=$at timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+done
+done
+for at in end sync; do
+  echo "== bench 20k prefetch_at=$at"; USC3D_PREFETCH_AT=$at timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --voxels 20000 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+done
+timeout 600 python -m pytest tests/test_gpu_multirank.py -m gpu -x -q 2>&1 | tail -3
