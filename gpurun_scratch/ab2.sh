@@ -1,10 +1,7 @@
 cd $GRAFT_REPO_ROOT
+echo "== tests"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
 for rep in 1 2 3; do
-for at in end sync; do
-  echo "== bench 150k prefetch_at=$at"; USC3D_PREFETCH_AT=$at timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+for v in 0 1; do
+  echo "== bench 150k stats_over_slices=$v"; USC3D_STATS_OVER_SLICES=$v timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
 done
 done
-for at in end sync; do
-  echo "== bench 20k prefetch_at=$at"; USC3D_PREFETCH_AT=$at timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --voxels 20000 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
-done
-timeout 600 python -m pytest tests/test_gpu_multirank.py -m gpu -x -q 2>&1 | tail -3
