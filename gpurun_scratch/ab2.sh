@@ -1,7 +1,10 @@
 cd $GRAFT_REPO_ROOT
-echo "== tests"; timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-for rep in 1 2 3; do
-for v in 0 1; do
-  echo "== bench 150k stats_over_slices=$v"; USC3D_STATS_OVER_SLICES=$v timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])"
+mkdir -p gpurun_out/r02c
+for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $pass | cut -d' ' -f1)
+  (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02c/$tag -- python $GRAFT_REPO_ROOT/tools/conv_bench.py --sorted --only 1:96x96 --reps 5 > $GRAFT_REPO_ROOT/gpurun_out/r02c/$tag.log 2>&1)
+  for k in gather_gemm_compact wgrad_full; do python tools/pmc_summary.py gpurun_out/r02c/$tag $k; done >> gpurun_out/r02c/pmc_conv96x96_s1.txt
+  rm -rf gpurun_out/r02c/$tag
 done
-done
+cat gpurun_out/r02c/pmc_conv96x96_s1.txt | cut -c1-120
+tail -3 gpurun_out/r02c/SQ_WAVE_CYCLES.log | cut -c1-200
