@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python bench.py --mode backbone --no-cpu-baseline 2>&1 | tail -1 | cut -c1-700
-timeout 600 python bench.py --mode backbone --steps 3 --warmup 1 --cpu-sample-voxels 4000 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['cpu_baseline'])" | cut -c1-600
+for n in base noflush noticket normw noA noB noAB noABflush kda2 kda4 kdb2 krb4; do
+  echo -n "$n: "; USC3D_LIB=$GRAFT_REPO_ROOT/build/ablate/$n.so timeout 200 python tools/conv_bench.py --sorted --only 1:96x96 --reps 10 2>/dev/null | grep "96x96" | head -1
+done
