@@ -1,4 +1,6 @@
 cd $GRAFT_REPO_ROOT
-for n in base wgfull; do
-  echo "== $n"; USC3D_LIB=$GRAFT_REPO_ROOT/build/ablate/$n.so timeout 200 python tools/conv_bench.py --sorted --reps 10 2>/dev/null | grep -E "128x96"
-done
+mkdir -p gpurun_out/r02d
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r02d/prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/r02d/prof.log 2>&1)
+python tools/idle_gaps.py gpurun_out/r02d/prof > gpurun_out/r02d/idle_gaps.txt 2>&1
+cat gpurun_out/r02d/idle_gaps.txt | cut -c1-220
+rm -rf gpurun_out/r02d/prof
