@@ -59,6 +59,11 @@ def parse(argv=None):
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the measured configuration); gloo only to smoke-test the N>1 code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices)")
+    ap.add_argument("--voxels-by-rank", default=None, metavar="N0,N1,...",
+                    help="scene size per rank (uneven ranks: the step of a small scene is host-bound, that of a large one "
+                         "device-bound; the collectives must line up all the same); default: --voxels on every rank")
+    ap.add_argument("--eager-ranks", default="", metavar="R0,R1,...",
+                    help="ranks that do NOT capture the decoder passes as HIP graphs (mixed eager / graphed ranks)")
     ap.add_argument("--cpu-sample-voxels", type=int, default=10_000,
                     help="scene size of the cpu_baseline leg (2 x (1 warm-up + 3 timed) passes of the CPU restatement)")
     return ap.parse_args(argv)
@@ -125,11 +130,16 @@ def make_mask3d_step(args, dev, rank, world):
         from unscene3d_amd.optim import FlatAdamW
         opt = FlatAdamW(params, lr=cfg.optimizer.lr, flat_grad=flat)     # same defaults as torch.optim.AdamW
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=cfg.optimizer.lr, total_steps=100000)
-    sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=args.voxels, seed=2000 + rank)[0]
+    voxels = args.voxels
+    if args.voxels_by_rank:
+        by_rank = [int(v) for v in args.voxels_by_rank.split(",")]
+        voxels = by_rank[rank % len(by_rank)]
+    eager = str(rank) in [r for r in args.eager_ranks.split(",") if r]
+    sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=voxels, seed=2000 + rank)[0]
     # raw scene arrays resident in HBM before the timed region (the collate reads them from there)
     sample = tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) if isinstance(x, np.ndarray) and i in (0, 1, 2)
                    else x for i, x in enumerate(sample))
-    if not args.no_graphs:
+    if not (args.no_graphs or eager):
         module.model.enable_decoder_graphs(batch_size=1, device=dev)
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(dev),
                                       spatial_sort=args.spatial_sort)
@@ -170,6 +180,7 @@ def make_mask3d_step(args, dev, rank, world):
 
     step.reducer = reducer
     step.module = module
+    step.params = params
     return step
 
 
@@ -181,6 +192,38 @@ def _allreduce_note(step, world):
         return "one flat buffer after backward"
     return (f"{len(red.bounds)} buckets of the flat buffer, {red.started_during_backward} started during backward "
             f"(last step)")
+
+
+def _device_id(dev):
+    """A string that names the physical device behind `dev`: its uuid when the runtime reports one, else the PCI bus
+    id, else the index (two ranks that print the same string share a device)."""
+    prop = torch.cuda.get_device_properties(dev)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(prop, attr, None)
+        if v not in (None, ""):
+            extra = "".join(f":{getattr(prop, a)}" for a in ("pci_domain_id", "pci_device_id") if hasattr(prop, a)) \
+                if attr == "pci_bus_id" else ""
+            return f"{attr}={v}{extra}"
+    return f"index={dev.index}"
+
+
+def _ranks_seen(dev, rank, world, backend, params):
+    """What the collectives really spanned (reference: pl.Trainer(gpus=N), main_instance_segmentation.py:86-92):
+    `rccl_ranks_seen` = dist.get_world_size() when the backend is nccl (= RCCL) else 0, the physical device of every
+    rank (all-gathered), and whether every rank holds the same weights after the run (data-parallel ranks that apply
+    the same averaged gradients must agree to the bit)."""
+    import socket
+    ids = [None] * world
+    dist.all_gather_object(ids, f"{socket.gethostname()}/{_device_id(dev)}")
+    same = None
+    if params:
+        with torch.no_grad():
+            tot = torch.zeros(world, dtype=torch.float64, device=dev)
+            tot[rank] = sum(p.detach().double().abs().sum() for p in params)     # one checksum per rank
+            dist.all_reduce(tot)
+            same = bool((tot == tot[0]).all().item())
+    return {"dist_backend": backend, "rccl_ranks_seen": dist.get_world_size() if backend == "nccl" else 0,
+            "rank_devices": ids, "distinct_devices": len(set(ids)), "weights_equal_across_ranks": same}
 
 
 def cpu_baseline(sample_voxels, mode="mask3d"):
@@ -269,7 +312,8 @@ def cpu_baseline_mask3d(sample_voxels, runs=3):
         target = [{"labels": torch.ones(masks.shape[0], dtype=torch.int64), "masks": masks, "segment_mask": seg_mask,
                    "point2segment": p2s}]
         feats = torch.from_numpy(feats)
-        out = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], [p2s], lambda n: torch.randperm(n))
+        out = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], [p2s], lambda n: torch.randperm(n),
+                                keep_graph=True)     # gradients reach every parameter, backbone included
         losses = crit(out, target, "segment_mask")
         sum(v * wd[k] for k, v in losses.items() if k in wd).backward()
         return time.perf_counter() - t0, coords4.shape[0]
@@ -479,6 +523,10 @@ def main():
                     roof["traffic"] = ent["bytes_per_launch"]
                     roof["traffic_source"] = "profiles/pmc_traffic.json"
 
+    ranks_seen = None
+    if world > 1:
+        ranks_seen = _ranks_seen(dev, rank, world, args.dist_backend, getattr(step, "params", None))
+
     if rank == 0:
         line = {
             "metric": "training scenes/sec (Res16UNet34C+Mask3D, 150k voxels)",
@@ -487,7 +535,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.mode].format(nvox=nvox),
                        "voxels_per_scene": int(nvox), "global_batch": world, "parallelism": f"dp{world}",
-                       "loss": float(loss), "grad_allreduce": _allreduce_note(step, world)},
+                       "loss": float(loss), "grad_allreduce": _allreduce_note(step, world),
+                       **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),
         }

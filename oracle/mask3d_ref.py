@@ -1,9 +1,9 @@
 """oracle/mask3d_ref.py — CPU (torch) restatement of Mask3D.forward and of the self-training step
 (reference models/mask3d.py:200-446, trainer/trainer.py:99-163).  TEST INFRASTRUCTURE ONLY.
 
-Consumes the device model's state_dict.  The decoder blocks are rebuilt from torch.nn primitives
-(`nn.MultiheadAttention`, `nn.LayerNorm`, `nn.Linear`), whose reference usage (mask3d.py:491-651)
-is pinned by tests/golden/decoder_layers.npz; FPS follows sampling_gpu.cu:73-176; the Fourier
+Consumes the device model's state_dict.  The decoder blocks are torch.nn.functional primitives
+(`F.multi_head_attention_forward` = nn.MultiheadAttention.forward, `F.layer_norm`, matrix products) applied to the
+state_dict's tensors, whose reference usage (mask3d.py:491-651) is pinned by tests/golden/decoder_layers.npz; FPS follows sampling_gpu.cu:73-176; the Fourier
 encoding follows models/position_embedding.py:12-40,128-157 (pinned by tests/golden/posenc.npz);
 the sparse backbone is oracle/res16unet_ref.py (ME semantics — parity unpinned, see sparse_ref.py).
 Random key sub-sampling is injected through `randperm(n)` so that device and oracle use the same
@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import numpy as np
 import torch
-import torch.nn as nn
 import torch.nn.functional as F
 
 from . import res16unet_ref as RU
@@ -56,31 +55,29 @@ def fourier_rows(xyz: torch.Tensor, lo, hi, gauss_B: torch.Tensor) -> torch.Tens
     return torch.cat([proj.sin(), proj.cos()], dim=1)
 
 
-class _Block(nn.Module):
-    def __init__(self, kind, d, heads, ff):
-        super().__init__()
-        self.kind = kind
-        if kind == "ffn":
-            self.linear1, self.linear2 = nn.Linear(d, ff), nn.Linear(ff, d)
-        elif kind == "ca":
-            self.multihead_attn = nn.MultiheadAttention(d, heads, dropout=0.0)
-        else:
-            self.self_attn = nn.MultiheadAttention(d, heads, dropout=0.0)
-        self.norm = nn.LayerNorm(d)
+def _mha(sd, pfx, d, heads, query, key, value, attn_mask=None):
+    """nn.MultiheadAttention.forward (sequence-first, dropout 0, need_weights=True) called functionally on the
+    state_dict's tensors, so that autograd reaches them (reference models/mask3d.py:491-605 builds the module; its use
+    is pinned by tests/golden/decoder_layers.npz and decoder_pass.npz)."""
+    return F.multi_head_attention_forward(
+        query, key, value, d, heads, sd[pfx + "in_proj_weight"], sd[pfx + "in_proj_bias"], None, None, False, 0.0,
+        sd[pfx + "out_proj.weight"], sd[pfx + "out_proj.bias"], training=True, key_padding_mask=None,
+        need_weights=True, attn_mask=attn_mask)[0]
 
 
-def _load(prefix, sd, kind, d, heads, ff, dtype):
-    blk = _Block(kind, d, heads, ff)
-    blk.load_state_dict({k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)})
-    return blk.to(dtype)
+def _ln(sd, pfx, d, x):
+    return F.layer_norm(x, (d,), sd[pfx + "weight"], sd[pfx + "bias"])
 
 
 def mask3d_forward(sd: dict, cfg, coords4: np.ndarray, feats: torch.Tensor, raw_xyz: torch.Tensor, point2segment,
-                   randperm, dtype=torch.float32):
-    """-> dict(pred_logits, pred_masks, aux_outputs) like the reference; sd = device model state_dict."""
+                   randperm, dtype=torch.float32, keep_graph=False):
+    """-> dict(pred_logits, pred_masks, aux_outputs) like the reference; sd = device model state_dict.
+    keep_graph: `sd` already holds CPU tensors of `dtype` (leaves with requires_grad): they are used as they are, so
+    that a backward pass from the criterion fills their .grad (full-step gradient / trajectory parity)."""
     m = cfg.model
     d, Q, H = m.hidden_dim, m.num_queries, m.num_heads
-    sd = {k: (v.detach().cpu().to(dtype) if v.dtype.is_floating_point else v.detach().cpu()) for k, v in sd.items()}
+    if not keep_graph:
+        sd = {k: (v.detach().cpu().to(dtype) if v.dtype.is_floating_point else v.detach().cpu()) for k, v in sd.items()}
     bsd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
     pyr = RU.Pyramid(coords4)
     layers = (2, 3, 4, 6, 2, 2, 2, 2)
@@ -163,16 +160,15 @@ def mask3d_forward(sd: dict, cfg, coords4: np.ndarray, feats: torch.Tensor, raw_
             b_attn = torch.logical_or(b_attn, torch.stack(midx)[..., None])
             pfx = f"lin_squeeze.0.{i}."
             src = b_aux.permute(1, 0, 2) @ sd[pfx + "weight"].T + sd[pfx + "bias"]
-            ca = _load(f"cross_attention.0.{i}.", sd, "ca", d, H, m.dim_feedforward, dtype)
-            sa = _load(f"self_attention.0.{i}.", sd, "sa", d, H, m.dim_feedforward, dtype)
-            ff = _load(f"ffn_attention.0.{i}.", sd, "ffn", d, H, m.dim_feedforward, dtype)
+            ca, sa, ff = f"cross_attention.0.{i}.", f"self_attention.0.{i}.", f"ffn_attention.0.{i}."
             tgt = queries.permute(1, 0, 2)
-            upd = ca.multihead_attn(query=tgt + query_pos, key=src + b_pos.permute(1, 0, 2), value=src,
-                                    attn_mask=b_attn.repeat_interleave(H, dim=0).permute(0, 2, 1))[0]
-            tgt = ca.norm(tgt + upd)
+            upd = _mha(sd, ca + "multihead_attn.", d, H, tgt + query_pos, src + b_pos.permute(1, 0, 2), src,
+                       attn_mask=b_attn.repeat_interleave(H, dim=0).permute(0, 2, 1))
+            tgt = _ln(sd, ca + "norm.", d, tgt + upd)
             qk = tgt + query_pos
-            tgt = sa.norm(tgt + sa.self_attn(qk, qk, value=tgt)[0])
-            tgt = ff.norm(tgt + ff.linear2(torch.relu(ff.linear1(tgt))))
+            tgt = _ln(sd, sa + "norm.", d, tgt + _mha(sd, sa + "self_attn.", d, H, qk, qk, tgt))
+            hid = torch.relu(tgt @ sd[ff + "linear1.weight"].T + sd[ff + "linear1.bias"])
+            tgt = _ln(sd, ff + "norm.", d, tgt + hid @ sd[ff + "linear2.weight"].T + sd[ff + "linear2.bias"])
             queries = tgt.permute(1, 0, 2)
             pred_cls.append(cls)
             pred_masks.append(segs)

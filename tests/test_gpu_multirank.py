@@ -1,7 +1,7 @@
-"""The N>1 code path of bench.py end to end on whatever GPUs the box has: two ranks (sharing device 0 when there is
-only one), gloo collectives — the criterion's num_masks all-reduce, the flat gradient all-reduce, graph capture with a
-process group alive, the instrumented roofline step on every rank.  (RCCL itself needs one GPU per rank; the driver's
-scaling bench covers that.)"""
+"""The N>1 code path of bench.py end to end on whatever GPUs the box has: two ranks over RCCL (`nccl`) when the box
+shows at least two devices, else gloo with both ranks sharing device 0 — the criterion's num_masks all-reduce, the
+gradient all-reduce (one flat buffer, and buckets started during backward), graph capture with a process group alive,
+uneven ranks (a large graphed scene next to a small eager one), the instrumented roofline step on every rank."""
 import json
 import os
 import subprocess
@@ -13,11 +13,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _backend():
+    """RCCL whenever the box can give every rank its own device (reference: pl.Trainer(gpus=N) over NCCL,
+    main_instance_segmentation.py:86-92); gloo on a one-GPU box, where the two ranks share the device."""
+    import torch
+    return "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+
+
 def _run(overlap, port):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", USC3D_OVERLAP_ALLREDUCE=overlap)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--voxels", "40000", "--dist-backend", "gloo", "--no-cpu-baseline"]
+           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -40,11 +47,11 @@ def test_overlapped_gradient_allreduce_equals_the_single_one():
     assert b["config"]["grad_allreduce"] == "one flat buffer after backward"
 
 
-def test_bench_two_ranks_gloo():
+def test_bench_two_ranks():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--voxels", "40000", "--dist-backend", "gloo", "--no-cpu-baseline"]
+           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -52,6 +59,32 @@ def test_bench_two_ranks_gloo():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["roofline"] is not None and rec["cpu_baseline"] is None
+    cfg = rec["config"]
+    assert cfg["dist_backend"] == _backend() and len(cfg["rank_devices"]) == 2
+    assert cfg["rccl_ranks_seen"] == (2 if _backend() == "nccl" else 0)
+    assert cfg["distinct_devices"] == (2 if _backend() == "nccl" else 1)
+    assert cfg["weights_equal_across_ranks"] is True
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_uneven_ranks_neither_hang_nor_diverge(overlap):
+    """Rank 0: a 150 k-voxel scene with captured decoder passes (device-bound step); rank 1: a 20 k-voxel scene run
+    eagerly (host-bound step, other launch counts per parameter, levels smaller than the sampled key counts).  The
+    collectives — num_masks, the learned gradient-write counts, the buckets started during backward on one rank and
+    after it on the other — must line up (no hang: the subprocess timeout), and both ranks must end with the same
+    weights to the bit and a finite loss."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", USC3D_OVERLAP_ALLREDUCE=overlap)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29571 + int(overlap)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2", "--voxels-by-rank", "150000,20000", "--eager-ranks", "1", "--dist-backend", _backend(),
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 2 and cfg["weights_equal_across_ranks"] is True
+    assert cfg["loss"] == cfg["loss"] and abs(cfg["loss"]) < 1e4          # finite
+    assert abs(cfg["voxels_per_scene"] - 150000) < 3000                     # rank 0's scene
 
 
 def test_bench_gpus_2_without_a_launcher_spawns_two_ranks():
@@ -59,7 +92,7 @@ def test_bench_gpus_2_without_a_launcher_spawns_two_ranks():
     and the line reports n_gpus == 2 (gloo here because the test box has one device; the default backend is RCCL)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--voxels", "40000", "--dist-backend", "gloo", "--no-cpu-baseline"]
+           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

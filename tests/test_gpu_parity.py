@@ -496,61 +496,7 @@ class _PermSource:
         return p.to(device) if device is not None else p
 
 
-def test_config3_full_mask3d_step_loss_parity(device):
-    """Config 3 at oracle size: collate (device voxelisation) -> Mask3D forward -> Hungarian -> 52 losses,
-    against the CPU restatement driven by the same state_dict and the same sampled indices."""
-    import oracle.mask3d_ref as OM
-    from unscene3d_amd.config import apply_overrides, default_config
-    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
-    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
-    from unscene3d_amd.models.criterion import SetCriterion
-    from unscene3d_amd.trainer.trainer import InstanceSegmentation
-
-    cfg = apply_overrides(default_config(), ["general.num_targets=3", "model.sample_sizes=[50,100,200,400,800]"])
-    ds = SyntheticFreeMaskDataset(n_scenes=2, target_voxels=12000, seed=3100)
-    batch = [ds[0], ds[1]]
-    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device))
-    data, target, names = collate(batch)
-
-    # collate parity: voxel rows == oracle sparse_quantize order, inverse maps exact
-    off = 0
-    for b, sample in enumerate(batch):
-        ec = R.voxel_floor(sample[0], 0.02)
-        eu, einv = R.sparse_quantize(ec)
-        n = len(eu)
-        assert np.array_equal(data.coordinates[off:off + n].cpu().numpy()[:, 1:], ec[eu])
-        assert np.all(data.coordinates[off:off + n, 0].cpu().numpy() == b)
-        assert np.array_equal(data.inverse_maps[b].cpu().numpy(), einv)
-        assert np.allclose(data.features[off:off + n].cpu().numpy(), sample[1][eu])
-        seg_ids = sample[2][eu, -1]
-        _, exp_inv = np.unique(seg_ids, return_inverse=True)
-        assert np.array_equal(target[b]["point2segment"].cpu().numpy(), exp_inv)
-        off += n
-
-    torch.manual_seed(7)
-    module = InstanceSegmentation(cfg).to(device).train()
-    module.model.randperm = _PermSource()
-    total, weighted = module.training_step((data, target, names))
-    total.backward()
-    assert len(weighted) == 52 and bool(torch.isfinite(total))
-
-    # oracle forward from the same weights
-    sd = module.model.state_dict()
-    coords4 = data.coordinates.cpu().numpy()
-    feats = data.features.cpu()
-    p2s = [t["point2segment"].cpu() for t in target]
-    out_ref = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], p2s, _PermSource())
-    tgt_cpu = [{k: v.cpu() for k, v in t.items()} for t in target]
-    crit_cpu = SetCriterion(num_classes=3, matcher=module.criterion.matcher, weight_dict=module.criterion.weight_dict,
-                            eos_coef=0.1, losses=["labels", "masks"], num_points=-1, oversample_ratio=3.0,
-                            importance_sample_ratio=0.75, class_weights=-1)
-    losses_ref = crit_cpu(out_ref, tgt_cpu, mask_type="segment_mask")
-    wd = module.criterion.weight_dict
-    total_ref = sum(v * wd[k] for k, v in losses_ref.items() if k in wd)
-    assert abs(float(total) - float(total_ref)) / abs(float(total_ref)) < REL_TOL, (float(total), float(total_ref))
-    for k, v in weighted.items():
-        ref = float(losses_ref[k] * wd[k])
-        assert abs(float(v) - ref) <= REL_TOL * max(abs(ref), 1e-3), (k, float(v), ref)
+# config 3 (full Mask3D step vs the oracle: collate, 52 losses, gradients, 3-step trajectory): tests/test_gpu_step_parity.py
 
 
 def _ncut_case(name):

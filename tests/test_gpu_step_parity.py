@@ -1,0 +1,237 @@
+"""Config 3 (BASELINE.json configs[2]) under the oracle in the configuration bench.py actually runs: the collate's
+z-order cell row permutation (`spatial_sort=5`) as well as the reference's first-occurrence order, the 52 losses, the
+gradients of the whole step and the loss trajectory over three AdamW + OneCycleLR steps.
+
+Reference: datasets/utils.py:403-414 (voxelisation + unique maps), trainer/trainer.py:99-163 (training_step),
+:953-966 (AdamW + OneCycleLR).  Oracle: oracle/mask3d_ref.py + oracle/sparse_ref.py driven by the device model's
+state_dict and the same injected key-sampling stream."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sparse_ref as R
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-3   # north_star tolerance for fp32 features / losses
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-30))
+
+
+class PermSource:
+    """k-th call -> torch.randperm(n) from a generator seeded with k: identical index streams for the device model and
+    the oracle (the reference draws them with torch.randperm, models/mask3d.py:325)."""
+
+    def __init__(self):
+        self.k = 0
+
+    def __call__(self, n, device=None):
+        g = torch.Generator().manual_seed(1000 + self.k)
+        self.k += 1
+        p = torch.randperm(n, generator=g)
+        return p.to(device) if device is not None else p
+
+
+def check_collate(batch, data, target, spatial_sort):
+    """Permutation-aware parity of the device collate with the oracle's sparse_quantize: per scene the voxel rows are
+    a permutation `perm` of the oracle's first-occurrence rows (the identity without spatial_sort), every point's
+    inverse map leads to its own voxel, and features / mask table / segment ids / target masks / segment masks are
+    permuted with the SAME permutation."""
+    off = 0
+    for b, sample in enumerate(batch):
+        ec = R.voxel_floor(sample[0], 0.02)
+        eu, einv = R.sparse_quantize(ec)
+        n = len(eu)
+        ecu = ec[eu]
+        c_dev = data.coordinates[off:off + n].cpu().numpy()
+        assert np.all(c_dev[:, 0] == b)
+        od, orf = np.lexsort(c_dev[:, 1:].T[::-1]), np.lexsort(ecu.T[::-1])
+        assert np.array_equal(c_dev[od, 1:], ecu[orf])                      # the same SET of voxels
+        perm = np.empty(n, np.int64)
+        perm[od] = orf                                                      # c_dev[i] == ecu[perm[i]]
+        assert np.array_equal(c_dev[:, 1:], ecu[perm])
+        if not spatial_sort:
+            assert np.array_equal(perm, np.arange(n))                       # ME's first-occurrence order itself
+        else:
+            assert not np.array_equal(perm, np.arange(n))                   # the permutation is really exercised
+        inv = data.inverse_maps[b].cpu().numpy()
+        assert inv.shape == einv.shape
+        assert np.array_equal(c_dev[inv, 1:], ec)                           # every point lands in its own voxel
+        assert np.array_equal(perm[inv], einv)
+        assert np.allclose(data.features[off:off + n].cpu().numpy(), sample[1][eu][perm])
+        tab = sample[2][eu][perm].astype(np.int64)
+        _, exp_inv = np.unique(tab[:, -1], return_inverse=True)
+        exp_inv = exp_inv.reshape(-1)
+        p2s = target[b]["point2segment"].cpu().numpy()
+        assert np.array_equal(p2s, exp_inv)
+        assert int(target[b]["num_segments"]) == int(exp_inv.max()) + 1
+        cols = tab[:, 1:-1] != 0
+        keep = np.nonzero(cols.any(0))[0]
+        assert np.array_equal(target[b]["masks"].cpu().numpy(), cols.T[keep])
+        tab[:, -1] = exp_inv
+        sm = np.zeros((len(keep), int(exp_inv.max()) + 1), bool)
+        for j, t in enumerate(keep):
+            sm[j, np.unique(tab[cols[:, t]])] = True                        # reference datasets/utils.py:503 quirk
+        assert np.array_equal(target[b]["segment_mask"].cpu().numpy(), sm)
+        off += n
+    assert off == data.coordinates.shape[0]
+
+
+def _setup(device, spatial_sort, overrides=()):
+    from unscene3d_amd.config import apply_overrides, default_config
+    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+    from unscene3d_amd.trainer.trainer import InstanceSegmentation
+
+    cfg = apply_overrides(default_config(), ["general.num_targets=3", "model.sample_sizes=[50,100,200,400,800]",
+                                             *overrides])
+    ds = SyntheticFreeMaskDataset(n_scenes=2, target_voxels=12000, seed=3100)
+    batch = [ds[0], ds[1]]
+    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device),
+                                      spatial_sort=spatial_sort)
+    torch.manual_seed(7)
+    module = InstanceSegmentation(cfg).to(device).train()
+    return cfg, batch, collate, module
+
+
+def _oracle_step(module, cfg, sd, data, target, perm_source, dtype):
+    """Forward + criterion of the CPU restatement on the leaves `sd` (keep_graph) -> (total, {key: weighted loss})."""
+    import oracle.mask3d_ref as OM
+    from unscene3d_amd.models.criterion import SetCriterion
+
+    coords4 = data.coordinates.cpu().numpy()
+    feats = data.features.cpu()
+    p2s = [t["point2segment"].cpu() for t in target]
+    out_ref = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], p2s, perm_source, dtype=dtype,
+                                keep_graph=True)
+    tgt_cpu = [{k: v.cpu() for k, v in t.items()} for t in target]
+    crit_cpu = SetCriterion(num_classes=3, matcher=module.criterion.matcher, weight_dict=module.criterion.weight_dict,
+                            eos_coef=0.1, losses=["labels", "masks"], num_points=-1, oversample_ratio=3.0,
+                            importance_sample_ratio=0.75, class_weights=-1)    # computes in f32 (`.float()`, as the reference)
+    losses_ref = crit_cpu(out_ref, tgt_cpu, mask_type="segment_mask")
+    wd = module.criterion.weight_dict
+    weighted = {k: v * wd[k] for k, v in losses_ref.items() if k in wd}
+    return sum(weighted.values()), weighted
+
+
+def _leaves(module, dtype):
+    return {k: (v.detach().cpu().to(dtype) if v.dtype.is_floating_point else v.detach().cpu()).clone()
+            .requires_grad_(v.dtype.is_floating_point) for k, v in module.model.state_dict().items()}
+
+
+@pytest.mark.parametrize("spatial_sort", [False, 5])
+def test_config3_full_mask3d_step_loss_and_gradient_parity(device, spatial_sort):
+    """Collate (device voxelisation, with and without the z-order cell permutation bench.py uses) -> Mask3D forward ->
+    Hungarian -> 52 losses -> backward, against the CPU restatement driven by the same state_dict and the same sampled
+    indices: collate bit-exact up to the stated permutation, losses < 1e-3, gradients of every parameter no further
+    from the f64 oracle than 3x the f32 oracle is (+1e-3) — the gate of test_config2 (a 34-layer ReLU/BN backward is
+    ill-conditioned in fp32)."""
+    cfg, batch, collate, module = _setup(device, spatial_sort)
+    data, target, names = collate(batch)
+    check_collate(batch, data, target, spatial_sort)
+
+    module.model.randperm = PermSource()
+    total, weighted = module.training_step((data, target, names))
+    total.backward()
+    assert len(weighted) == 52 and bool(torch.isfinite(total))
+
+    sd32 = _leaves(module, torch.float32)
+    total32, w32 = _oracle_step(module, cfg, sd32, data, target, PermSource(), torch.float32)
+    assert abs(float(total) - float(total32)) / abs(float(total32)) < REL_TOL, (float(total), float(total32))
+    for k, v in weighted.items():
+        ref = float(w32[k])
+        assert abs(float(v) - ref) <= REL_TOL * max(abs(ref), 1e-3), (k, float(v), ref)
+    total32.backward()
+
+    sd64 = _leaves(module, torch.float64)
+    total64, _ = _oracle_step(module, cfg, sd64, data, target, PermSource(), torch.float64)
+    assert abs(float(total) - float(total64)) / abs(float(total64)) < REL_TOL
+    total64.backward()
+
+    worst_dev, worst_cpu, worst_name = 0.0, 0.0, None
+    checked = 0
+    for name, p in module.model.named_parameters():
+        if name.startswith("backbone.final."):
+            assert p.grad is None
+            continue
+        g64 = sd64[name].grad
+        assert g64 is not None and p.grad is not None, name
+        if float(g64.norm()) < 1e-12:                   # e.g. the bias in front of a batch norm: exactly zero
+            assert float(p.grad.norm()) < 1e-6, name
+            continue
+        e = rel_err(p.grad, g64)
+        worst_cpu = max(worst_cpu, rel_err(sd32[name].grad, g64))
+        checked += 1
+        if e > worst_dev:
+            worst_dev, worst_name = e, name
+    assert checked > 300
+    assert worst_dev < 3 * worst_cpu + REL_TOL, (worst_dev, worst_cpu, worst_name)
+    # the groups the verdict names, individually: stem, deepest block, decoder weights
+    for prefix in ("backbone.conv0p1s1.", "backbone.block4.", "cross_attention.", "self_attention.", "ffn_attention.",
+                   "lin_squeeze.", "mask_embed_head.", "class_embed_head.", "query_projection."):
+        for name, p in module.model.named_parameters():
+            if name.startswith(prefix):
+                assert rel_err(p.grad, sd64[name].grad) < 3 * worst_cpu + REL_TOL, name
+
+
+@pytest.mark.parametrize("spatial_sort", [5])
+def test_config3_three_step_loss_trajectory(device, spatial_sort):
+    """Three AdamW + OneCycleLR steps (reference trainer/trainer.py:953-966; a short cycle so that the learning rate
+    is at its peak by the third step and the weights really move) on the device — flat-buffer AdamW kernel, in-place
+    parameter gradients — and on the oracle with torch.optim.AdamW: the loss before every update and after the last
+    one within 1e-3 of the oracle's."""
+    from unscene3d_amd.ddp import flatten_grads
+    from unscene3d_amd.optim import FlatAdamW
+
+    cfg, batch, collate, module = _setup(device, spatial_sort)
+    lr, cycle = cfg.optimizer.lr, 8
+    sd = _leaves(module, torch.float32)                               # before FlatAdamW re-points p.data
+    pnames = [n for n, _ in module.model.named_parameters() if not n.startswith("backbone.final.")]
+    params = [p for n, p in module.named_parameters() if ".backbone.final." not in n]
+    flat = flatten_grads(params)
+    opt = FlatAdamW(params, lr=lr, flat_grad=flat)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=lr, total_steps=cycle)
+    opt_ref = torch.optim.AdamW([sd[n] for n in pnames], lr=lr)
+    sched_ref = torch.optim.lr_scheduler.OneCycleLR(opt_ref, max_lr=lr, total_steps=cycle)
+
+    data, target, names = collate(batch)
+    perm_dev, perm_ref = PermSource(), PermSource()
+    module.model.randperm = perm_dev
+    dev_losses, ref_losses = [], []
+    for step in range(4):
+        total, _ = module.training_step((data, target, names))
+        dev_losses.append(float(total))
+        total_ref, _ = _oracle_step(module, cfg, sd, data, target, perm_ref, torch.float32)
+        ref_losses.append(float(total_ref))
+        assert perm_dev.k == perm_ref.k                               # both consumed the same sampling stream
+        if step == 3:
+            break
+        opt.zero_grad(set_to_none=False)
+        total.backward()
+        opt.step()
+        sched.step()
+        opt_ref.zero_grad(set_to_none=True)
+        total_ref.backward()
+        opt_ref.step()
+        sched_ref.step()
+    for a, b in zip(dev_losses, ref_losses):
+        assert abs(a - b) <= REL_TOL * abs(b), (dev_losses, ref_losses)
+    # the check has teeth: the three updates moved the loss by far more than the tolerance
+    assert abs(ref_losses[3] - ref_losses[0]) > 10 * REL_TOL * abs(ref_losses[0]), ref_losses
+
+
+def test_collate_row_permutation_at_full_size(device):
+    """The collate block alone on the 150 k-voxel bench scene with bench.py's spatial_sort=5."""
+    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+
+    batch = [SyntheticFreeMaskDataset(n_scenes=1, target_voxels=150_000, seed=2000)[0]]
+    for spatial_sort in (5, False):
+        collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device),
+                                          spatial_sort=spatial_sort)
+        data, target, _ = collate(batch)
+        assert abs(data.coordinates.shape[0] - 150_000) < 3000
+        check_collate(batch, data, target, spatial_sort)

@@ -112,6 +112,9 @@ class FlatAdamW(torch.optim.Optimizer):
                     self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
                     self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
                     steps.add(int(st["step"]))
+                else:       # no state in the checkpoint (never stepped): fresh moments, not whatever was held before
+                    self.exp_avg[off:off + n].zero_()
+                    self.exp_avg_sq[off:off + n].zero_()
                 off += n
             if len(steps) > 1:
                 raise RuntimeError("FlatAdamW.load_state_dict: parameters with different step counts (one shared "
