@@ -173,14 +173,17 @@ def make_mask3d_step(args, dev, rank, world):
             dist.all_reduce(flat)      # one flat ~158 MB gradient buffer
             flat.div_(w)
         opt.step()
-        sched.step()
+        state["sched"].step()
         if prefetch is not None:
             prefetch.submit([sample])  # the next step's voxelisation + coordinate maps, on a side stream under backward
         return total.detach(), batch[0].coordinates.shape[0]
 
+    state = {"sched": sched}
     step.reducer = reducer
     step.module = module
     step.params = params
+    step.opt = opt
+    step.set_sched = lambda s: state.__setitem__("sched", s)      # tools/det_probe_mr.py restarts the schedule per trial
     return step
 
 

@@ -452,6 +452,67 @@ int usc_attn_bwd(const float* q, const float* k, const float* v,
                  int32_t E, float* dq, float* dk, float* dv, void* ws,
                  int64_t ws_bytes, usc_stream_t s);
 
+/* Self attention of the decoder queries (S = L <= 128 keys, no mask, head dim 16): q, k, v, o, dO, dq, dk, dv
+ * f32[L,B,E] sequence-first, lse f32[B*H,128].  ONE launch each way, one workgroup per (batch, head); every sum
+ * has a fixed order inside the workgroup (bit-reproducible under any load: no cross-workgroup atomics).
+ * Replaces nn.MultiheadAttention's attention core in SelfAttentionLayer (models/mask3d.py:491-545). */
+int usc_self_attn_fwd(const float* q, const float* k, const float* v, int32_t L,
+                      int32_t B, int32_t H, int32_t E, float* o, float* lse,
+                      usc_stream_t s);
+int usc_self_attn_bwd(const float* q, const float* k, const float* v, const float* o,
+                      const float* lse, const float* dO, int32_t L, int32_t B,
+                      int32_t H, int32_t E, float* dq, float* dk, float* dv,
+                      usc_stream_t s);
+
+/* Rectangular linear sum assignment (minimise) of n_prob independent cost matrices f32[n_prob, nr, nc], one wave per
+ * problem, entirely on the device: row_ind / col_ind i64[n_prob, min(nr,nc)] (rows ascending, like scipy), status
+ * i32[n_prob] (0 = solved; 1 = infeasible, i.e. infinite / NaN costs — the indices are then the identity).
+ * The algorithm, its f64 dual updates and its tie-breaking are those of scipy.optimize.linear_sum_assignment
+ * (rectangular_lsap: shortest augmenting paths), so equal costs give scipy's assignment.
+ * Replaces `linear_sum_assignment(C.cpu())` of HungarianMatcher.memory_efficient_forward (models/matcher.py:150-168):
+ * no device->host copy and no host solve in the middle of the training step. */
+int usc_lsap_batch(const float* cost, int32_t n_prob, int32_t nr, int32_t nc,
+                   int64_t* row_ind, int64_t* col_ind, int32_t* status, usc_stream_t s);
+
+/* The set criterion on the device, per scene and for all L <= 16 prediction levels at once (reference
+ * models/matcher.py:98-168 cost matrices; models/criterion.py:22-73, :138-216 losses).  masks[l] / dmasks[l]: the
+ * level's mask logits f32[S, ld] (ld >= Q columns, Q <= 128 queries) and their gradient; logits: class logits
+ * addressed as logits[l*ls_level + q*ls_q + c], c < C; labels i64[T] (253 = ignore), T <= 32 targets.
+ *   usc_criterion_target_bits  tm u8[T,S] -> bits u32[S] (bit t = row s belongs to target t), cnt i32[T] = |tm[t]|
+ *   usc_criterion_costs        cost = w_mask*BCE + w_class*(-p[label]) + w_dice*dice  f32[L,Q,T] (the LSAP input), its
+ *                              parts cmask / cdice [L,Q,T], nmat [L,Q,T] = sum_s sigmoid(x) tm, ssum [L,Q] =
+ *                              sum_s sigmoid(x), logp [L,Q,C] = log softmax (kept for the losses and the backward)
+ *   usc_criterion_losses       src/tid i64[L,T] (usc_lsap_batch) -> part f32[L,4] = (sum w*nll, sum w, mask loss, dice
+ *                              loss) of this scene, tcls i32[L,Q] = target class per query (noobj = C-1 unmatched)
+ *   usc_criterion_table        parts [B,L,4] of the batch's scenes -> table [L,4] = (loss_ce, loss_mask, loss_dice, 0),
+ *                              den_tot [L]
+ *   usc_criterion_backward     gtable = d total / d table [L,4] -> dmasks (full padded width, zero outside the matched
+ *                              columns) and dlogits (same addressing as logits)
+ * Fixed summation order everywhere.  Replaces the torch op chains of HungarianMatcher.memory_efficient_forward and
+ * SetCriterion.loss_labels / loss_masks. */
+int64_t usc_criterion_ws_bytes(int32_t L, int32_t S, int32_t T);
+int usc_criterion_target_bits(const uint8_t* tm, int32_t T, int32_t S, uint32_t* bits,
+                              int32_t* cnt, usc_stream_t s);
+int usc_criterion_costs(const float* const* masks, int32_t L, int32_t ld, int32_t S,
+                        int32_t Q, int32_t T, const uint32_t* bits, const int32_t* cnt,
+                        const float* logits, int64_t ls_level, int64_t ls_q, int32_t C,
+                        const int64_t* labels, float w_mask, float w_class, float w_dice,
+                        float* cost, float* cmask, float* cdice, float* nmat, float* ssum,
+                        float* logp, void* ws, int64_t ws_bytes, usc_stream_t s);
+int usc_criterion_losses(const float* cmask, const float* cdice, const float* logp,
+                         const int64_t* src, const int64_t* tid, const int64_t* labels,
+                         const float* class_w, int32_t L, int32_t Q, int32_t T, int32_t C,
+                         int32_t noobj, int32_t* tcls, float* part, usc_stream_t s);
+int usc_criterion_table(const float* parts, int32_t B, int32_t L, float* table,
+                        float* den_tot, usc_stream_t s);
+int usc_criterion_backward(const float* const* masks, float* const* dmasks, int32_t L,
+                           int32_t ld, int32_t S, int32_t Q, int32_t T, const uint32_t* bits,
+                           const int32_t* cnt, const int64_t* src, const int64_t* tid,
+                           const float* nmat, const float* ssum, const float* logp,
+                           const int32_t* tcls, const float* class_w, const float* gtable,
+                           const float* den_tot, int32_t C, int64_t ls_level, int64_t ls_q,
+                           float* dlogits, usc_stream_t s);
+
 /* Linear layer on a handful of rows (the 100 decoder queries):
  *   y[M,N] = x[M,K] W[N,K]^T + b[N]   (b may be NULL);  N, K multiples of 32.
  * usc_linear_bwd: dx[M,K] = dy W, dW[N,K] = dy^T x, db[N] = column sums of dy; each

@@ -793,6 +793,36 @@ def test_multihead_attention_matches_nn_module(device, S):
         assert rel_err(b, a) < 1e-4
 
 
+@pytest.mark.parametrize("L,B", [(100, 1), (100, 2), (128, 1), (37, 3), (1, 1), (33, 1)])
+def test_self_attention_one_launch(device, L, B):
+    """usc_self_attn_fwd / _bwd (the decoder's SelfAttentionLayer core, reference models/mask3d.py:491-545) against
+    softmax(q k^T / 4) v in f64 on the CPU: output and all three input gradients; and twice the same bits."""
+    from unscene3d_amd import ops
+    H, E = 8, 128
+    g = torch.Generator().manual_seed(L * 7 + B)
+    q, k, v, do = (torch.randn(L, B, E, generator=g) for _ in range(4))
+
+    def ref(q, k, v):
+        qh, kh, vh = (t.double().reshape(L, B * H, 16).transpose(0, 1) for t in (q, k, v))
+        p = torch.softmax(qh @ kh.transpose(1, 2) / 4.0, dim=-1)
+        return (p @ vh).transpose(0, 1).reshape(L, B, E)
+
+    qr, kr, vr = (t.clone().double().requires_grad_(True) for t in (q, k, v))
+    o_ref = ref(qr, kr, vr)
+    o_ref.backward(do.double())
+    qd, kd, vd = (t.to(device).requires_grad_(True) for t in (q, k, v))
+    o = ops.self_attention(qd, kd, vd, H)
+    o.backward(do.to(device))
+    assert rel_err(o.detach(), o_ref.detach()) < 1e-5
+    for got, exp in ((qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+        # (one key: the softmax is constant, dq = dk = 0 exactly in the reference)
+        assert float((got.double().cpu() - exp).norm()) <= 1e-5 * float(exp.norm()) + 1e-6
+    q2, k2, v2 = (t.to(device).requires_grad_(True) for t in (q, k, v))
+    o2 = ops.self_attention(q2, k2, v2, H)
+    o2.backward(do.to(device))
+    assert torch.equal(o2, o) and torch.equal(q2.grad, qd.grad) and torch.equal(k2.grad, kd.grad)
+
+
 @pytest.mark.parametrize("L,S,B", [(100, 3200, 1), (100, 200, 2), (37, 1000, 1), (128, 12800, 1)])
 def test_fused_masked_cross_attention(device, L, S, B):
     """usc_attn_fwd/bwd vs softmax(q k^T / sqrt(hd) + mask) v in float64 (forward and dq, dk, dv), incl. ragged
@@ -1190,3 +1220,76 @@ def test_config5_ncut_second_scene_product_path(device):
         assert c > 0.9999, (it, c)
         signed += 1
     assert signed >= 5
+
+
+def test_device_lsap_equals_scipy_including_ties(device):
+    """usc_lsap_batch vs scipy.optimize.linear_sum_assignment (the reference's solver, models/matcher.py:161-163):
+    the same row / column indices on random, tie-heavy (small integer), all-equal and structured matrices, both
+    orientations, incl. the decoder's [100 queries, T <= 25 targets] shape — the tie-breaking of the augmenting-path
+    scan is part of the result."""
+    from scipy.optimize import linear_sum_assignment
+    from unscene3d_amd import ops
+    rng = np.random.default_rng(5)
+    shapes = [(100, 25), (100, 7), (100, 1), (25, 100), (1, 1), (3, 3), (64, 64), (65, 17), (130, 40), (12, 200)]
+    for nr, nc in shapes:
+        mats = []
+        for kind in range(8):
+            if kind % 4 == 0:
+                c = rng.standard_normal((nr, nc))
+            elif kind % 4 == 1:
+                c = rng.integers(0, 3, (nr, nc))                       # heavy ties
+            elif kind % 4 == 2:
+                c = np.zeros((nr, nc))
+            else:
+                c = rng.integers(0, 6, (nr, nc)) * 0.25 + (rng.random((nr, 1)) < 0.3)
+            mats.append(c.astype(np.float32))
+        cost = torch.from_numpy(np.stack(mats)).to(device)
+        row, col, status = ops.lsap_batch(cost)
+        assert int(status.abs().sum()) == 0
+        for k, c in enumerate(mats):
+            a, b = linear_sum_assignment(c)
+            assert np.array_equal(row[k].cpu().numpy(), a) and np.array_equal(col[k].cpu().numpy(), b), (nr, nc, k)
+    # infeasible / invalid costs are flagged and keep the indices in range
+    bad = torch.full((2, 5, 3), float("inf"), device=device)
+    bad[1] = float("nan")
+    row, col, status = ops.lsap_batch(bad)
+    assert status.tolist() == [1, 1] and int(row.max()) < 5 and int(col.max()) < 3
+
+
+def test_advice_round2_regressions(device):
+    """(a) a model can be deep-copied / pickled after a native forward (the usc_bn descriptor cache lives outside the
+    module); (b) in_proj refuses a positional term that would need broadcasting instead of reading out of bounds;
+    (c) q and k sharing their input but NOT their positional term get separate, correct gradients."""
+    import copy
+    import pickle
+    from types import SimpleNamespace
+
+    from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd import ops
+    from unscene3d_amd.models.res16unet import Res16UNet14
+
+    c = R.coordmap_build(_scene_coords(5, 3000, 10, batch=1))[2]
+    cfg = SimpleNamespace(bn_momentum=0.02, conv1_kernel_size=3, dilations=[1, 1, 1, 1])
+    torch.manual_seed(0)
+    model = Res16UNet14(3, 20, cfg, out_fpn=True).to(device).train()
+    x = ME.SparseTensor(features=torch.randn(len(c), 3, device=device), coordinates=_dev(c, device), device=device)
+    model(x)
+    clone = copy.deepcopy(model)
+    assert sorted(clone.state_dict()) == sorted(model.state_dict())
+    pickle.loads(pickle.dumps(model.cpu()))
+
+    E = 128
+    W = torch.randn(3 * E, E, device=device, requires_grad=True)
+    b = torch.zeros(3 * E, device=device, requires_grad=True)
+    xq = torch.randn(100, 2, E, device=device, requires_grad=True)
+    with pytest.raises(RuntimeError):
+        ops.in_proj(xq, xq, xq, W, b, pos_q=torch.randn(100, 1, E, device=device), pos_k=None)
+    pos = torch.randn(100, 2, E, device=device, requires_grad=True)
+    q, k, v = ops.in_proj(xq, xq, xq, W, b, pos_q=pos, pos_k=None)       # same input, different positional terms
+    (q.sum() * 1.0 + k.sum() * 2.0 + v.sum() * 3.0).backward()
+    xr = xq.detach().clone().requires_grad_(True)
+    pr = pos.detach().clone().requires_grad_(True)
+    Wd = W.detach()
+    ref = ((xr + pr) @ Wd[:E].T).sum() + 2.0 * (xr @ Wd[E:2 * E].T).sum() + 3.0 * (xr @ Wd[2 * E:].T).sum()
+    ref.backward()
+    assert rel_err(xq.grad, xr.grad) < 1e-5 and rel_err(pos.grad, pr.grad) < 1e-5

@@ -167,7 +167,7 @@ def test_config3_full_mask3d_step_loss_and_gradient_parity(device, spatial_sort)
         checked += 1
         if e > worst_dev:
             worst_dev, worst_name = e, name
-    assert checked > 300
+    assert checked > 250, checked
     assert worst_dev < 3 * worst_cpu + REL_TOL, (worst_dev, worst_cpu, worst_name)
     # the groups the verdict names, individually: stem, deepest block, decoder weights
     for prefix in ("backbone.conv0p1s1.", "backbone.block4.", "cross_attention.", "self_attention.", "ffn_attention.",

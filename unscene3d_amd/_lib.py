@@ -117,6 +117,17 @@ SIGNATURES = {
     "usc_attn_ws_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "usc_attn_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p]),
     "usc_attn_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
+    "usc_lsap_batch": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p]),
+    "usc_criterion_ws_bytes": (_i64, [_i32, _i32, _i32]),
+    "usc_criterion_target_bits": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
+    "usc_criterion_costs": (C.c_int, [_p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _i64, _i32, _p, _f32, _f32, _f32,
+                                      _p, _p, _p, _p, _p, _p, _p, _i64, _p]),
+    "usc_criterion_losses": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "usc_criterion_table": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),
+    "usc_criterion_backward": (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                         _i32, _i64, _i64, _p, _p]),
+    "usc_self_attn_fwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p]),
+    "usc_self_attn_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p, _p, _p]),
     "usc_linear_fwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),
     "usc_linear_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     "usc_layernorm_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _p, _p, _p, _p]),

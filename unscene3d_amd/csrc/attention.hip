@@ -332,6 +332,208 @@ __global__ __launch_bounds__(256) void attn_dq_reduce_kernel(AttnParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Self attention of the 100 queries (reference models/mask3d.py:491-545 SelfAttentionLayer): S = L <= 128 keys, no
+// mask.  One launch each way, one workgroup per (batch, head); no partials leave the workgroup, every sum has a
+// fixed order (no float atomics): bit-reproducible at any load.
+//   forward : wave w = query tile w, the <= 4 key chunks in sequence (online softmax), o and lse written directly
+//   backward: wave w = key chunk w (dk, dv of its 32 keys over all query tiles); D = rowsum(dO * o) in the prologue;
+//             the four waves' dq partials are summed through LDS in wave order
+__global__ __launch_bounds__(256) void self_attn_fwd_kernel(AttnParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.x, b = bh / p.H, hh = bh % p.H;
+  const int q0 = wave * 32;
+  if (q0 >= p.L) return;
+  const int64_t rs = (int64_t)p.B * p.E;
+  const int64_t hoff = (int64_t)b * p.E + hh * HD;
+  const bool qok = q0 + i < p.L;
+  float qv[8];
+  {
+    const float* qp = p.q + (int64_t)(qok ? q0 + i : 0) * rs + hoff + 8 * h;
+    const float4 a = *reinterpret_cast<const float4*>(qp), c = *reinterpret_cast<const float4*>(qp + 4);
+    const float t[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) qv[u] = qok ? t[u] * p.scale : 0.f;
+  }
+  f32x16 oT;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oT[r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  for (int key0 = 0; key0 < p.S; key0 += 32) {
+    float kv[8], vT[16];
+    {
+      const int key = key0 + i;
+      const float* kp = p.k + (int64_t)(key < p.S ? key : 0) * rs + hoff + 8 * h;
+      const float4 ka = *reinterpret_cast<const float4*>(kp), kc = *reinterpret_cast<const float4*>(kp + 4);
+      kv[0] = ka.x; kv[1] = ka.y; kv[2] = ka.z; kv[3] = ka.w; kv[4] = kc.x; kv[5] = kc.y; kv[6] = kc.z; kv[7] = kc.w;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int kr = key0 + arow(t, h);
+        vT[t] = (i < HD && kr < p.S) ? p.v[(int64_t)kr * rs + hoff + i] : 0.f;
+      }
+    }
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s = MFMA32(kv[t], qv[t], s);           // [keys x queries]
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool masked = key0 + arow(r, h) >= p.S || !qok;
+      s[r] = masked ? -INFINITY : s[r];
+      mx = fmaxf(mx, s[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_safe);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_safe); psum += s[r]; }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oT[r] *= alpha;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) oT = MFMA32(vT[t], s[t], oT);
+    m_run = m_new;
+  }
+  l_run += __shfl_xor(l_run, 32, 64);
+  if (qok) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* op = p.o + (int64_t)(q0 + i) * rs + hoff;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) op[arow(r, h)] = oT[r] * inv;
+    if (h == 0) p.lse[(int64_t)bh * kMaxL + q0 + i] = l_run > 0.f ? m_run + __logf(l_run) : INFINITY;
+  }
+}
+
+__global__ __launch_bounds__(256) void self_attn_bwd_kernel(AttnParams p, const float* __restrict__ o) {
+  __shared__ float sq[kMaxL][HD + 1], sdo[kMaxL][HD + 1];   // q * scale, dO of this (batch, head)
+  __shared__ float slse[kMaxL], sD[kMaxL];
+  __shared__ float sdq[4][kMaxL][HD];                       // dq partial of every wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int bh = blockIdx.x, b = bh / p.H, hh = bh % p.H;
+  const int64_t rs = (int64_t)p.B * p.E;
+  const int64_t hoff = (int64_t)b * p.E + hh * HD;
+  for (int e = threadIdx.x; e < kMaxL * HD; e += 256) {
+    const int qi = e / HD, d = e % HD;
+    const bool ok = qi < p.L;
+    sq[qi][d] = ok ? p.q[(int64_t)qi * rs + hoff + d] * p.scale : 0.f;
+    sdo[qi][d] = ok ? p.dO[(int64_t)qi * rs + hoff + d] : 0.f;
+  }
+  for (int e = threadIdx.x; e < kMaxL; e += 256) {
+    float dsum = 0.f;
+    if (e < p.L) {
+      const float* dop = p.dO + (int64_t)e * rs + hoff;
+      const float* op = o + (int64_t)e * rs + hoff;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dsum += dop[d] * op[d];
+    }
+    slse[e] = e < p.L ? p.lse[(int64_t)bh * kMaxL + e] : INFINITY;
+    sD[e] = dsum;
+  }
+  __syncthreads();
+  const int ntile = (p.L + 31) >> 5;
+  f32x16 dqT[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqT[t][r] = 0.f;
+  const int key0 = 32 * wave;
+  if (key0 < p.S) {
+    const int key = key0 + i;
+    const bool kok = key < p.S;
+    float kv[8], vv[8], kT[16];
+    {
+      const float* kp = p.k + (int64_t)(kok ? key : 0) * rs + hoff + 8 * h;
+      const float* vp = p.v + (int64_t)(kok ? key : 0) * rs + hoff + 8 * h;
+      const float4 a = *reinterpret_cast<const float4*>(kp), cc = *reinterpret_cast<const float4*>(kp + 4);
+      const float4 e = *reinterpret_cast<const float4*>(vp), g = *reinterpret_cast<const float4*>(vp + 4);
+      const float t1[8] = {a.x, a.y, a.z, a.w, cc.x, cc.y, cc.z, cc.w}, t2[8] = {e.x, e.y, e.z, e.w, g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { kv[u] = kok ? t1[u] : 0.f; vv[u] = kok ? t2[u] : 0.f; }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int kr = key0 + arow(t, h);
+        kT[t] = (i < HD && kr < p.S) ? p.k[(int64_t)kr * rs + hoff + i] : 0.f;
+      }
+    }
+    f32x16 dkT, dvT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkT[r] = 0.f; dvT[r] = 0.f; }
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+      if (tile >= ntile) break;
+      const int q0 = tile * 32;
+      float qv[8], dov[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { qv[u] = sq[q0 + i][8 * h + u]; dov[u] = sdo[q0 + i][8 * h + u]; }
+      {   // [keys x queries]: dq
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { s = MFMA32(kv[t], qv[t], s); dp = MFMA32(vv[t], dov[t], dp); }
+        const float lse_j = slse[q0 + i], D_j = sD[q0 + i];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool masked = q0 + i >= p.L || key0 + arow(r, h) >= p.S;
+          const float pr = masked ? 0.f : __expf(s[r] - lse_j);
+          s[r] = pr * (dp[r] - D_j) * p.scale;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) dqT[tile] = MFMA32(kT[t], s[t], dqT[tile]);
+      }
+      {   // [queries x keys]: dk, dv
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { s = MFMA32(qv[t], kv[t], s); dp = MFMA32(dov[t], vv[t], dp); }
+        f32x16 ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qr = q0 + arow(r, h);
+          const bool masked = !kok || qr >= p.L;
+          const float pr = masked ? 0.f : __expf(s[r] - slse[qr]);
+          s[r] = pr;
+          ds[r] = pr * (dp[r] - sD[qr]);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int qr = q0 + arow(t, h);
+          const float doT = i < HD ? sdo[qr][i] : 0.f;
+          const float qT = i < HD ? sq[qr][i] : 0.f;
+          dvT = MFMA32(doT, s[t], dvT);
+          dkT = MFMA32(qT, ds[t], dkT);
+        }
+      }
+    }
+    if (kok) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        p.dk[(int64_t)key * rs + hoff + arow(r, h)] = dkT[r];
+        p.dv[(int64_t)key * rs + hoff + arow(r, h)] = dvT[r];
+      }
+    }
+  }
+#pragma unroll
+  for (int tile = 0; tile < 4; ++tile) {
+    const int qi = tile * 32 + i;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) sdq[wave][qi][arow(r, h)] = dqT[tile][r];
+  }
+  __syncthreads();
+  const int nw = (p.S + 31) >> 5;               // waves that had a key chunk; the others hold zeros
+  for (int e = threadIdx.x; e < p.L * HD; e += 256) {
+    const int qi = e / HD, d = e % HD;
+    float acc = sdq[0][qi][d];
+    for (int w = 1; w < nw; ++w) acc += sdq[w][qi][d];
+    p.dq[(int64_t)qi * rs + hoff + d] = acc;
+  }
+}
+
 static int pick_splits(int BH, int S) {
   int chunks = (S + 31) / 32;
   int want = (1024 + BH * 4 - 1) / (BH * 4);     // ~1024 waves in flight
@@ -411,6 +613,33 @@ int usc_attn_bwd(const float* q, const float* k, const float* v, const uint8_t* 
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H, p.nsplit), dim3(256), 0, st, p);
   hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)ceil_div((int64_t)B * H * L, 4)), dim3(256), 0, st, p);
   USC_CHECK_LAUNCH("usc_attn_bwd");
+  return USC_OK;
+}
+
+/* self attention (no mask, S = L <= 128): o [L,B,E], lse [B*H,128]; one launch */
+int usc_self_attn_fwd(const float* q, const float* k, const float* v, int32_t L, int32_t B, int32_t H, int32_t E,
+                      float* o, float* lse, usc_stream_t s) {
+  USC_REQUIRE(L >= 1 && L <= kMaxL && B >= 1 && H >= 1 && E == H * HD,
+              "usc_self_attn_fwd: needs head dim 16 and at most 128 queries");
+  USC_REQUIRE(q && k && v && o && lse, "usc_self_attn_fwd: bad argument");
+  AttnParams p{};
+  p.q = q; p.k = k; p.v = v; p.L = L; p.S = L; p.B = B; p.H = H; p.E = E; p.scale = 1.0f / sqrtf((float)HD);
+  p.o = o; p.lse = lse;
+  hipLaunchKernelGGL(self_attn_fwd_kernel, dim3(B * H), dim3(256), 0, as_stream(s), p);
+  USC_CHECK_LAUNCH("usc_self_attn_fwd");
+  return USC_OK;
+}
+
+int usc_self_attn_bwd(const float* q, const float* k, const float* v, const float* o, const float* lse, const float* dO,
+                      int32_t L, int32_t B, int32_t H, int32_t E, float* dq, float* dk, float* dv, usc_stream_t s) {
+  USC_REQUIRE(L >= 1 && L <= kMaxL && B >= 1 && H >= 1 && E == H * HD,
+              "usc_self_attn_bwd: needs head dim 16 and at most 128 queries");
+  USC_REQUIRE(q && k && v && o && lse && dO && dq && dk && dv, "usc_self_attn_bwd: bad argument");
+  AttnParams p{};
+  p.q = q; p.k = k; p.v = v; p.L = L; p.S = L; p.B = B; p.H = H; p.E = E; p.scale = 1.0f / sqrtf((float)HD);
+  p.lse = (float*)lse; p.dO = dO; p.dq = dq; p.dk = dk; p.dv = dv;
+  hipLaunchKernelGGL(self_attn_bwd_kernel, dim3(B * H), dim3(256), 0, as_stream(s), p, o);
+  USC_CHECK_LAUNCH("usc_self_attn_bwd");
   return USC_OK;
 }
 

@@ -53,7 +53,8 @@ class BucketedGradReducer:
     the first step: `expected` is the maximum over ranks and a bucket is eligible only if every one of its parameters
     reports on every rank with the same count.  A gradient write that arrives after its bucket's all-reduce was
     started (more reports than learned) would race with the collective; it is detected, exchanged between the ranks
-    with the next step's collectives and raised on every rank (`RuntimeError`) instead of corrupting the weights.
+    with that step's collectives and raised on every rank two steps later (`RuntimeError`; the flag is read from pinned
+    host memory without a stream synchronisation).
     """
 
     def __init__(self, params, flat, world_size: int, bucket_bytes: int = 24 << 20):
@@ -81,7 +82,7 @@ class BucketedGradReducer:
         self.order, self.cursor = [], 0              # eligible buckets, last first
         self.handles, self.launched = [], []
         self.started_during_backward = 0
-        self._late, self._late_flag, self._late_handle = False, None, None
+        self._late, self._late_flag, self._late_pending = False, None, []
         self._hooks = [p.register_post_accumulate_grad_hook(self.on_grad) for p in self.params]
 
     def install(self):
@@ -121,13 +122,19 @@ class BucketedGradReducer:
         """After backward: reduce what has not been started (same order on every rank), wait, average."""
         import torch.distributed as dist
         self.started_during_backward = sum(self.launched)
-        if self._late_handle is not None:        # last step's flag: long complete by now, no stall
-            self._late_handle.wait()
-            self._late_handle = None
-            if float(self._late_flag.item()) > 0:
+        # Late-write flags of EARLIER steps, each copied to pinned host memory behind its all-reduce.  A .item() on the
+        # device flag here would make the host wait for the whole backward pass before it can queue the remaining
+        # buckets; instead the value of the step before last is read (its copy finished long ago: waiting for it
+        # costs nothing and bounds the host's run-ahead at two steps), at the same step on every rank.
+        lag = 1 if self.flat.is_cuda else 0       # host tensors (tests): nothing runs ahead, look at the last step
+        while len(self._late_pending) > lag:
+            ev, host = self._late_pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            if float(host[0]) > 0:
                 raise RuntimeError("BucketedGradReducer: on some rank a gradient was written after its bucket's "
                                    "all-reduce had started (more writes per step than learned in the first step); "
-                                   "the previous step's gradients are unreliable — rebuild the reducer or set "
+                                   "the gradients of that step are unreliable — rebuild the reducer or set "
                                    "USC3D_OVERLAP_ALLREDUCE=0")
         if self.expected is None:
             # agree across ranks: max count, and eligibility only where min == max > 0 on every rank
@@ -150,8 +157,17 @@ class BucketedGradReducer:
             self._late_flag = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
         self._late_flag.fill_(1.0 if self._late else 0.0)
         self._late = False
-        self._late_handle = dist.all_reduce(self._late_flag, op=dist.ReduceOp.MAX, async_op=True)
+        late_handle = dist.all_reduce(self._late_flag, op=dist.ReduceOp.MAX, async_op=True)
         for h in self.handles:
             h.wait()
         self.flat.div_(self.world)
+        late_handle.wait()                       # stream-ordered for RCCL; a 4-byte host wait for gloo
+        if self._late_flag.is_cuda:
+            host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            host.copy_(self._late_flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._late_pending.append((ev, host))
+        else:
+            self._late_pending.append((None, self._late_flag.clone()))
         return self.flat

@@ -26,6 +26,12 @@ def edge_weights(vertices: torch.Tensor, faces: torch.Tensor, colors: torch.Tens
     ops._chk(colors, torch.float32, "colors")
     ops._chk(faces, torch.int32, "faces")
     V, F = vertices.shape[0], faces.shape[0]
+    if F > 0:
+        # the device kernels dereference the indices: reject a malformed mesh BEFORE the first launch (one small
+        # reduction + read-back; the module's call ends in a host merge anyway)
+        lo, hi = torch.aminmax(faces)
+        if int(lo) < 0 or int(hi) >= V:
+            raise RuntimeError(f"felzenszwalb_cpp: face index out of range [0, {V}) (min {int(lo)}, max {int(hi)})")
     dev = vertices.device
     st = ops._stream
     fn = torch.empty((F, 3), dtype=torch.float32, device=dev)

@@ -5,6 +5,8 @@ sigmoid-BCE + dice on the matched masks, each divided by the number of target ma
 Differences from the reference are organisational only: all 13 levels' cost matrices are built on
 the device first and copied to the host in ONE transfer (the reference syncs 13*B times), then
 scipy solves them; the loss arithmetic and its reduction order follow the reference line by line."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -26,6 +28,95 @@ def sigmoid_ce_loss(inputs, targets, num_masks: float, weights):
 
 dice_loss_jit = dice_loss
 sigmoid_ce_loss_jit = sigmoid_ce_loss
+
+
+FUSED = os.environ.get("USC3D_FUSED_CRITERION", "1") == "1"
+
+
+class _FusedCriterion(torch.autograd.Function):
+    """Matching + losses of all prediction levels on the device (csrc/criterion.hip): per scene the cost matrices of
+    the 13 levels (2 launches), their assignments (usc_lsap_batch, scipy's algorithm and tie-breaking), the label /
+    mask / dice losses (1 launch) — no device->host copy, no host solve — and one table launch for the batch.
+    Inputs: class logits f32[L,B,Q,C] and, per scene and level, the mask logits f32[S_b, ld] (ld >= Q: the padded
+    tables of models.mask3d._mask_logits are taken as they are).  Output: the [L*4] loss table
+    (loss_ce, loss_mask, loss_dice, loss_noise_robust = 0 per level)."""
+
+    @staticmethod
+    def forward(ctx, crit, targets, mask_type, logits, *mask_tables):
+        import ctypes as C
+        from .. import ops
+        from .._lib import check, lib
+        L, B, Q, NC = logits.shape
+        dev = logits.device
+        logits = logits.contiguous()
+        st = ops._stream()
+        m = crit.matcher
+        parts = torch.empty((B, L, 4), dtype=torch.float32, device=dev)
+        scenes = []
+        for b in range(B):
+            tabs = [t.contiguous() for t in mask_tables[b * L:(b + 1) * L]]
+            S, ld = tabs[0].shape
+            tm = targets[b][mask_type]
+            labels = targets[b]["labels"].to(torch.int64).contiguous()
+            T = int(tm.shape[0])
+            tm8 = tm.contiguous().view(torch.uint8) if tm.dtype == torch.bool else (tm != 0).contiguous().view(torch.uint8)
+            bits = torch.empty(S, dtype=torch.int32, device=dev)
+            cnt = torch.empty(T, dtype=torch.int32, device=dev)
+            check(lib.usc_criterion_target_bits(tm8.data_ptr(), T, S, bits.data_ptr(), cnt.data_ptr(), st),
+                  "usc_criterion_target_bits")
+            ptrs = (C.c_void_p * L)(*[t.data_ptr() for t in tabs])
+            cost = torch.empty((L, Q, T), dtype=torch.float32, device=dev)
+            comps = torch.empty((3, L, Q, T), dtype=torch.float32, device=dev)      # cmask | cdice | nmat
+            ssum = torch.empty((L, Q), dtype=torch.float32, device=dev)
+            logp = torch.empty((L, Q, NC), dtype=torch.float32, device=dev)
+            wsb = lib.usc_criterion_ws_bytes(L, S, T)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            lg = logits[:, b]                                                       # [L,Q,C] view: strides (B*Q*C, C, 1)
+            check(lib.usc_criterion_costs(ptrs, L, ld, S, Q, T, bits.data_ptr(), cnt.data_ptr(), lg.data_ptr(),
+                                          B * Q * NC, NC, NC, labels.data_ptr(), float(m.cost_mask), float(m.cost_class),
+                                          float(m.cost_dice), cost.data_ptr(), comps[0].data_ptr(), comps[1].data_ptr(),
+                                          comps[2].data_ptr(), ssum.data_ptr(), logp.data_ptr(), ws.data_ptr(), wsb, st),
+                  "usc_criterion_costs")
+            src, tid, status = ops.lsap_batch(cost)                                 # [L,T] queries (ascending), targets
+            tcls = torch.empty((L, Q), dtype=torch.int32, device=dev)
+            check(lib.usc_criterion_losses(comps[0].data_ptr(), comps[1].data_ptr(), logp.data_ptr(), src.data_ptr(),
+                                           tid.data_ptr(), labels.data_ptr(), crit.empty_weight.data_ptr(), L, Q, T, NC,
+                                           crit.num_classes, tcls.data_ptr(), parts[b].data_ptr(), st),
+                  "usc_criterion_losses")
+            scenes.append(dict(tabs=tabs, S=S, ld=ld, T=T, bits=bits, cnt=cnt, src=src, tid=tid, comps=comps, ssum=ssum,
+                               logp=logp, tcls=tcls, status=status))
+        table = torch.empty((L, 4), dtype=torch.float32, device=dev)
+        den_tot = torch.empty(L, dtype=torch.float32, device=dev)
+        check(lib.usc_criterion_table(parts.data_ptr(), B, L, table.data_ptr(), den_tot.data_ptr(), st),
+              "usc_criterion_table")
+        ctx.scenes, ctx.den_tot, ctx.shape, ctx.class_w = scenes, den_tot, (L, B, Q, NC), crit.empty_weight
+        crit.last_indices = [[(sc["src"][l], sc["tid"][l]) for sc in scenes] for l in range(L)]   # device tensors
+        crit.last_lsap_status = [sc["status"] for sc in scenes]
+        return table.reshape(-1)
+
+    @staticmethod
+    def backward(ctx, dflat):
+        import ctypes as C
+        from .. import ops
+        from .._lib import check, lib
+        L, B, Q, NC = ctx.shape
+        g = dflat.contiguous()
+        dev = g.device
+        st = ops._stream()
+        dlogits = torch.empty((L, B, Q, NC), dtype=torch.float32, device=dev)
+        grads = []
+        for b, sc in enumerate(ctx.scenes):
+            dtab = torch.empty((L, sc["S"], sc["ld"]), dtype=torch.float32, device=dev)
+            ptrs = (C.c_void_p * L)(*[t.data_ptr() for t in sc["tabs"]])
+            dptrs = (C.c_void_p * L)(*[dtab[l].data_ptr() for l in range(L)])
+            check(lib.usc_criterion_backward(ptrs, dptrs, L, sc["ld"], sc["S"], Q, sc["T"], sc["bits"].data_ptr(),
+                                             sc["cnt"].data_ptr(), sc["src"].data_ptr(), sc["tid"].data_ptr(),
+                                             sc["comps"][2].data_ptr(), sc["ssum"].data_ptr(), sc["logp"].data_ptr(),
+                                             sc["tcls"].data_ptr(), ctx.class_w.data_ptr(), g.data_ptr(),
+                                             ctx.den_tot.data_ptr(), NC, B * Q * NC, NC, dlogits[:, b].data_ptr(), st),
+                  "usc_criterion_backward")
+            grads.extend(dtab.unbind(0))
+        return (None, None, None, dlogits, *grads)
 
 
 class LossDict(dict):
@@ -211,9 +302,52 @@ class SetCriterion(nn.Module):
         out.flat = flat
         return out
 
+    def _fused_tables(self, levels, targets, mask_type):
+        """The per-(scene, level) mask-logit tables [S, ld] for the device criterion, or None when the fused path does
+        not apply (CPU tensors, sub-sampled points, drop loss, noise-robust loss, > 32 targets or > 128 queries ...)."""
+        if not (FUSED and self.losses == ["labels", "masks"] and self.num_points == -1 and self.matcher.num_points == -1
+                and self.weight_dict.get("loss_noise_robust", 0) == 0 and not self.use_droploss and targets
+                and 1 <= len(levels) <= 16):
+            return None
+        lg = levels[0]["pred_logits"]
+        if not (lg.is_cuda and lg.dtype == torch.float32 and lg.dim() == 3 and lg.shape[1] <= 128
+                and lg.shape[2] == self.num_classes + 1):
+            return None
+        Q = lg.shape[1]
+        tables = []
+        for b, tgt in enumerate(targets):
+            tm = tgt.get(mask_type)
+            if tm is None or not tm.is_cuda or not (1 <= tm.shape[0] <= min(32, Q)) or "labels" not in tgt:
+                return None
+            ld = None
+            for lv in levels:
+                t = lv["pred_masks"][b]
+                t = getattr(t, "_usc_padded", t)                 # models.mask3d._mask_logits: the padded [S, 128] table
+                if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous()
+                        and Q <= t.shape[1] <= 128 and t.shape[0] == tm.shape[1] and t.shape[1] == (ld or t.shape[1])):
+                    return None
+                ld = t.shape[1]
+                tables.append(t)
+        return tables
+
     def forward(self, outputs, targets, mask_type, coords=None):
         final = {k: v for k, v in outputs.items() if k != "aux_outputs"}
         levels = [final] + list(outputs.get("aux_outputs", []))
+        tables = self._fused_tables(levels, targets, mask_type)
+        if tables is not None:
+            if is_dist_avail_and_initialized():     # the reference's collective (criterion.py:258-260); its result is
+                # never used by the losses (loss_masks overwrites num_masks, :189), so nobody waits for it here
+                nm = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=tables[0].device)
+                torch.distributed.all_reduce(nm)
+            logits = torch.stack([lv["pred_logits"] for lv in levels])                       # [L,B,Q,C]
+            flat = _FusedCriterion.apply(self, targets, mask_type, logits, *tables)
+            out = LossDict()
+            for l in range(len(levels)):
+                sfx = "" if l == 0 else f"_{l - 1}"
+                for j, name in enumerate(("loss_ce", "loss_mask", "loss_dice", "loss_noise_robust")):
+                    out[name + sfx] = flat[4 * l + j]
+            out.flat = flat
+            return out
         all_indices = self.match_all_levels(levels, targets, mask_type)
 
         num_masks = sum(len(t["labels"]) for t in targets)

@@ -407,7 +407,11 @@ def _mask_logits(feats, mask_embed):
     pad = (-Q) % 32
     W = F.pad(mask_embed, (0, 0, 0, pad)) if pad else mask_embed
     out = ops.linear(feats, W.contiguous())
-    return out[:, :Q] if pad else out
+    if not pad:
+        return out
+    view = out[:, :Q]
+    view._usc_padded = out        # the device criterion reads (and differentiates) the padded table directly
+    return view
 
 
 def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None, mask_bsl=None, pos_q=None,
@@ -424,6 +428,10 @@ def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask
     if mask_bsl is not None and hd == 16 and L <= 128:
         # `mask_bsl` = the decoder's bool[B, S, L] mask (same for every head): fused HIP kernels, no score tensor
         out = ops.masked_cross_attention(q, k, v, mask_bsl, H)
+        return ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    if mask_bsl is None and attn_mask is None and hd == 16 and L == S and L <= 128:
+        # the decoder's self attention (100 queries): one HIP launch each way instead of the library's fused kernels
+        out = ops.self_attention(q, k, v, H)
         return ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
     if mask_bsl is not None:
         attn_mask = mask_bsl.repeat_interleave(H, dim=0).permute(0, 2, 1)

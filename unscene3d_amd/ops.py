@@ -980,7 +980,10 @@ class _InProj(torch.autograd.Function):
         def same(a, c):
             return a is not None and c is not None and a.data_ptr() == c.data_ptr() and a.shape == c.shape \
                 and a.stride() == c.stride()
-        ctx.same_qk, ctx.same_kv, ctx.same_pos = same(xq, xk), same(xk, xv), same(pos_q, pos_k)
+        # q and k may share one summed input gradient only if their positional terms are the same too (both absent,
+        # or one tensor) — also when a term was folded into the many-row input above
+        ctx.same_qk, ctx.same_kv = same(xq, xk), same(xk, xv)
+        ctx.same_pos = (pos_q is None and pos_k is None) or same(pos_q, pos_k)
         return tuple(o.view(*shp[:-1], E) for o, shp in zip(outs, ctx.shapes))
 
     @staticmethod
@@ -1004,7 +1007,7 @@ class _InProj(torch.autograd.Function):
         # k first, then q on top of it when they share the input (and the positional term); v last on top of both
         # when it shares the input too: one summed tensor per distinct input
         gk = bwd(1, dk, x1, p1, need[1] or need_pk)
-        chain_q = ctx.same_qk and gk is not None and (p0 is None or ctx.same_pos)
+        chain_q = ctx.same_qk and gk is not None and ctx.same_pos
         gq = bwd(0, dq, x0, p0, need[0] or need_pq, dx_add=gk if chain_q else None)
         if chain_q:                       # gq = d(xq + pos) summed over the q and k paths
             gx, gpos = gq, gq
@@ -1030,6 +1033,12 @@ class _InProj(torch.autograd.Function):
 def in_proj(xq, xk, xv, W, b, pos_q=None, pos_k=None):
     _chk(W, torch.float32, "in_proj_weight")
     _chk(b, torch.float32, "in_proj_bias")
+    # the kernels read the positional term row for row: no broadcasting (a [Q,1,E] term with B > 1 would be read
+    # out of bounds)
+    if pos_q is not None and pos_q.shape != xq.shape:
+        raise RuntimeError(f"in_proj: pos_q {tuple(pos_q.shape)} must have the shape of the query input {tuple(xq.shape)}")
+    if pos_k is not None and pos_k.shape != xk.shape:
+        raise RuntimeError(f"in_proj: pos_k {tuple(pos_k.shape)} must have the shape of the key input {tuple(xk.shape)}")
     return _InProj.apply(xq, xk, xv, W, b, pos_q, pos_k)
 
 
@@ -1071,3 +1080,58 @@ def masked_cross_attention(q, k, v, mask_bsl, num_heads):
     if E != 16 * num_heads or L > 128 or mask_bsl.dtype != torch.bool or tuple(mask_bsl.shape) != (B, k.shape[0], L):
         raise RuntimeError("masked_cross_attention: needs head dim 16, <= 128 queries and a bool[B,S,L] mask")
     return _MaskedCrossAttention.apply(q, k, v, mask_bsl, num_heads)
+
+
+class _SelfAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, num_heads):
+        L, B, E = q.shape
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o = torch.empty_like(q)
+        lse = torch.empty((B * num_heads, 128), dtype=torch.float32, device=q.device)
+        check(lib.usc_self_attn_fwd(_ptr(q), _ptr(k), _ptr(v), L, B, num_heads, E, _ptr(o), _ptr(lse), _stream()),
+              "usc_self_attn_fwd")
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.num_heads = num_heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        L, B, E = q.shape
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        check(lib.usc_self_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(do), L, B, ctx.num_heads, E,
+                                    _ptr(dq), _ptr(dk), _ptr(dv), _stream()), "usc_self_attn_bwd")
+        return dq, dk, dv, None
+
+
+def self_attention(q, k, v, num_heads):
+    """softmax(q k^T / 4) v per head for head dim 16, no mask: q, k, v f32[L,B,E] (sequence-first) with the same
+    L <= 128 — the attention core of the decoder's SelfAttentionLayer (reference models/mask3d.py:491-545), one
+    launch each way, bit-reproducible."""
+    L, B, E = q.shape
+    if E != 16 * num_heads or L > 128 or k.shape != q.shape or v.shape != q.shape:
+        raise RuntimeError("self_attention: needs head dim 16, <= 128 queries and q, k, v of one shape")
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError(f"self_attention: {name} must be an f32 HIP tensor")
+    return _SelfAttention.apply(q, k, v, num_heads)
+
+
+def lsap_batch(cost: torch.Tensor):
+    """scipy.optimize.linear_sum_assignment of every matrix of cost f32[P, nr, nc] on the device ->
+    (row_ind i64[P, m], col_ind i64[P, m], status i32[P]) with m = min(nr, nc); ties resolve like scipy's
+    (usc_lsap_batch).  status != 0 marks an infeasible problem (infinite / NaN costs; scipy raises ValueError there) —
+    it stays on the device: the caller decides when to look."""
+    require_device()
+    _chk(cost, torch.float32, "cost")
+    if cost.dim() != 3:
+        raise RuntimeError("lsap_batch: cost must be f32 [n_problems, nr, nc]")
+    P, nr, nc = cost.shape
+    m = min(nr, nc)
+    row = torch.empty((P, m), dtype=torch.int64, device=cost.device)
+    col = torch.empty((P, m), dtype=torch.int64, device=cost.device)
+    status = torch.empty(max(P, 1), dtype=torch.int32, device=cost.device)
+    check(lib.usc_lsap_batch(_ptr(cost), P, nr, nc, _ptr(row), _ptr(col), _ptr(status), _stream()), "usc_lsap_batch")
+    return row, col, status[:P]

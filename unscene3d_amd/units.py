@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -87,11 +88,16 @@ def workspace(nbytes: int, device):
     return ws
 
 
+# usc_bn descriptors per module, OUTSIDE the module: a ctypes structure inside `bn.__dict__` made copy.deepcopy(model)
+# (EMA copies), torch.save(model) and pickling for spawn fail ("ctypes objects containing pointers cannot be pickled")
+_BN_DESC = weakref.WeakKeyDictionary()
+
+
 def _bn_desc(bn: torch.nn.BatchNorm1d, training: bool):
-    """usc_bn of an nn.BatchNorm1d, cached on the module while its tensors stay where they are."""
+    """usc_bn of an nn.BatchNorm1d, cached per module while its tensors stay where they are."""
     key = (bn.weight.data_ptr(), bn.bias.data_ptr(), 0 if bn.running_mean is None else bn.running_mean.data_ptr(),
            training, bn.momentum, bn.eps)
-    cached = bn.__dict__.get("_usc_desc")
+    cached = _BN_DESC.get(bn)
     if cached is not None and cached[0] == key:
         return cached[1]
     d = BNDesc()
@@ -105,7 +111,7 @@ def _bn_desc(bn: torch.nn.BatchNorm1d, training: bool):
         raise NotImplementedError("cumulative-average batch norm (momentum=None) is not on the hot path")
     d.eps, d.momentum, d.c, d.training = float(bn.eps), float(bn.momentum), bn.num_features, int(training)
     ref = (d, C.byref(d))
-    bn.__dict__["_usc_desc"] = (key, ref)
+    _BN_DESC[bn] = (key, ref)
     return ref
 
 
