@@ -1,6 +1,5 @@
 #!/usr/bin/env python
-"""Bit-reproducibility probe of the full self-training step (developer aid; the regression test that grew out of it
-is tests/test_gpu_determinism.py).
+"""Bit-reproducibility probe of the full self-training step (stress harness of tests/test_gpu_determinism.py).
 
 Runs forward + criterion + backward of ONE fixed batch with FIXED weights and a fixed key-sampling stream `--iters`
 times and compares the loss bits and every parameter gradient's bits with the first iteration.  `--load N` starts N
@@ -13,7 +12,7 @@ import subprocess
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Two-rank trajectory reproducibility probe (developer aid behind tests/test_gpu_determinism.py).
+"""Two-rank trajectory reproducibility probe (stress harness of tests/test_gpu_determinism.py).
 
 Launched with torch.distributed.run --nproc-per-node 2 (ranks share device 0 on a one-GPU box: gloo; RCCL when the box
 has two devices).  Every TRIAL resets weights, optimizer moments, LR schedule and the RNG to the same initial state and
@@ -11,7 +11,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
@@ -40,7 +40,7 @@ def main():
     if a.load and rank == 0:
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
         for _ in range(a.load):
-            kids.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "det_probe.py"), "--child", "--graphs",
+            kids.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "stress", "step_probe.py"), "--child", "--graphs",
                                           "--prefetch", "--iters", "1000000", "--seconds", "100000", "--voxels", "40000"],
                                          env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
     args = bench.parse(["--gpus", str(world), "--voxels", str(a.voxels), "--no-cpu-baseline", "--dist-backend", backend]
