@@ -59,13 +59,20 @@ def parse(argv=None):
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the measured configuration); gloo only to smoke-test the N>1 code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices)")
+    ap.add_argument("--scenes-per-gpu", type=int, default=1, metavar="B",
+                    help="scenes per rank and step (the reference trains with batch_size 5-8 per GPU, conf/data/indoor.yaml:25; "
+                         "the headline metric is quoted at 1): B distinct synthetic scenes collated into one sparse batch, "
+                         "decoder passes captured for batch B")
+    ap.add_argument("--rotate", type=int, default=0, metavar="N",
+                    help="rotate N distinct scene sets (voxel counts spread over +-20 %% of --voxels) through the steps "
+                         "instead of replaying one; per-step times p10/p50/p90 are added to the line")
     ap.add_argument("--voxels-by-rank", default=None, metavar="N0,N1,...",
                     help="scene size per rank (uneven ranks: the step of a small scene is host-bound, that of a large one "
                          "device-bound; the collectives must line up all the same); default: --voxels on every rank")
     ap.add_argument("--eager-ranks", default="", metavar="R0,R1,...",
                     help="ranks that do NOT capture the decoder passes as HIP graphs (mixed eager / graphed ranks)")
     ap.add_argument("--cpu-sample-voxels", type=int, default=10_000,
-                    help="scene size of the cpu_baseline leg (2 x (1 warm-up + 3 timed) passes of the CPU restatement)")
+                    help="scene size of the cpu_baseline legs (3 warm-up + up to 10 timed passes of the CPU restatement each)")
     return ap.parse_args(argv)
 
 
@@ -107,7 +114,8 @@ WORKLOADS = {
                 "per GPU, {nvox} voxels @2cm (voxelise + coordinate/kernel maps rebuilt every step), random-init weights",
     "mask3d": "BASELINE.json configs[2]: full Mask3D self-train step (device collate/voxelise -> Res16UNet34C -> "
               "100-query decoder 3x4 passes -> Hungarian (scipy, host) -> 52 losses -> backward -> AdamW + OneCycleLR), "
-              "one synthetic ScanNet-shaped scene per GPU, {nvox} voxels @2cm, pseudo-mask targets, random-init weights",
+              "{spr} synthetic ScanNet-shaped scene(s) per GPU and step, {nvox} voxels @2cm each, pseudo-mask targets, "
+              "random-init weights",
 }
 
 
@@ -119,7 +127,8 @@ def make_mask3d_step(args, dev, rank, world):
     from unscene3d_amd.ddp import flatten_grads
     from unscene3d_amd.trainer.trainer import InstanceSegmentation
 
-    cfg = apply_overrides(default_config(), ["general.num_targets=3", f"data.batch_size={world}"])
+    B = max(1, args.scenes_per_gpu)
+    cfg = apply_overrides(default_config(), ["general.num_targets=3", f"data.batch_size={world * B}"])
     torch.manual_seed(1234)
     module = InstanceSegmentation(cfg).to(dev).train()
     params = [p for n, p in module.named_parameters() if ".backbone.final." not in n]    # unused in forward
@@ -135,12 +144,20 @@ def make_mask3d_step(args, dev, rank, world):
         by_rank = [int(v) for v in args.voxels_by_rank.split(",")]
         voxels = by_rank[rank % len(by_rank)]
     eager = str(rank) in [r for r in args.eager_ranks.split(",") if r]
-    sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=voxels, seed=2000 + rank)[0]
-    # raw scene arrays resident in HBM before the timed region (the collate reads them from there)
-    sample = tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) if isinstance(x, np.ndarray) and i in (0, 1, 2)
-                   else x for i, x in enumerate(sample))
+    def resident(sample):
+        # raw scene arrays resident in HBM before the timed region (the collate reads them from there)
+        return tuple(torch.from_numpy(np.ascontiguousarray(x)).to(dev) if isinstance(x, np.ndarray) and i in (0, 1, 2)
+                     else x for i, x in enumerate(sample))
+    # scene sets: one per rotation slot, B scenes each; slot 0 of B = 1 is the scene of rounds 1-2 (seed 2000 + rank)
+    n_sets = max(1, args.rotate)
+    sets = []
+    for j in range(n_sets):
+        scale = 1.0 if n_sets == 1 else 0.8 + 0.4 * ((j * 5) % n_sets) / max(1, n_sets - 1)   # spread, not sorted
+        seed = 2000 + rank if (B == 1 and j == 0) else 2000 + 1000 * rank + 16 * j
+        ds = SyntheticFreeMaskDataset(n_scenes=B, target_voxels=int(voxels * scale), seed=seed)
+        sets.append([resident(ds[i]) for i in range(B)])
     if not (args.no_graphs or eager):
-        module.model.enable_decoder_graphs(batch_size=1, device=dev)
+        module.model.enable_decoder_graphs(batch_size=B, device=dev)
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(dev),
                                       spatial_sort=args.spatial_sort)
 
@@ -154,13 +171,15 @@ def make_mask3d_step(args, dev, rank, world):
         from unscene3d_amd.datasets.prefetch import ScenePrefetcher
         prefetch = ScenePrefetcher(collate, add_raw_coordinates=cfg.data.add_raw_coordinates, device=dev,
                                    precompute=module.model.precompute_geometry)
-        prefetch.submit([sample])      # the first batch, outside the timed region like the resident raw arrays
+        prefetch.submit(sets[0])       # the first batch, outside the timed region like the resident raw arrays
+    state = {"k": 0}
 
     def step(w):
+        state["k"] += 1
         if prefetch is not None:
             batch = prefetch.take()
         else:
-            batch = collate([sample])
+            batch = collate(sets[(state["k"] - 1) % n_sets])
         out = module.training_step(batch)
         total, _ = out
         opt.zero_grad(set_to_none=False)
@@ -174,11 +193,12 @@ def make_mask3d_step(args, dev, rank, world):
             flat.div_(w)
         opt.step()
         state["sched"].step()
-        if prefetch is not None:
-            prefetch.submit([sample])  # the next step's voxelisation + coordinate maps, on a side stream under backward
+        if prefetch is not None:       # the next step's voxelisation + coordinate maps, on a side stream under backward
+            prefetch.submit(sets[state["k"] % n_sets])
         return total.detach(), batch[0].coordinates.shape[0]
 
-    state = {"sched": sched}
+    state["sched"] = sched
+    step.scenes_per_rank = B
     step.reducer = reducer
     step.module = module
     step.params = params
@@ -275,11 +295,14 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline_mask3d(sample_voxels, runs=3):
-    """oracle/mask3d_ref.py forward + criterion + backward on one small scene (SURVEY.md §8d "Timing the reference CPU
-    path": ME cannot run, so the baseline is the CPU restatement): one warm-up + `runs` timed passes with all host
-    threads, the same with 3 threads (the reference's scripts export OMP_NUM_THREADS=3,
-    scripts/unsupervised/train_unscene3d.sh:2); median / min / max; value scaled by voxels/150000."""
+def cpu_baseline_mask3d(sample_voxels, runs=10, warmup=3, leg_budget_s=25.0):
+    """oracle/mask3d_ref.py forward + criterion + backward (through every parameter, backbone included) on one small
+    scene (SURVEY.md §8d "Timing the reference CPU path": ME cannot run, so the baseline is the CPU restatement):
+    `warmup` untimed + up to `runs` timed passes per leg — 3 threads (the reference's scripts export
+    OMP_NUM_THREADS=3, scripts/unsupervised/train_unscene3d.sh:2) and all host threads; a leg stops early (never below
+    3 timed passes) once it has used `leg_budget_s` seconds, so that the default bench run stays within minutes on a
+    128-thread host where the restatement's many small torch ops are oversubscribed.  median / p10 / p90 / min / max;
+    value scaled by voxels/150000."""
     import oracle.mask3d_ref as OM
     from oracle import sparse_ref as R
     from unscene3d_amd.config import apply_overrides, default_config, instantiate_model
@@ -323,17 +346,21 @@ def cpu_baseline_mask3d(sample_voxels, runs=3):
 
     all_threads = torch.get_num_threads()
     legs = {}
-    for name, nthr in (("all_threads", all_threads), ("omp3", 3)):
+    for name, nthr in (("omp3", 3), ("all_threads", all_threads)):
         torch.set_num_threads(nthr)
-        one_pass()                                   # warm-up (allocator, thread pool, lazy imports)
+        leg_t0 = time.perf_counter()
+        for _ in range(warmup):                      # allocator, thread pool, lazy imports
+            one_pass()
+            if time.perf_counter() - leg_t0 > leg_budget_s:
+                break
         ts = []
-        for _ in range(runs):
+        while len(ts) < runs and (len(ts) < 3 or time.perf_counter() - leg_t0 < leg_budget_s):
             dt, nv = one_pass()
             ts.append(dt)
         ts.sort()
-        med = ts[len(ts) // 2]
-        legs[name] = {"threads": nthr, "median_s": med, "min_s": ts[0], "max_s": ts[-1],
-                      "scenes_per_s_150k_equiv": (nv / VOXELS) / med}
+        q = lambda f: ts[min(len(ts) - 1, int(round(f * (len(ts) - 1))))]
+        legs[name] = {"threads": nthr, "timed_passes": len(ts), "median_s": q(0.5), "p10_s": q(0.1), "p90_s": q(0.9),
+                      "min_s": ts[0], "max_s": ts[-1], "scenes_per_s_150k_equiv": (nv / VOXELS) / q(0.5)}
     torch.set_num_threads(all_threads)
     best = max(legs.values(), key=lambda l: l["scenes_per_s_150k_equiv"])
     a, o = legs["all_threads"], legs["omp3"]
@@ -343,13 +370,14 @@ def cpu_baseline_mask3d(sample_voxels, runs=3):
         "value": best["scenes_per_s_150k_equiv"],
         "unit": "scenes/s in 150k-voxel-scene equivalents (measured on a smaller scene, scaled by voxels/150000)",
         "cores": best["threads"], "kind": "port", "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
-        "runs": runs, "legs": legs,
+        "runs": best["timed_passes"], "legs": legs,
         "sample": f"oracle Mask3D self-train step (voxelise + maps + Res16UNet34C + decoder + Hungarian + losses, forward "
-                  f"+ backward, no optimizer; CPU restatement, not the reference binary: MinkowskiEngine cannot run "
-                  f"here) on one {nv}-voxel synthetic scene; 1 warm-up + {runs} timed passes per leg; "
-                  f"{a['threads']} threads: median {a['median_s']:.2f} s (min {a['min_s']:.2f}, max {a['max_s']:.2f}); "
-                  f"3 threads (the reference's OMP_NUM_THREADS=3): median {o['median_s']:.2f} s "
-                  f"(min {o['min_s']:.2f}, max {o['max_s']:.2f})",
+                  f"+ backward through all parameters, no optimizer; CPU restatement, not the reference binary: "
+                  f"MinkowskiEngine cannot run here) on one {nv}-voxel synthetic scene; {warmup} warm-up + up to {runs} "
+                  f"timed passes per leg (a leg stops after {leg_budget_s:.0f} s, >= 3 passes); "
+                  f"3 threads (the reference's OMP_NUM_THREADS=3): {o['timed_passes']} passes, median {o['median_s']:.2f} s "
+                  f"(p10 {o['p10_s']:.2f}, p90 {o['p90_s']:.2f}); {a['threads']} threads: {a['timed_passes']} passes, "
+                  f"median {a['median_s']:.2f} s (p10 {a['p10_s']:.2f}, p90 {a['p90_s']:.2f})",
     }
 
 
@@ -493,8 +521,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if args.rotate else None
+    if marks:
+        marks[0].record()
+    for k in range(args.steps):
         loss, nvox = step(world)
+        if marks:
+            marks[k + 1].record()          # device-side step boundaries (no host wait inside the timed loop)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -530,14 +563,22 @@ def main():
     if world > 1:
         ranks_seen = _ranks_seen(dev, rank, world, args.dist_backend, getattr(step, "params", None))
 
+    spr = getattr(step, "scenes_per_rank", 1)
+    rot = None
+    if marks:
+        per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+        q = lambda f: per[min(len(per) - 1, int(round(f * (len(per) - 1))))]
+        rot = {"rotated_scene_sets": args.rotate, "step_ms_p10": q(0.1), "step_ms_p50": q(0.5), "step_ms_p90": q(0.9),
+               "step_ms_min": per[0], "step_ms_max": per[-1]}
     if rank == 0:
         line = {
             "metric": "training scenes/sec (Res16UNet34C+Mask3D, 150k voxels)",
-            "value": world * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "value": world * spr * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.mode].format(nvox=nvox),
-                       "voxels_per_scene": int(nvox), "global_batch": world, "parallelism": f"dp{world}",
+            "config": {"workload": WORKLOADS[args.mode].format(nvox=int(nvox) // spr, spr=spr),
+                       "voxels_per_scene": int(nvox) // spr, "scenes_per_gpu": spr, "global_batch": world * spr,
+                       "parallelism": f"dp{world}", **(rot or {}),
                        "loss": float(loss), "grad_allreduce": _allreduce_note(step, world),
                        **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,

@@ -453,8 +453,9 @@ int usc_attn_bwd(const float* q, const float* k, const float* v,
                  int64_t ws_bytes, usc_stream_t s);
 
 /* Self attention of the decoder queries (S = L <= 128 keys, no mask, head dim 16): q, k, v, o, dO, dq, dk, dv
- * f32[L,B,E] sequence-first, lse f32[B*H,128].  ONE launch each way, one workgroup per (batch, head); every sum
- * has a fixed order inside the workgroup (bit-reproducible under any load: no cross-workgroup atomics).
+ * f32[L,B,E] sequence-first, lse f32[B*H,128].  ONE launch each way (forward: one workgroup per (batch, head);
+ * backward: per (batch, head) one workgroup per query tile for dq and one per key chunk for dk / dv); no partial
+ * sum leaves a workgroup and every sum has a fixed order (bit-reproducible under any load, no atomics).
  * Replaces nn.MultiheadAttention's attention core in SelfAttentionLayer (models/mask3d.py:491-545). */
 int usc_self_attn_fwd(const float* q, const float* k, const float* v, int32_t L,
                       int32_t B, int32_t H, int32_t E, float* o, float* lse,

@@ -78,7 +78,7 @@ coarse, _, parent = ops.coordmap_build(cmap.coords, quant=2, tensor_stride=2)
 nbr2, kidx = ops.kernel_map_down2(cmap, parent, coarse)
 
 stream = ops._stream
-for n, C in ((N, 96), (N, 32), (coarse.n, 96), (9402, 128), (2222, 256), (507, 256)):
+for n, C in ((N, 96), (N, 64), (N, 32), (coarse.n, 96), (9402, 128), (2222, 256), (507, 256)):
     R = copies(4 * n * C)
     x = [torch.randn(n, C, device=dev) for _ in range(R)]
     dy = [torch.randn(n, C, device=dev) for _ in range(R)]
@@ -118,6 +118,15 @@ for n, C in ((N, 96), (N, 32), (coarse.n, 96), (9402, 128), (2222, 256), (507, 2
         idx = torch.randint(0, n, (n,), device=dev)
         rep(f"gather_rows (random rows)          {tag}", 8 * n * C + 8 * n,
             timed([lambda i=i: ops.gather_rows(x[i], idx) for i in range(R)]))
+        # scatter-add of row gradients (the backward of the gather: dst[idx[i]] += src[i]) through a permutation, i.e.
+        # without duplicates, like the decoder's sampled keys: src read + dst read-modify-write + indices
+        perm = torch.randperm(n, device=dev)
+        dst = [torch.zeros(n, C, device=dev) for _ in range(R)]
+
+        def f_scatter(i):
+            check(lib.usc_scatter_add_rows(x[i].data_ptr(), C, perm.data_ptr(), n, dst[i].data_ptr(), stream()))
+        rep(f"scatter_add_rows (permutation)     {tag}", 12 * n * C + 8 * n, timed([lambda i=i: f_scatter(i) for i in range(R)]))
+        del dst
     del x, dy
 R = copies(400 * N)
 m100 = [torch.randn(N, 100, device=dev) for _ in range(R)]

@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <limits.h>
+#include <stdlib.h>
 
 namespace usc {
 namespace {
@@ -58,6 +59,173 @@ __host__ __device__ inline LsapLayout lsap_layout(int nr, int nc, bool stage) {
   return L;
 }
 constexpr int64_t kLsapLdsBudget = 60 * 1024;
+
+// ---- wave reductions on the DPP path (row shifts + row broadcasts: VALU latency; __shfl_xor is two LDS-crossbar trips
+// per level, and a scan step is a chain of three dependent reductions).  A lane without a source keeps its own value
+// (bound_ctrl off, old = own), which is the identity of min / max.
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_keep_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_keep_f64(double x) {
+  const int lo = dpp_keep_i32<CTRL, ROW_MASK>(__double2loint(x)), hi = dpp_keep_i32<CTRL, ROW_MASK>(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+#define USC_DPP_REDUCE(T, OP, DPP, BCAST)                                         \
+  x = OP(x, DPP<0x111, 0xf>(x)); x = OP(x, DPP<0x112, 0xf>(x));                   \
+  x = OP(x, DPP<0x114, 0xf>(x)); x = OP(x, DPP<0x118, 0xf>(x));                   \
+  x = OP(x, DPP<0x142, 0xa>(x)); x = OP(x, DPP<0x143, 0xc>(x));
+__device__ inline int imin(int a, int b) { return a < b ? a : b; }
+__device__ inline int imax(int a, int b) { return a > b ? a : b; }
+__device__ inline double wave_min_f64_dpp(double x) {
+  USC_DPP_REDUCE(double, fmin, dpp_keep_f64, 0)
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+__device__ inline int wave_min_i32_dpp(int x) {
+  USC_DPP_REDUCE(int, imin, dpp_keep_i32, 0)
+  return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ inline int wave_max_i32_dpp(int x) {
+  USC_DPP_REDUCE(int, imax, dpp_keep_i32, 0)
+  return __builtin_amdgcn_readlane(x, 63);
+}
+#undef USC_DPP_REDUCE
+
+// Register-resident variant for nc <= 128 columns (the decoder's 100 queries): lane l owns the columns l and l + 64 —
+// dual variable v, shortest-path cost, assigned row, predecessor and the column's POSITION in scipy's `remaining` list
+// all live in registers; only u, col4row, the visited-row flags and the staged cost matrix are in LDS.  Removing a
+// column (`remaining[index] = remaining[--num]`) = the lane owning the column at the last position takes over `index`.
+// A scan step is then two LDS reads, a handful of f64 operations and three DPP reductions (~400 cycles; the
+// LDS-resident form below needs ~1500).
+__global__ __launch_bounds__(64) void lsap_reg_kernel(const float* __restrict__ cost_all, int nr0, int nc0,
+                                                      int64_t* __restrict__ row_ind, int64_t* __restrict__ col_ind,
+                                                      int32_t* __restrict__ status) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int lane = threadIdx.x;
+  const bool tr = nr0 > nc0;
+  const int nr = tr ? nc0 : nr0, nc = tr ? nr0 : nc0;
+  const float* __restrict__ cost = cost_all + (int64_t)blockIdx.x * nr0 * nc0;
+  const LsapLayout L = lsap_layout(nr, nc, true);
+  double* u = (double*)(lds + L.u);
+  double* spc_l = (double*)(lds + L.spc);       // shortest-path costs of the finished augmentation (for the u update)
+  int* col4row = (int*)(lds + L.col4row);
+  unsigned char* SR = lds + L.SR;
+  float* cm = (float*)(lds + L.cm);
+  int64_t* rout = row_ind + (int64_t)blockIdx.x * nr;
+  int64_t* cout_ = col_ind + (int64_t)blockIdx.x * nr;
+  constexpr int NCL = 2;
+  double v[NCL], spc[NCL];
+  int r4c[NCL], path[NCL], pos[NCL];
+  bool sc[NCL];
+#pragma unroll
+  for (int c = 0; c < NCL; ++c) { v[c] = 0.0; spc[c] = INFINITY; r4c[c] = -1; path[c] = -1; pos[c] = -1; sc[c] = false; }
+  for (int e = lane; e < nr; e += 64) { u[e] = 0.0; col4row[e] = -1; }
+  for (int e = lane; e < nr * nc; e += 64) {
+    const int i = e / nc, j = e - i * nc;
+    cm[e] = tr ? cost[(int64_t)j * nc0 + i] : cost[(int64_t)i * nc0 + j];
+  }
+  __syncthreads();
+  bool infeasible = false;
+  for (int cur = 0; cur < nr && !infeasible; ++cur) {
+    double minVal = 0.0;
+    int num = nc;
+#pragma unroll
+    for (int c = 0; c < NCL; ++c) {
+      const int j = lane + 64 * c;
+      pos[c] = j < nc ? nc - 1 - j : -1;              // remaining[it] = nc - it - 1  <=>  pos(j) = nc - 1 - j
+      spc[c] = INFINITY;
+      sc[c] = false;
+    }
+    for (int e = lane; e < nr; e += 64) SR[e] = 0;
+    __syncthreads();
+    int i = cur, sink = -1;
+    while (sink < 0) {
+      if (lane == 0) SR[i] = 1;
+      const double ui = u[i];
+      const float* crow = cm + i * nc;
+      double lmin = INFINITY;
+      int lfirst = INT_MAX, lastU = -1;
+#pragma unroll
+      for (int c = 0; c < NCL; ++c) {
+        if (pos[c] >= 0) {
+          const double r = ((minVal + (double)crow[lane + 64 * c]) - ui) - v[c];
+          if (r < spc[c]) { path[c] = i; spc[c] = r; }
+          const double sv = spc[c];
+          const bool un = r4c[c] < 0;
+          if (sv < lmin) { lmin = sv; lfirst = pos[c]; lastU = un ? pos[c] : -1; }
+          else if (sv == lmin) { lfirst = imin(lfirst, pos[c]); if (un) lastU = imax(lastU, pos[c]); }
+        }
+      }
+      const double gmin = wave_min_f64_dpp(lmin);
+      if (!(gmin < INFINITY)) { infeasible = true; break; }
+      const bool tied = lfirst != INT_MAX && lmin == gmin;
+      const int gfirst = wave_min_i32_dpp(tied ? lfirst : INT_MAX);
+      const int gU = wave_max_i32_dpp(tied ? lastU : -1);
+      const int index = gU >= 0 ? gU : gfirst;
+      minVal = gmin;
+      // the column at list position `index` (exactly one lane / slot holds it)
+      int mine = -1;
+#pragma unroll
+      for (int c = 0; c < NCL; ++c)
+        if (pos[c] == index) mine = c;
+      const unsigned long long own = __ballot(mine >= 0);
+      const int src = __builtin_ctzll(own);
+      const int j = __builtin_amdgcn_readlane(lane + 64 * (mine < 0 ? 0 : mine), src);
+      const int r4 = __builtin_amdgcn_readlane(mine < 0 ? -1 : r4c[mine], src);
+      // remaining[index] = remaining[--num]: the column at the last position moves to `index`, the chosen one leaves
+      --num;
+#pragma unroll
+      for (int c = 0; c < NCL; ++c) {
+        if (pos[c] == num && num != index) pos[c] = index;
+        else if (pos[c] == index && lane + 64 * c == j) { pos[c] = -1; sc[c] = true; }
+      }
+      if (r4 < 0) sink = j; else i = r4;
+    }
+    if (infeasible) break;
+    // duals: u over the visited rows needs the path costs of their columns (other lanes' registers -> LDS)
+#pragma unroll
+    for (int c = 0; c < NCL; ++c)
+      if (lane + 64 * c < nc) spc_l[lane + 64 * c] = spc[c];
+    __syncthreads();
+    for (int e = lane; e < nr; e += 64) {
+      if (e == cur) u[e] += minVal;
+      else if (SR[e]) u[e] += minVal - spc_l[col4row[e]];
+    }
+#pragma unroll
+    for (int c = 0; c < NCL; ++c)
+      if (sc[c]) v[c] -= minVal - spc[c];
+    __syncthreads();
+    // augment along the path: j -> i = path[j]; row4col[j] = i; swap(col4row[i], j)
+    int j = sink;
+    for (;;) {
+      const int ow = j & 63, oc = j >> 6;
+      const int ii = __builtin_amdgcn_readlane(oc == 0 ? path[0] : path[1], ow);
+      if (lane == ow) { if (oc == 0) r4c[0] = ii; else r4c[1] = ii; }
+      const int t = col4row[ii];
+      __syncthreads();
+      if (lane == 0) col4row[ii] = j;
+      __syncthreads();
+      j = t;
+      if (ii == cur) break;
+    }
+  }
+  if (infeasible) {
+    if (lane == 0) status[blockIdx.x] = 1;
+    for (int e = lane; e < nr; e += 64) { rout[e] = e; cout_[e] = e; }
+    return;
+  }
+  if (lane == 0) status[blockIdx.x] = 0;
+  if (!tr) {
+    for (int e = lane; e < nr; e += 64) { rout[e] = e; cout_[e] = col4row[e]; }
+  } else {
+    for (int e = lane; e < nr; e += 64) {
+      const int q = col4row[e];
+      int rank = 0;
+      for (int t = 0; t < nr; ++t) rank += col4row[t] < q ? 1 : 0;
+      rout[rank] = q;
+      cout_[rank] = e;
+    }
+  }
+}
 
 // one wave = one problem.  nr0 x nc0 = the caller's matrix; internally rows = the smaller side.
 __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost_all, int nr0, int nc0, int stage,
@@ -187,8 +355,13 @@ int usc_lsap_batch(const float* cost, int32_t n_prob, int32_t nr, int32_t nc, in
   LsapLayout L = lsap_layout(r, c, true);
   if (L.total > kLsapLdsBudget) { stage = false; L = lsap_layout(r, c, false); }
   USC_REQUIRE(L.total <= kLsapLdsBudget, "usc_lsap_batch: %d x %d is too large for the one-wave solver (LDS)", nr, nc);
-  hipLaunchKernelGGL(lsap_kernel, dim3(n_prob), dim3(64), (size_t)L.total, as_stream(s), cost, (int)nr, (int)nc,
-                     stage ? 1 : 0, row_ind, col_ind, status);
+  static const bool lds_form = getenv("USC3D_LSAP_LDS") != nullptr;      // A/B switch: the LDS-resident form
+  if (c <= 128 && stage && !lds_form)
+    hipLaunchKernelGGL(lsap_reg_kernel, dim3(n_prob), dim3(64), (size_t)L.total, as_stream(s), cost, (int)nr, (int)nc,
+                       row_ind, col_ind, status);
+  else
+    hipLaunchKernelGGL(lsap_kernel, dim3(n_prob), dim3(64), (size_t)L.total, as_stream(s), cost, (int)nr, (int)nc,
+                       stage ? 1 : 0, row_ind, col_ind, status);
   USC_CHECK_LAUNCH("usc_lsap_batch");
   return USC_OK;
 }

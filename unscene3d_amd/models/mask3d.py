@@ -285,13 +285,22 @@ class Mask3D(nn.Module):
                             (n_scenes, curr_sample_size, pos_encodings_pcd[hlevel][0][0].shape[1]))
                     if tuple(tuple(h) for h in have) != tuple(tuple(w) for w in want):
                         step_fn = self._eager_pass(dec, i)
-                    elif n_scenes == 1 and _GATHER_INTO_GRAPH_INPUTS:
-                        bufs = step_fn.input_buffers        # gather straight into the captured pass's input buffers
+                    elif _GATHER_INTO_GRAPH_INPUTS:
+                        slices = aux[hlevel].coordinate_manager.batch_slices(aux[hlevel]._ts())
+                        if all(isinstance(sl, slice) for sl in slices):      # scenes are contiguous row ranges
+                            bufs = step_fn.input_buffers    # gather straight into the captured pass's input buffers
                 if bufs is not None:
-                    batched_aux = ops.gather_rows(decomposed_aux[0].contiguous(), rand_idx[0], out=bufs[2][0]).unsqueeze(0)
-                    batched_attn = torch.index_select(decomposed_attn[0], 0, rand_idx[0], out=bufs[3][0]).unsqueeze(0)
-                    batched_pos_enc = torch.index_select(pos_encodings_pcd[hlevel][0][0], 0, rand_idx[0],
-                                                         out=bufs[4][0]).unsqueeze(0)
+                    # ONE gather for the whole batch: rows of the level's feature / mask tables addressed by
+                    # scene offset + sampled index, written into the [B, K, .] input buffers of the captured pass
+                    gidx = rand_idx[0] if n_scenes == 1 else torch.cat(
+                        [rand_idx[k] + slices[k].start for k in range(n_scenes)])
+                    feats_l = aux[hlevel].F.contiguous()
+                    batched_aux = ops.gather_rows(feats_l, gidx, out=bufs[2].view(-1, feats_l.shape[1])).view(bufs[2].shape)
+                    batched_attn = torch.index_select(attn_mask.F, 0, gidx,
+                                                      out=bufs[3].view(-1, bufs[3].shape[2])).view(bufs[3].shape)
+                    for k in range(n_scenes):
+                        torch.index_select(pos_encodings_pcd[hlevel][0][k], 0, rand_idx[k], out=bufs[4][k])
+                    batched_pos_enc = bufs[4]
                 else:
                     batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k])
                                           for k in range(n_scenes)])
@@ -301,7 +310,7 @@ class Mask3D(nn.Module):
                 # a query whose sampled keys are all masked attends to everything (reference :346)
                 batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
                 if bufs is not None:
-                    torch.logical_or(batched_attn, mask_idx[0][None, :, None], out=batched_attn)
+                    torch.logical_or(batched_attn, _stack(mask_idx)[..., None], out=batched_attn)
                 else:
                     batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
 
@@ -339,15 +348,29 @@ class Mask3D(nn.Module):
         outputs_class = query_feat if defer_class else self.class_embed_head(query_feat)
 
         output_masks, output_segments = [], []
-        if (point2segment is not None and ret_attn_mask and num_pooling_steps >= 1 and len(mask_segments) == 1
-                and query_feat.is_cuda and _FUSED_ATTN_MASK):
-            # one scene per GPU: the per-voxel logits are rows of the [segments, Q] logits; the first pooling step reads
-            # them through point2segment (no [voxels, Q] table: 59 MB written and read back per call at 150 k voxels)
-            # and the last one applies sigmoid < 0.5 (reference :418-436)
-            output_segments.append(_mask_logits(mask_segments[0], mask_embed[0]))
+        if (point2segment is not None and ret_attn_mask and num_pooling_steps >= 1 and query_feat.is_cuda
+                and _FUSED_ATTN_MASK):
+            # the per-voxel logits are rows of the [segments, Q] logits; the first pooling step reads them through
+            # point2segment (no [voxels, Q] table: 59 MB written and read back per call at 150 k voxels) and the last
+            # one applies sigmoid < 0.5 (reference :418-436).  Several scenes: the segment tables are stacked and the
+            # row index carries each scene's segment offset (the voxel rows of a batch are one table already).
+            for i, seg_feat in enumerate(mask_segments):
+                output_segments.append(_mask_logits(seg_feat, mask_embed[i]))
             cm, ts = mask_features.coordinate_manager, mask_features._ts()
-            pooled = output_segments[0].detach()
-            rows = point2segment[0].to(torch.int64).contiguous()
+            if len(output_segments) == 1:
+                pooled = output_segments[0].detach()
+                rows = point2segment[0].to(torch.int64).contiguous()
+            else:
+                Q = output_segments[0].shape[1]
+                pooled = torch.cat([getattr(o, "_usc_padded", o).detach() for o in output_segments])[:, :Q]
+                rows = getattr(cm, "_usc_p2s_batched", None)
+                if rows is None or rows.shape[0] != mask_features.F.shape[0]:
+                    off, parts = 0, []
+                    for p2s, seg in zip(point2segment, mask_segments):
+                        parts.append(p2s.to(torch.int64) + off)
+                        off += seg.shape[0]
+                    rows = torch.cat(parts).contiguous()
+                    cm._usc_p2s_batched = rows          # geometry only: built once per batch
             for step in range(num_pooling_steps):
                 pooled = ops.avgpool_down2(pooled, cm.stride_map(ts)["nbr2"], row_of=rows if step == 0 else None,
                                            threshold=step == num_pooling_steps - 1)

@@ -4,7 +4,7 @@ process walks all scenes of a split one after the other).
 SURVEY.md §8e: scenes are independent, so the path scales by REPLICAS — no collective.  Two levels:
 
 * across GPUs: rank r of W takes scenes r, r+W, r+2W, ... (`scene_shard`, static sharding by index mod W; ranks are
-  separate processes, e.g. `torchrun --nproc-per-node W tools/pseudo_masks_run.py`, and never talk to each other);
+  separate processes, e.g. `torchrun --nproc-per-node W tools/pseudo_masks_run.py --scenes DIR --out OUT`, and never talk to each other);
 * inside one GPU: `concurrent` scenes at a time, each on its own host thread and its own HIP stream.  One masked-NCut
   loop is a chain of ~20 latency-bound eigen-solves, each a persistent launch of 64 workgroups that keeps a quarter
   of the 256 CUs busy and ends in a small device->host copy (the bipartition logic runs on the host, like the
