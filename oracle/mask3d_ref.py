@@ -70,10 +70,13 @@ def _ln(sd, pfx, d, x):
 
 
 def mask3d_forward(sd: dict, cfg, coords4: np.ndarray, feats: torch.Tensor, raw_xyz: torch.Tensor, point2segment,
-                   randperm, dtype=torch.float32, keep_graph=False):
+                   randperm, dtype=torch.float32, keep_graph=False, attn_hook=None):
     """-> dict(pred_logits, pred_masks, aux_outputs) like the reference; sd = device model state_dict.
     keep_graph: `sd` already holds CPU tensors of `dtype` (leaves with requires_grad): they are used as they are, so
-    that a backward pass from the criterion fills their .grad (full-step gradient / trajectory parity)."""
+    that a backward pass from the criterion fills their .grad (full-step gradient / trajectory parity).
+    attn_hook(pass_index, mask bool[B,K,Q]) -> mask: lets a test look at / replace the thresholded attention mask of a
+    decoder pass — a DISCRETE decision (sigmoid(mean logit) < 0.5, mask3d.py:432-436) that two fp32 evaluation orders
+    may take differently for logits within rounding of zero."""
     m = cfg.model
     d, Q, H = m.hidden_dim, m.num_queries, m.num_heads
     if not keep_graph:
@@ -158,6 +161,8 @@ def mask3d_forward(sd: dict, cfg, coords4: np.ndarray, feats: torch.Tensor, raw_
             b_pos = torch.stack([pos_enc[lvl][b][ridx[b]] for b in range(nb)])
             b_attn.permute(0, 2, 1)[b_attn.sum(1) == K] = False
             b_attn = torch.logical_or(b_attn, torch.stack(midx)[..., None])
+            if attn_hook is not None:
+                b_attn = attn_hook(len(pred_cls), b_attn)
             pfx = f"lin_squeeze.0.{i}."
             src = b_aux.permute(1, 0, 2) @ sd[pfx + "weight"].T + sd[pfx + "bias"]
             ca, sa, ff = f"cross_attention.0.{i}.", f"self_attention.0.{i}.", f"ffn_attention.0.{i}."

@@ -97,8 +97,9 @@ def _setup(device, spatial_sort, overrides=()):
     return cfg, batch, collate, module
 
 
-def _oracle_step(module, cfg, sd, data, target, perm_source, dtype):
-    """Forward + criterion of the CPU restatement on the leaves `sd` (keep_graph) -> (total, {key: weighted loss})."""
+def _oracle_step(module, cfg, sd, data, target, perm_source, dtype, attn_hook=None, forced_indices=None, info=None):
+    """Forward + criterion of the CPU restatement on the leaves `sd` (keep_graph) -> (total, {key: weighted loss}).
+    attn_hook / forced_indices: impose the device run's discrete decisions (attention masks, assignments)."""
     import oracle.mask3d_ref as OM
     from unscene3d_amd.models.criterion import SetCriterion
 
@@ -106,11 +107,15 @@ def _oracle_step(module, cfg, sd, data, target, perm_source, dtype):
     feats = data.features.cpu()
     p2s = [t["point2segment"].cpu() for t in target]
     out_ref = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], p2s, perm_source, dtype=dtype,
-                                keep_graph=True)
+                                keep_graph=True, attn_hook=attn_hook)
     tgt_cpu = [{k: v.cpu() for k, v in t.items()} for t in target]
     crit_cpu = SetCriterion(num_classes=3, matcher=module.criterion.matcher, weight_dict=module.criterion.weight_dict,
                             eos_coef=0.1, losses=["labels", "masks"], num_points=-1, oversample_ratio=3.0,
                             importance_sample_ratio=0.75, class_weights=-1)    # computes in f32 (`.float()`, as the reference)
+    if info is not None:            # the oracle's OWN assignments (before any is imposed)
+        levels = [{k: v for k, v in out_ref.items() if k != "aux_outputs"}] + list(out_ref["aux_outputs"])
+        info["indices"] = crit_cpu.match_all_levels(levels, tgt_cpu, "segment_mask")
+    crit_cpu.forced_indices = forced_indices
     losses_ref = crit_cpu(out_ref, tgt_cpu, mask_type="segment_mask")
     wd = module.criterion.weight_dict
     weighted = {k: v * wd[k] for k, v in losses_ref.items() if k in wd}
@@ -122,34 +127,74 @@ def _leaves(module, dtype):
             .requires_grad_(v.dtype.is_floating_point) for k, v in module.model.state_dict().items()}
 
 
+class _MaskExchange:
+    """attn_hook of the oracle: compares the oracle's own thresholded attention mask of every decoder pass with the
+    device's and hands back the device's, so that both differentiate the SAME piecewise-smooth function."""
+
+    def __init__(self, device_masks):
+        self.dev, self.bits, self.diff = [m.cpu() for m in device_masks], 0, 0
+
+    def __call__(self, k, mask):
+        d = self.dev[k]
+        assert d.shape == mask.shape, (k, d.shape, mask.shape)
+        self.bits += mask.numel()
+        self.diff += int((d != mask).sum())
+        return d
+
+
 @pytest.mark.parametrize("spatial_sort", [False, 5])
 def test_config3_full_mask3d_step_loss_and_gradient_parity(device, spatial_sort):
     """Collate (device voxelisation, with and without the z-order cell permutation bench.py uses) -> Mask3D forward ->
     Hungarian -> 52 losses -> backward, against the CPU restatement driven by the same state_dict and the same sampled
-    indices: collate bit-exact up to the stated permutation, losses < 1e-3, gradients of every parameter no further
-    from the f64 oracle than 3x the f32 oracle is (+1e-3) — the gate of test_config2 (a 34-layer ReLU/BN backward is
-    ill-conditioned in fp32)."""
+    indices: collate bit-exact up to the stated permutation, losses < 1e-3, gradients of every parameter.
+
+    The step contains DISCRETE decisions — the attention masks `sigmoid(mean logit) < 0.5` of the 12 decoder passes
+    (reference models/mask3d.py:432-436) and the 13 x B assignments.  A logit within fp32 rounding of zero flips a mask
+    bit, which switches one key on or off for one query and moves the gradient of everything upstream of the coarse
+    feature maps by ~0.5 % — measured on this very case for the CPU fp32 oracle against the f64 oracle (6.6e-3 without
+    the permutation, 1.6e-4 with it; the device: 6.6e-3 / 4.9e-3, identical for both kernel families).  So the test
+    (1) checks the decisions themselves: the oracle's own masks differ from the device's in < 1e-4 of the bits, its
+    own assignments in at most a few (level, scene) problems, and (2) compares gradients with the device's decisions
+    imposed on the oracle: what is left is smooth, and the gate is tight."""
     cfg, batch, collate, module = _setup(device, spatial_sort)
     data, target, names = collate(batch)
     check_collate(batch, data, target, spatial_sort)
 
     module.model.randperm = PermSource()
+    module.model.attn_mask_record = []
     total, weighted = module.training_step((data, target, names))
     total.backward()
-    assert len(weighted) == 52 and bool(torch.isfinite(total))
+    dev_masks = module.model.attn_mask_record
+    module.model.attn_mask_record = None
+    dev_indices = [[(s_.cpu(), t_.cpu()) for s_, t_ in lv] for lv in module.criterion.last_indices]
+    assert len(weighted) == 52 and bool(torch.isfinite(total)) and len(dev_masks) == 12
 
+    # (a) the oracle on its own: losses, and its discrete decisions against the device's
     sd32 = _leaves(module, torch.float32)
-    total32, w32 = _oracle_step(module, cfg, sd32, data, target, PermSource(), torch.float32)
+    info = {}
+    total32, w32 = _oracle_step(module, cfg, sd32, data, target, PermSource(), torch.float32, info=info)
     assert abs(float(total) - float(total32)) / abs(float(total32)) < REL_TOL, (float(total), float(total32))
     for k, v in weighted.items():
         ref = float(w32[k])
         assert abs(float(v) - ref) <= REL_TOL * max(abs(ref), 1e-3), (k, float(v), ref)
-    total32.backward()
+    problems = differing = 0
+    for lv_dev, lv_ref in zip(dev_indices, info["indices"]):
+        for (sd_, td_), (sr_, tr_) in zip(lv_dev, lv_ref):
+            problems += 1
+            differing += int(not (torch.equal(sd_, sr_) and torch.equal(td_, tr_)))
+    assert problems == 26 and differing <= 3, (differing, problems)      # (identical queries of the first level: ties)
 
-    sd64 = _leaves(module, torch.float64)
-    total64, _ = _oracle_step(module, cfg, sd64, data, target, PermSource(), torch.float64)
-    assert abs(float(total) - float(total64)) / abs(float(total64)) < REL_TOL
-    total64.backward()
+    # (b) gradients with the device's masks and assignments imposed on the oracle, f32 and f64
+    grads = {}
+    for dt in (torch.float32, torch.float64):
+        sd = _leaves(module, dt)
+        ex = _MaskExchange(dev_masks)
+        tot, _ = _oracle_step(module, cfg, sd, data, target, PermSource(), dt, attn_hook=ex, forced_indices=dev_indices)
+        assert ex.bits > 0 and ex.diff <= 1e-4 * ex.bits, (ex.diff, ex.bits)
+        assert abs(float(total) - float(tot)) / abs(float(tot)) < REL_TOL
+        tot.backward()
+        grads[dt] = sd
+    sd32, sd64 = grads[torch.float32], grads[torch.float64]
 
     worst_dev, worst_cpu, worst_name = 0.0, 0.0, None
     checked = 0
@@ -172,22 +217,17 @@ def test_config3_full_mask3d_step_loss_and_gradient_parity(device, spatial_sort)
         if e > worst_dev:
             worst_dev, worst_name = e, name
     assert checked > 250, checked
-    # (1) the whole gradient vector: the device is no further from f64 than 3x the f32 oracle is (+1e-3)
+    # the whole gradient vector, and every single parameter: no further from f64 than 3x the f32 oracle (+1e-3)
     glob_dev, glob_cpu = (num_dev / den) ** 0.5, (num_cpu / den) ** 0.5
     assert glob_dev < 3 * glob_cpu + REL_TOL, (glob_dev, glob_cpu)
-    # (2) every single parameter: within an order of magnitude of the f32 oracle's own worst deviation.  (The worst
-    #     parameter is a kernel of the stride-16 level — ~100 rows here — where ONE ReLU / max decision that differs
-    #     between two fp32 summation orders moves the whole gradient by ~1 %: measured 0.9 % device vs 0.17 % oracle
-    #     with the z-order permutation, 0.3 % vs 0.2 % without; a wrongly permuted target table or a kernel bug gives
-    #     O(1).)
-    assert worst_dev < 10 * worst_cpu + REL_TOL, (worst_dev, worst_cpu, worst_name)
+    assert worst_dev < 3 * worst_cpu + REL_TOL, (worst_dev, worst_cpu, worst_name)
     # the groups the verdict names, individually: stem, deepest block, decoder weights
     for prefix in ("backbone.conv0p1s1.", "backbone.block4.", "cross_attention.", "self_attention.", "ffn_attention.",
                    "lin_squeeze.", "mask_embed_head.", "class_embed_head.", "query_projection."):
         hit = 0
         for name, p in module.model.named_parameters():
             if name.startswith(prefix) and float(sd64[name].grad.norm()) >= 1e-12:
-                assert rel_err(p.grad, sd64[name].grad) < 10 * worst_cpu + REL_TOL, name
+                assert rel_err(p.grad, sd64[name].grad) < 3 * worst_cpu + REL_TOL, name
                 hit += 1
         assert hit > 0, prefix
 

@@ -314,6 +314,9 @@ class Mask3D(nn.Module):
                 else:
                     batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
 
+                rec = getattr(self, "attn_mask_record", None)
+                if rec is not None:          # parity tests: the thresholded masks are discrete decisions
+                    rec.append(batched_attn.detach().clone())
                 queries = step_fn(queries, query_pos, batched_aux.contiguous(), batched_attn.contiguous(),
                                   batched_pos_enc.contiguous())
 

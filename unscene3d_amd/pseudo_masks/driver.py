@@ -5,18 +5,17 @@ SURVEY.md §8e: scenes are independent, so the path scales by REPLICAS — no co
 
 * across GPUs: rank r of W takes scenes r, r+W, r+2W, ... (`scene_shard`, static sharding by index mod W; ranks are
   separate processes, e.g. `torchrun --nproc-per-node W tools/pseudo_masks_run.py --scenes DIR --out OUT`, and never talk to each other);
-* inside one GPU: `concurrent` scenes at a time, each on its own host thread and its own HIP stream.  One masked-NCut
-  loop is a chain of ~20 latency-bound eigen-solves, each a persistent launch of 64 workgroups that keeps a quarter
-  of the 256 CUs busy and ends in a small device->host copy (the bipartition logic runs on the host, like the
-  reference's); the GIL is released while a thread waits for its copy.  Measured on the 625-segment bench scene
-  (`bench.py --mode ncut --scenes K`): 6.0 scenes/s with one scene in flight, 9.7 with two, 6.3 with four, 5.3 with
-  six — beyond two, the persistent launches (64 spinning workgroups each) starve the short kernels between them and
-  the host threads queue on the interpreter lock.  Default: two.
+* inside one GPU: `concurrent` scenes in flight, each on its own HIP stream, driven by ONE host thread.  A scene's
+  masked-NCut loop is a chain of ~20 latency-bound eigen-solves (each a persistent launch of 64 workgroups = a quarter
+  of the 256 CUs) separated by a small device->host copy and some S-sized host logic; `ncut.unscene3d_steps` is that
+  loop as a generator which yields at the copy, so the scheduler here resumes whichever scene's eigenvector has
+  arrived, does its host logic, queues its next iteration and moves on — the other scenes' solves keep the GPU busy
+  meanwhile.  (Round 2 gave every scene its own host THREAD: 6.0 scenes/s with one scene in flight, 9.7 with two,
+  6.3 with four — the threads queued on the interpreter lock.  Round 3: the per-iteration host logic lost its 6 ms
+  rebuild of the neighbour sets, and the scenes share one thread.)  Default: three in flight (192 of the 256 CUs
+  hold persistent solves, the rest serve the short affinity kernels).
 """
 from __future__ import annotations
-
-import threading
-from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -30,48 +29,81 @@ def scene_shard(n_scenes: int, rank: int = 0, world: int = 1):
     return list(range(rank, n_scenes, world))
 
 
+NCUT_DEFAULTS = dict(affinity_tau=0.6, max_number_of_instances=20, min_segment_size=4, separation_mode="max",
+                     max_extent_ratio=0.8)
+
+
 def default_scene_fn(scene, **kw):
     """scene: dict with `features` (tensor [S,d] or a tuple of two), `unique_segments`, `seg_connectivity` (directed
     pairs) -> bool[K, S] masks over segments (ncut.unscene3d with the published settings unless overridden)."""
-    args = dict(affinity_tau=0.6, max_number_of_instances=20, min_segment_size=4, separation_mode="max",
-                max_extent_ratio=0.8)
+    args = dict(NCUT_DEFAULTS)
     args.update(kw)
     return ncut.unscene3d(scene["features"], scene["unique_segments"], scene["seg_connectivity"], **args)
 
 
+def default_scene_steps(scene, **kw):
+    """The same as a generator (ncut.unscene3d_steps): yields the event of every eigenvector copy."""
+    args = dict(NCUT_DEFAULTS)
+    args.update(kw)
+    return ncut.unscene3d_steps(scene["features"], scene["unique_segments"], scene["seg_connectivity"], **args)
+
+
 class PseudoMaskDriver:
-    def __init__(self, device="cuda", concurrent: int = 2, rank: int = 0, world: int = 1, scene_fn=default_scene_fn):
+    def __init__(self, device="cuda", concurrent: int = 3, rank: int = 0, world: int = 1, scene_fn=None,
+                 scene_steps=default_scene_steps):
+        """scene_steps(scene, **kw) -> generator yielding torch.cuda.Event (the default: the masked-NCut loop);
+        scene_fn(scene, **kw) -> masks: a plain function instead (then every scene runs to completion on its stream,
+        `concurrent` has no effect)."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("the pseudo-mask generator runs on the HIP device; there is no CPU path")
-        self.concurrent, self.rank, self.world, self.scene_fn = max(1, int(concurrent)), rank, world, scene_fn
+        self.concurrent, self.rank, self.world = max(1, int(concurrent)), rank, world
+        self.scene_fn, self.scene_steps = scene_fn, scene_steps
         self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.concurrent)]
-        self._free = list(range(self.concurrent))
-        self._lock = threading.Lock()
-
-    def _run_one(self, scene, kw):
-        with self._lock:
-            slot = self._free.pop()
-        try:
-            torch.cuda.set_device(self.device)                 # the current device is per host thread
-            with torch.cuda.stream(self._streams[slot]):
-                out = self.scene_fn(scene, **kw)
-            self._streams[slot].synchronize()
-            return out
-        finally:
-            with self._lock:
-                self._free.append(slot)
 
     def run(self, scenes, **kw):
         """scenes: sequence (the WHOLE split; this rank takes its shard).  -> {scene index: masks} for this rank."""
         mine = scene_shard(len(scenes), self.rank, self.world)
         if not mine:
             return {}
+        torch.cuda.set_device(self.device)
         main = torch.cuda.current_stream(self.device)
         for st in self._streams:                               # inputs may have been produced on the caller's stream
             st.wait_stream(main)
-        if self.concurrent == 1:
-            return {i: self._run_one(scenes[i], kw) for i in mine}
-        with ThreadPoolExecutor(max_workers=self.concurrent) as pool:
-            futures = {i: pool.submit(self._run_one, scenes[i], kw) for i in mine}
-            return {i: f.result() for i, f in futures.items()}
+        out = {}
+        if self.scene_fn is not None:
+            for n, i in enumerate(mine):
+                with torch.cuda.stream(self._streams[n % self.concurrent]):
+                    out[i] = self.scene_fn(scenes[i], **kw)
+            for st in self._streams:
+                st.synchronize()
+            return out
+        todo = list(mine)
+        slots = {}                                             # stream slot -> (scene index, generator, pending event)
+
+        def advance(slot, i, gen):
+            """Resume scene i on its stream until its next copy event (or its end)."""
+            with torch.cuda.stream(self._streams[slot]):
+                try:
+                    slots[slot] = (i, gen, next(gen))
+                except StopIteration as done:
+                    out[i] = done.value
+                    slots.pop(slot, None)
+                    if todo:
+                        j = todo.pop(0)
+                        advance(slot, j, self.scene_steps(scenes[j], **kw))
+
+        for slot in range(min(self.concurrent, len(todo))):
+            j = todo.pop(0)
+            advance(slot, j, self.scene_steps(scenes[j], **kw))
+        while slots:
+            ready = [sl for sl, (_, _, ev) in slots.items() if ev.query()]
+            if not ready:                                      # nothing has arrived: wait for the oldest request
+                sl = next(iter(slots))
+                slots[sl][2].synchronize()
+                ready = [sl]
+            for sl in ready:
+                i, gen, _ = slots[sl]
+                advance(sl, i, gen)
+        main.wait_stream(self._streams[0])
+        return out

@@ -88,24 +88,59 @@ def second_smallest_eigenvector(A, D, eps=1e-5):
     return np.copy(vec), vec
 
 
+def second_smallest_eigenvector_async(A, D, eps=1e-5):
+    """The same solve without waiting for it: -> (pinned host f64[S], event).  The vector is valid once the event has
+    fired (`event.synchronize()`); nothing else on the host waits, so several scenes' solves can be in flight on
+    their own streams from ONE host thread (`unscene3d_steps`)."""
+    S = A.shape[0]
+    evec = torch.empty(S, dtype=torch.float64, device=A.device)
+    evals = torch.empty(2, dtype=torch.float64, device=A.device)
+    ws = torch.empty(lib.usc_ncut_fiedler_ws_bytes(S), dtype=torch.uint8, device=A.device)
+    check(lib.usc_ncut_fiedler(A.data_ptr(), D.data_ptr(), S, float(eps), evec.data_ptr(), evals.data_ptr(),
+                               ws.data_ptr(), ws.numel(), ops._stream()), "usc_ncut_fiedler")
+    host = torch.empty(S, dtype=torch.float64).pin_memory()
+    host.copy_(evec, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return host, ev, (evec, evals, ws)         # the device buffers stay referenced until the copy has run
+
+
 def get_salient_areas(second_smallest_vec):
     avg = np.sum(second_smallest_vec) / len(second_smallest_vec)
     return second_smallest_vec > avg
 
 
-def separate_segments(bipartition, second_smallest_vec, unique_segments, seg_connectivity, mode="max"):
-    """Connected blobs of the foreground side under the directed `seg_connectivity` pairs, merged in the
-    reference's scan order (:181-250); returns the blob selected by `mode` as a set of segment ids."""
+def neighbour_sets(unique_segments, seg_connectivity):
+    """{segment id: set of the ids it points to} for the directed `seg_connectivity` pairs — geometry of the scene, the
+    same in every iteration of the cut loop (the reference rebuilds it per call, :181-190: S boolean masks over E pairs,
+    6 of the 7 ms a call took on the 625-segment scene)."""
     uniq = np.asarray(unique_segments.cpu() if isinstance(unique_segments, torch.Tensor) else unique_segments)
     conn = np.asarray(seg_connectivity.cpu() if isinstance(seg_connectivity, torch.Tensor) else seg_connectivity)
-    neighbours = {int(s): set(conn[conn[:, 0] == s, 1].tolist()) for s in uniq}
+    out = {int(s): set() for s in uniq}
+    if conn.size:
+        order = np.argsort(conn[:, 0], kind="stable")
+        src, dst = conn[order, 0], conn[order, 1]
+        cuts = np.nonzero(np.diff(src))[0] + 1
+        for s0, chunk in zip(src[np.concatenate([[0], cuts])].tolist(), np.split(dst, cuts)):
+            if s0 in out:
+                out[s0] = set(chunk.tolist())
+    return out
+
+
+def separate_segments(bipartition, second_smallest_vec, unique_segments, seg_connectivity, mode="max", neighbours=None):
+    """Connected blobs of the foreground side under the directed `seg_connectivity` pairs, merged in the
+    reference's scan order (:181-250); returns the blob selected by `mode` as a set of segment ids.
+    `neighbours`: neighbour_sets(unique_segments, seg_connectivity), when the caller keeps it across iterations."""
+    uniq = np.asarray(unique_segments.cpu() if isinstance(unique_segments, torch.Tensor) else unique_segments)
+    if neighbours is None:
+        neighbours = neighbour_sets(uniq, seg_connectivity)
     fg_ids = uniq[bipartition]
     blobs = []
     for c in fg_ids:
         nb = neighbours[int(c)]
         last, merged, k = -1, False, 0
         while k < len(blobs):
-            if nb & blobs[k]:
+            if not nb.isdisjoint(blobs[k]):
                 merged = True
                 blobs[k].add(int(c))
                 if last != -1:
@@ -162,6 +197,53 @@ def aggregate_features(encoded_features, segment_ids, seg_connectivity, aggregat
     return agg, unique_segments
 
 
+def unscene3d_steps(aggregated_features, unique_segments, seg_connectivity, segment_ids=None, scene_coords=None,
+                    scene_colors=None, affinity_tau=0.65, max_number_of_instances=20, similarity_metric="cos",
+                    max_extent_ratio=0.8, max_surface_ratio=0.3, eps=1e-5, min_segment_size=4, separation_mode="max",
+                    eigvec_hook=None):
+    """The masked-NCut loop of `unscene3d` as a generator: it queues one iteration's device work (affinity, degree,
+    generalized eigenvector, copy to pinned memory) on the CURRENT stream, yields the event that marks the eigenvector's
+    arrival on the host, and — resumed after that event — does the iteration's host logic and queues the next one.
+    `StopIteration.value` is the bool[K, S] result.  One host thread can keep several scenes in flight, each on its own
+    stream (pseudo_masks/driver.py), without the scenes' host logic fighting over the interpreter lock."""
+    num_segments = len(unique_segments)
+    if num_segments < 3:
+        return np.ones(num_segments, dtype=bool).reshape(1, -1)
+    feats = aggregated_features
+    dev = (feats[0] if isinstance(feats, tuple) else feats).device
+    neighbours = neighbour_sets(unique_segments, seg_connectivity)
+    bipartitions, foreground = [], set()
+    painting = torch.zeros(num_segments, device=dev)
+    current_mask = None
+    for it in range(max_number_of_instances):
+        if it > 0:
+            feats, painting = get_masked_affinity_matrix(painting, feats, current_mask)
+        A, D = get_affinity_matrix(feats, tau=affinity_tau, eps=eps, normalize_sim=True,
+                                   similarity_metric=similarity_metric, painting=painting.bool())
+        host, event, keep = second_smallest_eigenvector_async(A, D, eps)
+        yield event
+        event.synchronize()
+        vec = host.numpy().copy()
+        del keep
+        if eigvec_hook is not None:
+            vec = eigvec_hook(it, vec)
+        bipartition = get_salient_areas(vec)
+        if bipartition.sum() / len(bipartition) > max_extent_ratio:
+            bipartition = np.logical_not(bipartition)
+            vec = vec * -1
+        part = separate_segments(bipartition, vec, unique_segments, seg_connectivity, mode=separation_mode,
+                                 neighbours=neighbours)
+        part_mask = torch.as_tensor(segment_ids_to_mask(part, unique_segments), device=dev)
+        current_mask = part_mask
+        if len(part & foreground) / len(part) > 0.5:
+            continue
+        if len(part) < min_segment_size:
+            continue
+        bipartitions.append(segment_ids_to_mask(part - foreground, unique_segments))
+        foreground |= part
+    return np.stack(bipartitions) if bipartitions else np.zeros((0, num_segments), dtype=bool)
+
+
 def unscene3d(aggregated_features, unique_segments, seg_connectivity, segment_ids=None, scene_coords=None,
               scene_colors=None, affinity_tau=0.65, max_number_of_instances=20, similarity_metric="cos",
               max_extent_ratio=0.8, max_surface_ratio=0.3, eps=1e-5, min_segment_size=4, separation_mode="max",
@@ -172,33 +254,11 @@ def unscene3d(aggregated_features, unique_segments, seg_connectivity, segment_id
     parity tests use it to impose the sign LAPACK happened to return in the reference run: that sign is
     rounding noise whenever painted (isolated) segments exist and is not reproducible even between two
     scipy installations, yet it steers balanced cuts (0.2 <= foreground ratio <= 0.8)."""
-    num_segments = len(unique_segments)
-    if num_segments < 3:
-        return np.ones(num_segments, dtype=bool).reshape(1, -1)
-    feats = aggregated_features
-    dev = (feats[0] if isinstance(feats, tuple) else feats).device
-    bipartitions, foreground = [], set()
-    painting = torch.zeros(num_segments, device=dev)
-    current_mask = None
-    for it in range(max_number_of_instances):
-        if it > 0:
-            feats, painting = get_masked_affinity_matrix(painting, feats, current_mask)
-        A, D = get_affinity_matrix(feats, tau=affinity_tau, eps=eps, normalize_sim=True,
-                                   similarity_metric=similarity_metric, painting=painting.bool())
-        _, vec = second_smallest_eigenvector(A, D, eps)
-        if eigvec_hook is not None:
-            vec = eigvec_hook(it, vec)
-        bipartition = get_salient_areas(vec)
-        if bipartition.sum() / len(bipartition) > max_extent_ratio:
-            bipartition = np.logical_not(bipartition)
-            vec = vec * -1
-        part = separate_segments(bipartition, vec, unique_segments, seg_connectivity, mode=separation_mode)
-        part_mask = torch.as_tensor(segment_ids_to_mask(part, unique_segments), device=dev)
-        current_mask = part_mask
-        if len(part & foreground) / len(part) > 0.5:
-            continue
-        if len(part) < min_segment_size:
-            continue
-        bipartitions.append(segment_ids_to_mask(part - foreground, unique_segments))
-        foreground |= part
-    return np.stack(bipartitions) if bipartitions else np.zeros((0, num_segments), dtype=bool)
+    gen = unscene3d_steps(aggregated_features, unique_segments, seg_connectivity, segment_ids, scene_coords,
+                          scene_colors, affinity_tau, max_number_of_instances, similarity_metric, max_extent_ratio,
+                          max_surface_ratio, eps, min_segment_size, separation_mode, eigvec_hook)
+    try:
+        while True:
+            next(gen).synchronize()
+    except StopIteration as done:
+        return done.value
