@@ -182,4 +182,4 @@ def mask3d_forward(sd: dict, cfg, coords4: np.ndarray, feats: torch.Tensor, raw_
     pred_masks.append(segs)
     return {"pred_logits": pred_cls[-1], "pred_masks": pred_masks[-1],
             "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(pred_cls[:-1], pred_masks[:-1])],
-            "backbone_features": pcd}
+            "backbone_features": pcd, "backbone_levels": aux}

@@ -19,6 +19,8 @@
 // no neighbour in the wave's 32 rows are skipped with a wave-uniform ballot.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace usc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -942,6 +944,10 @@ static int wgrad_full_ct(int ctiles, int NBf) {
 static int64_t wgrad_full_splits(int K, int ctiles, int cb, int CT, int NBf, int64_t n_rows) {
   const int64_t blocks_per_split = (int64_t)K * (ctiles / CT) * (cb / NBf);
   int64_t S = 512 / blocks_per_split;                         // one round of 2 workgroups per CU
+  // USC3D_WGRAD_ONE_SLICE_FROM=<blocks>: no pair split (and no reduction launch) once a single slice already has that
+  // many workgroups (experiment knob)
+  static const int one_from = getenv("USC3D_WGRAD_ONE_SLICE_FROM") ? atoi(getenv("USC3D_WGRAD_ONE_SLICE_FROM")) : 0;
+  if (one_from > 0 && blocks_per_split >= one_from) S = 1;
   const int64_t by_rows = n_rows / (K > 1 ? 4096 : 256) + 1;   // identity pairs (dense layers): 64 rows per wave suffice
   if (S > by_rows) S = by_rows;
   if (S > 64) S = 64;

@@ -223,7 +223,9 @@ class Mask3D(nn.Module):
                 queries = self.np_feature_projection(queries)
             else:
                 queries = torch.zeros_like(query_pos).permute(0, 2, 1)
-            query_pos = query_pos.permute(2, 0, 1)
+            # [Q, B, d] materialised ONCE: every pass adds it to its queries / keys (an eager pass would otherwise make
+            # its own contiguous copy three times, 36 small copies per step)
+            query_pos = query_pos.permute(2, 0, 1).contiguous()
         elif self.random_queries:
             query_pos = torch.rand(n_scenes, self.mask_dim, self.num_queries, device=x.device) - 0.5
             queries = torch.zeros_like(query_pos).permute(0, 2, 1)

@@ -67,11 +67,12 @@ def get_affinity_matrix(feats, tau=0.15, eps=1e-5, normalize_sim=True, similarit
 def get_masked_affinity_matrix(painting, feats, mask):
     """Zero the features of painted segments (reference :122-135)."""
     S = feats[0].shape[0] if isinstance(feats, tuple) else feats.shape[0]
-    painting = ((painting.view(S, 1).float() + mask.view(S, 1).float()) > 0).float()
+    painting = torch.logical_or(painting.view(S, 1) > 0, mask.view(S, 1) > 0).float()
+    keep = 1 - painting                       # exactly 0 or 1: (1 - painting) * f as in the reference
     if isinstance(feats, tuple):
-        feats = tuple((1 - painting) * f for f in feats)
+        feats = tuple(keep * f for f in feats)
     else:
-        feats = (1 - painting) * feats
+        feats = keep * feats
     return feats, painting.squeeze()
 
 
@@ -88,7 +89,7 @@ def second_smallest_eigenvector(A, D, eps=1e-5):
     return np.copy(vec), vec
 
 
-def second_smallest_eigenvector_async(A, D, eps=1e-5):
+def second_smallest_eigenvector_async(A, D, eps=1e-5, host=None):
     """The same solve without waiting for it: -> (pinned host f64[S], event).  The vector is valid once the event has
     fired (`event.synchronize()`); nothing else on the host waits, so several scenes' solves can be in flight on
     their own streams from ONE host thread (`unscene3d_steps`)."""
@@ -98,7 +99,8 @@ def second_smallest_eigenvector_async(A, D, eps=1e-5):
     ws = torch.empty(lib.usc_ncut_fiedler_ws_bytes(S), dtype=torch.uint8, device=A.device)
     check(lib.usc_ncut_fiedler(A.data_ptr(), D.data_ptr(), S, float(eps), evec.data_ptr(), evals.data_ptr(),
                                ws.data_ptr(), ws.numel(), ops._stream()), "usc_ncut_fiedler")
-    host = torch.empty(S, dtype=torch.float64).pin_memory()
+    if host is None or host.numel() != S:
+        host = torch.empty(S, dtype=torch.float64).pin_memory()     # callers in a loop pass their buffer back in
     host.copy_(evec, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
@@ -135,22 +137,37 @@ def separate_segments(bipartition, second_smallest_vec, unique_segments, seg_con
     if neighbours is None:
         neighbours = neighbour_sets(uniq, seg_connectivity)
     fg_ids = uniq[bipartition]
-    blobs = []
-    for c in fg_ids:
-        nb = neighbours[int(c)]
-        last, merged, k = -1, False, 0
+    # The reference scans ALL blobs for every foreground id (:196-216): the first blob its neighbour set touches takes
+    # the id, later touching blobs are merged into that one — with the scan's quirk that the blob right after a merged
+    # (popped) one is skipped.  `owner` (id -> its blob) finds the touching blobs directly; only an id that touches two
+    # or more blobs needs the reference's positional scan.  Same partition, same blob order.
+    blobs, owner = [], {}
+    for c in fg_ids.tolist():
+        nb = neighbours[c]
+        touching = {id(owner[x]) for x in nb if x in owner}
+        if not touching:
+            blob = {c}
+            blobs.append(blob)
+            owner[c] = blob
+            continue
+        if len(touching) == 1:
+            blob = owner[next(x for x in nb if x in owner)]
+            blob.add(c)
+            owner[c] = blob
+            continue
+        last, k = -1, 0
         while k < len(blobs):
             if not nb.isdisjoint(blobs[k]):
-                merged = True
-                blobs[k].add(int(c))
+                blobs[k].add(c)
+                owner[c] = blobs[k]
                 if last != -1:
-                    blobs[last] = blobs[last] | blobs[k]
+                    blobs[last] |= blobs[k]
+                    for x in blobs[k]:
+                        owner[x] = blobs[last]
                     blobs.pop(k)
                 else:
                     last = k
             k += 1
-        if not merged:
-            blobs.append({int(c)})
     if mode == "max":
         seed_id = int(uniq[int(np.argmax(second_smallest_vec))])
         return next(b for b in blobs if seed_id in b)
@@ -214,13 +231,13 @@ def unscene3d_steps(aggregated_features, unique_segments, seg_connectivity, segm
     neighbours = neighbour_sets(unique_segments, seg_connectivity)
     bipartitions, foreground = [], set()
     painting = torch.zeros(num_segments, device=dev)
-    current_mask = None
+    current_mask, host = None, None
     for it in range(max_number_of_instances):
         if it > 0:
             feats, painting = get_masked_affinity_matrix(painting, feats, current_mask)
         A, D = get_affinity_matrix(feats, tau=affinity_tau, eps=eps, normalize_sim=True,
                                    similarity_metric=similarity_metric, painting=painting.bool())
-        host, event, keep = second_smallest_eigenvector_async(A, D, eps)
+        host, event, keep = second_smallest_eigenvector_async(A, D, eps, host=host)
         yield event
         event.synchronize()
         vec = host.numpy().copy()
