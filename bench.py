@@ -43,7 +43,7 @@ def parse(argv=None):
                     help="mask3d: BASELINE.json configs[2] full self-train step (the metric's config); "
                          "backbone: configs[1] Res16UNet34C fwd+bwd only; "
                          "ncut: configs[4] masked-NCut pseudo-mask loop on a 625-segment scene (secondary metric)")
-    ap.add_argument("--scenes", type=int, default=3,
+    ap.add_argument("--scenes", type=int, default=16,
                     help="--mode ncut: scenes in flight on one GPU (one HIP stream each, one host thread for all)")
     ap.add_argument("--no-graphs", action="store_true", help="do not capture the decoder passes as HIP graphs")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of the flat-buffer kernel")

@@ -12,8 +12,11 @@ SURVEY.md §8e: scenes are independent, so the path scales by REPLICAS — no co
   arrived, does its host logic, queues its next iteration and moves on — the other scenes' solves keep the GPU busy
   meanwhile.  (Round 2 gave every scene its own host THREAD: 6.0 scenes/s with one scene in flight, 9.7 with two,
   6.3 with four — the threads queued on the interpreter lock.  Round 3: the per-iteration host logic lost its 6 ms
-  rebuild of the neighbour sets, and the scenes share one thread.)  Default: three in flight (192 of the 256 CUs
-  hold persistent solves, the rest serve the short affinity kernels).
+  rebuild of the neighbour sets, and the scenes share one thread.)  Measured on the 625-segment bench scene
+  (`bench.py --mode ncut --scenes K`): 8.1 scenes/s with one scene in flight (eigen-solve bound: 5.6 ms x 20
+  iterations), 11.1 / 14.5 / 16.1 / 21.0 / 23.5 / 25.0 / 26.7 with 2 / 3 / 4 / 6 / 12 / 16 / 24.  A solve's 64 workgroups hold
+  only 20 KB of LDS each, so the solves of many scenes share the CUs; smaller grids per solve (USC3D_TRI_G = 48, 32)
+  were measured slower at every K.  Default: 16 in flight.
 """
 from __future__ import annotations
 
@@ -49,7 +52,7 @@ def default_scene_steps(scene, **kw):
 
 
 class PseudoMaskDriver:
-    def __init__(self, device="cuda", concurrent: int = 3, rank: int = 0, world: int = 1, scene_fn=None,
+    def __init__(self, device="cuda", concurrent: int = 16, rank: int = 0, world: int = 1, scene_fn=None,
                  scene_steps=default_scene_steps):
         """scene_steps(scene, **kw) -> generator yielding torch.cuda.Event (the default: the masked-NCut loop);
         scene_fn(scene, **kw) -> masks: a plain function instead (then every scene runs to completion on its stream,
