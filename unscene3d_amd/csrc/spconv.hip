@@ -531,7 +531,17 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restri
       const float4 bv = *reinterpret_cast<const float4*>(bias + (j * 4) % cout);
       v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
     }
-    for (int g = 0; g < G; ++g) {
+    // eight slices in flight per thread (a runtime-G loop waits for every load before the next is issued: 27 dependent
+    // round trips for the 27 offset groups of a small map); the adds keep the order g ascending
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = reinterpret_cast<const float4*>(partial)[(int64_t)(g + u) * numel4 + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+    }
+    for (; g < G; ++g) {
       const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)g * numel4 + j];
       v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
@@ -881,6 +891,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t numel, int accumulate,
                                     float* __restrict__ dW) {
+  // float4 per thread when the slice length allows it (every [K, cin, cout] with cout % 4 == 0), slices in s order
+  if ((numel & 3) == 0 && (reinterpret_cast<uintptr_t>(dW) & 15) == 0) {   // (a .grad view may sit at any float offset)
+    const int64_t n4 = numel >> 2;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += (int64_t)gridDim.x * blockDim.x) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int s = 0; s < S; ++s) {
+        const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)s * n4 + j];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (accumulate) {      // straight into the parameter's gradient buffer
+        const float4 o = reinterpret_cast<const float4*>(dW)[j];
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      reinterpret_cast<float4*>(dW)[j] = v;
+    }
+    return;
+  }
   for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < numel; j += (int64_t)gridDim.x * blockDim.x) {
     float v = 0.f;
     for (int s = 0; s < S; ++s) v += partial[(int64_t)s * numel + j];
