@@ -9,8 +9,8 @@ equal --gpus (checked), the backend is nccl (= RCCL) and every rank owns one dev
 
 One "step" (default --mode mask3d, BASELINE.json configs[2]) = one full self-training step over one synthetic
 ScanNet-shaped 150k-voxel scene per GPU: device collate (2 cm voxelisation, hash unique, targets) -> coordinate /
-kernel maps -> Res16UNet34C -> 3x4 decoder passes -> 13 cost matrices -> Hungarian (scipy, host) -> 52 losses ->
-backward -> (N>1: gradient all-reduce) -> AdamW + OneCycleLR.  The raw scene arrays are resident in HBM before the
+kernel maps -> Res16UNet34C -> 3x4 decoder passes -> 13 cost matrices -> Hungarian (device: usc_lsap_batch, scipy's
+algorithm and tie-breaking) -> 52 losses -> backward -> (N>1: gradient all-reduce) -> AdamW + OneCycleLR.  The raw scene arrays are resident in HBM before the
 timed region.  Rank 0 prints ONE JSON line (DESIGN.md §5 defines `roofline` and `cpu_baseline`).
 """
 import argparse
@@ -113,7 +113,7 @@ WORKLOADS = {
     "backbone": "BASELINE.json configs[1]: Res16UNet34C backbone fwd+bwd+AdamW, one synthetic ScanNet-shaped scene "
                 "per GPU, {nvox} voxels @2cm (voxelise + coordinate/kernel maps rebuilt every step), random-init weights",
     "mask3d": "BASELINE.json configs[2]: full Mask3D self-train step (device collate/voxelise -> Res16UNet34C -> "
-              "100-query decoder 3x4 passes -> Hungarian (scipy, host) -> 52 losses -> backward -> AdamW + OneCycleLR), "
+              "100-query decoder 3x4 passes -> Hungarian (on the device) -> 52 losses -> backward -> AdamW + OneCycleLR), "
               "{spr} synthetic ScanNet-shaped scene(s) per GPU and step, {nvox} voxels @2cm each, pseudo-mask targets, "
               "random-init weights",
 }

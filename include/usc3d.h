@@ -449,8 +449,9 @@ int usc_attn_fwd(const float* q, const float* k, const float* v,
 int usc_attn_bwd(const float* q, const float* k, const float* v,
                  const uint8_t* mask, const float* o, const float* lse,
                  const float* dO, int32_t L, int32_t S, int32_t B, int32_t H,
-                 int32_t E, float* dq, float* dk, float* dv, void* ws,
-                 int64_t ws_bytes, usc_stream_t s);
+                 int32_t E, float* dq, float* dk, float* dv,
+                 int32_t mask_bits_in_ws /* ws = the forward call's workspace, packed mask still at its start */,
+                 void* ws, int64_t ws_bytes, usc_stream_t s);
 
 /* Self attention of the decoder queries (S = L <= 128 keys, no mask, head dim 16): q, k, v, o, dO, dq, dk, dv
  * f32[L,B,E] sequence-first, lse f32[B*H,128].  ONE launch each way (forward: one workgroup per (batch, head);

@@ -1019,18 +1019,22 @@ def test_triplane_projection_loss(device):
     assert float(exp_grad.abs().sum()) > 0 and rel_err(lg.grad, exp_grad) < 1e-4, rel_err(lg.grad, exp_grad)
 
 
-@pytest.mark.parametrize("level_embed,sample_sizes,voxels", [(False, "[20,50,100,200,800]", 12000),
-                                                             (True, "[20,50,100,200,800]", 12000),
-                                                             (False, "[200,800,3200,12800,51200]", 12000),
-                                                             (False, "[200,800,3200,12800,51200]", 150000)])
-def test_decoder_graph_capture_equals_eager(device, level_embed, sample_sizes, voxels):
+@pytest.mark.parametrize("level_embed,sample_sizes,voxels,scenes", [(False, "[20,50,100,200,800]", 12000, 1),
+                                                                    (True, "[20,50,100,200,800]", 12000, 1),
+                                                                    (False, "[200,800,3200,12800,51200]", 12000, 1),
+                                                                    (False, "[200,800,3200,12800,51200]", 150000, 1),
+                                                                    (False, "[20,50,100,200,800]", 12000, 3),
+                                                                    (False, "[200,800,3200,12800,51200]", 20000, 2)])
+def test_decoder_graph_capture_equals_eager(device, level_embed, sample_sizes, voxels, scenes):
     """The HIP-graph captured decoder passes give the same loss and gradients as the eager path.
     (Two module instances with identical weights: capture must happen before the module's first backward.)
     With use_level_embed the embedding weight must receive its gradient from the captured passes too.
     Third case: the reference's own sample sizes on a 12 k-voxel scene — every level is SMALLER than its captured key
     count, so the graphed module pads the keys (masked) up to it while the eager one attends over the level as is.
     Fourth case: the bench configuration itself (150 k voxels, 3 200 / 12 800 sampled keys per level: the many-row
-    projections inside the captured graphs)."""
+    projections inside the captured graphs).  Last two: several scenes of DIFFERENT size per GPU (the reference trains
+    with 5-8, conf/data/indoor.yaml:25) — the batched gather into the captured passes' input buffers, the stacked
+    attention-mask chain, ragged levels (some scenes sampled, some padded and masked) and the per-scene criterion."""
     from unscene3d_amd.config import apply_overrides, default_config
     from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
     from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
@@ -1038,17 +1042,18 @@ def test_decoder_graph_capture_equals_eager(device, level_embed, sample_sizes, v
 
     cfg = apply_overrides(default_config(), ["general.num_targets=3", f"model.sample_sizes={sample_sizes}",
                                              f"model.use_level_embed={level_embed}"])
-    ds = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=voxels, seed=3300)
+    batch = [SyntheticFreeMaskDataset(n_scenes=1, target_voxels=int(voxels * (1.0 - 0.3 * k)), seed=3300 + k)[0]
+             for k in range(scenes)]
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device))
     torch.manual_seed(3)
     eager = InstanceSegmentation(cfg).to(device).train()
     graphed = InstanceSegmentation(cfg).to(device).train()
     graphed.load_state_dict(eager.state_dict())
-    graphed.model.enable_decoder_graphs(batch_size=1, device=device)
+    graphed.model.enable_decoder_graphs(batch_size=scenes, device=device)
     results = []
     for module in (eager, graphed):
         module.model.randperm = _PermSource()
-        total, weighted = module.training_step(collate([ds[0]]))
+        total, weighted = module.training_step(collate(batch))
         total.backward()
         g = torch.cat([p.grad.reshape(-1) for n, p in module.named_parameters()
                        if p.grad is not None and "backbone" not in n])
@@ -1293,3 +1298,43 @@ def test_advice_round2_regressions(device):
     ref = ((xr + pr) @ Wd[:E].T).sum() + 2.0 * (xr @ Wd[E:2 * E].T).sum() + 3.0 * (xr @ Wd[2 * E:].T).sum()
     ref.backward()
     assert rel_err(xq.grad, xr.grad) < 1e-5 and rel_err(pos.grad, pr.grad) < 1e-5
+
+
+def test_mask_module_several_scenes_equals_the_table_path(device, monkeypatch):
+    """Mask3D.mask_module on a batch of three scenes: the stacked-segment-table chain (first pooling step reads the
+    [sum S, Q] logits through point2segment + scene offset, last step thresholds) gives the same attention mask and the
+    same segment logits as the reference-shaped path (per-voxel logit table, MinkowskiAvgPooling, sigmoid < 0.5;
+    reference models/mask3d.py:407-446)."""
+    from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd.config import apply_overrides, default_config, instantiate_model
+    import unscene3d_amd.models.mask3d as M3
+
+    cfg = apply_overrides(default_config(), ["general.num_targets=3"])
+    torch.manual_seed(11)
+    model = instantiate_model(cfg).to(device).train()
+    c = R.coordmap_build(_scene_coords(21, 9000, 18, batch=3))[2]
+    x = ME.SparseTensor(coordinates=_dev(c, device), features=torch.zeros(len(c), 3, device=device), device=device)
+    cm = x.coordinate_manager
+    cm.prepare(1, n_down=4, ksize=3)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(len(c), 128, generator=g).to(device)
+    mask_features = ME.SparseTensor(features=feats, coordinate_manager=cm, coordinate_map_key=x.coordinate_map_key)
+    sizes = [s.stop - s.start for s in cm.batch_slices(1)]
+    S = [17, 40, 29]
+    p2s = [torch.randint(0, s_, (n,), generator=g).to(device) for s_, n in zip(S, sizes)]
+    segs = [torch.randn(s_, 128, generator=g).to(device) for s_ in S]
+    queries = torch.randn(3, 100, 128, generator=g).to(device)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(M3, "_FUSED_ATTN_MASK", fused)
+        if hasattr(cm, "_usc_p2s_batched"):
+            del cm._usc_p2s_batched
+        for steps in (1, 3):
+            _, seg_logits, attn = model.mask_module(queries, mask_features, segs, steps, ret_attn_mask=True,
+                                                    point2segment=p2s, coords=None, defer_class=True)
+            outs[(fused, steps)] = (attn.F.clone(), [s.detach().clone() for s in seg_logits])
+    for steps in (1, 3):
+        a, b = outs[(True, steps)], outs[(False, steps)]
+        assert a[0].dtype == torch.bool and torch.equal(a[0], b[0])
+        assert all(torch.equal(u, v) for u, v in zip(a[1], b[1]))
+        assert 0.05 < float(a[0].float().mean()) < 0.95

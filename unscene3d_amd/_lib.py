@@ -116,7 +116,7 @@ SIGNATURES = {
     "usc_elastic_displace": (C.c_int, [_p, _i32, _i64, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _f64, _p, _p]),
     "usc_attn_ws_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "usc_attn_fwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i64, _p]),
-    "usc_attn_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _i64, _p]),
+    "usc_attn_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
     "usc_lsap_batch": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p, _p]),
     "usc_criterion_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_criterion_target_bits": (C.c_int, [_p, _i32, _i32, _p, _p, _p]),

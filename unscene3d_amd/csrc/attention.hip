@@ -3,8 +3,9 @@
 // boolean memory_mask).  softmax(q k^T / sqrt(hd) + mask) v without materialising the [heads, queries, keys] score
 // tensor: the library path is two skinny batched GEMMs (hd = 16), a 41 MB softmax and a 41 MB float mask per call.
 //   forward : split over keys (flash-decoding style partial (o, m, l) per split) + a combine kernel
-//   backward: recomputes the probabilities from the saved log-sum-exp; dk / dv per key chunk, dq as partial sums
-//             per (split, wave) reduced in a fixed order (deterministic, no float atomics)
+//   backward: recomputes the probabilities from the saved log-sum-exp (D = rowsum(dO * o) in the prologue); dk / dv
+//             per key chunk, dq as partial sums per (split, wave) reduced in a fixed order (deterministic, no float
+//             atomics); the mask packed by the forward call is reused
 // All matrix products run on v_mfma_f32_32x32x2_f32 with the key / query index as the 32-wide tile dimension.
 // Tensors keep the module's sequence-first layout [len, batch, heads*hd]; the mask is the decoder's own
 // bool[batch, keys, queries] (True = masked), shared by all heads and packed to bits by a pre-pass.
@@ -35,7 +36,8 @@ struct AttnParams {
   float* lse;       // [B*H, kMaxL]
   // backward
   const float* dO;  // [L, B, E]
-  const float* D;   // [B*H, kMaxL]
+  const float* O;   // [L, B, E] forward output (backward: D = rowsum(dO * O) in the prologue)
+  const float* D;   // [B*H, kMaxL] (unused since the prologue computes it)
   float* dq_part;   // [B*H, nsplit*4, kMaxL, HD]
   float* dq;        // [L, B, E]
   float* dk;        // [S, B, E]
@@ -141,42 +143,37 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
-// one thread per (bh, query, channel)
+// one wave per (bh, query): lane = (split group g = lane >> 4, channel d = lane & 15); every lane walks a quarter of the
+// splits (max, then the weighted sums), the four groups are combined by two shuffles in a fixed order.  (The first
+// version had one thread per (bh, query, channel) walk all <= 64 splits twice: 16 us at 12 800 keys.)
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int d = (int)(t % HD);
-  const int64_t r = t / HD;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int qi = (int)(r % p.L);
   const int bh = (int)(r / p.L);
   if (bh >= p.B * p.H) return;
+  const int d = lane & 15, g = lane >> 4;
   float M = -INFINITY;
-  for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, p.ml_part[((int64_t)bh * p.nsplit + s) * 2 * kMaxL + qi]);
+  for (int s = g; s < p.nsplit; s += 4) M = fmaxf(M, p.ml_part[((int64_t)bh * p.nsplit + s) * 2 * kMaxL + qi]);
+  M = fmaxf(M, __shfl_xor(M, 16, 64));
+  M = fmaxf(M, __shfl_xor(M, 32, 64));
   const float Ms = M == -INFINITY ? 0.f : M;
   float Lsum = 0.f, acc = 0.f;
-  for (int s = 0; s < p.nsplit; ++s) {
+  for (int s = g; s < p.nsplit; s += 4) {
     const float* ml = p.ml_part + ((int64_t)bh * p.nsplit + s) * 2 * kMaxL;
     const float w = __expf(ml[qi] - Ms);
     Lsum += ml[kMaxL + qi] * w;
     acc += p.o_part[(((int64_t)bh * p.nsplit + s) * kMaxL + qi) * HD + d] * w;
   }
-  const int b = bh / p.H, hh = bh % p.H;
-  p.o[(int64_t)qi * p.B * p.E + (int64_t)b * p.E + hh * HD + d] = Lsum > 0.f ? acc / Lsum : 0.f;
-  if (d == 0) p.lse[(int64_t)bh * kMaxL + qi] = Lsum > 0.f ? Ms + __logf(Lsum) : INFINITY;
-}
-
-// D[bh][q] = sum_d dO[q][b][h*HD+d] * O[...]
-__global__ __launch_bounds__(256) void attn_rowdot_kernel(const float* __restrict__ dO, const float* __restrict__ O, int L,
-                                                         int B, int H, int E, float* __restrict__ D) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int qi = (int)(t % L);
-  const int bh = (int)(t / L);
-  if (bh >= B * H) return;
-  const int b = bh / H, hh = bh % H;
-  const int64_t off = (int64_t)qi * B * E + (int64_t)b * E + hh * HD;
-  float s = 0.f;
-#pragma unroll
-  for (int d = 0; d < HD; ++d) s += dO[off + d] * O[off + d];
-  D[(int64_t)bh * kMaxL + qi] = s;
+  Lsum += __shfl_xor(Lsum, 16, 64);
+  Lsum += __shfl_xor(Lsum, 32, 64);
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  if (g == 0) {
+    const int b = bh / p.H, hh = bh % p.H;
+    p.o[(int64_t)qi * p.B * p.E + (int64_t)b * p.E + hh * HD + d] = Lsum > 0.f ? acc / Lsum : 0.f;
+    if (d == 0) p.lse[(int64_t)bh * kMaxL + qi] = Lsum > 0.f ? Ms + __logf(Lsum) : INFINITY;
+  }
 }
 
 // ---- backward: workgroup = (bh, key split); wave w takes the key chunks w, w+4, ... of the split
@@ -194,8 +191,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     sdo[qi][d] = ok ? p.dO[(int64_t)qi * rs + hoff + d] : 0.f;
   }
   for (int e = threadIdx.x; e < kMaxL; e += 256) {
+    float dsum = 0.f;                     // D = rowsum(dO * O): 16 products per query, recomputed by every workgroup
+    if (e < p.L) {                        // (a separate launch + a round trip through memory before)
+      const float* dop = p.dO + (int64_t)e * rs + hoff;
+      const float* op = p.O + (int64_t)e * rs + hoff;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dsum += dop[d] * op[d];
+    }
     slse[e] = e < p.L ? p.lse[(int64_t)bh * kMaxL + e] : INFINITY;
-    sD[e] = e < p.L ? p.D[(int64_t)bh * kMaxL + e] : 0.f;
+    sD[e] = dsum;
   }
   __syncthreads();
   const int ntile = (p.L + 31) >> 5;
@@ -577,7 +581,7 @@ int usc_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* 
   p.o = o; p.lse = lse;
   hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)ceil_div((int64_t)B * S, 4)), dim3(256), 0, st, mask, (int64_t)B * S, (int)L, bits);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H, p.nsplit), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)ceil_div((int64_t)B * H * L * HD, 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)ceil_div((int64_t)B * H * L, 4)), dim3(256), 0, st, p);
   USC_CHECK_LAUNCH("usc_attn_fwd");
   return USC_OK;
 }
@@ -585,7 +589,7 @@ int usc_attn_fwd(const float* q, const float* k, const float* v, const uint8_t* 
 /* backward: dq [L,B,E], dk / dv [S,B,E]; D scratch f32[B*H,128] */
 int usc_attn_bwd(const float* q, const float* k, const float* v, const uint8_t* mask, const float* o, const float* lse,
                  const float* dO, int32_t L, int32_t S, int32_t B, int32_t H, int32_t E, float* dq, float* dk, float* dv,
-                 void* ws, int64_t ws_bytes, usc_stream_t s) {
+                 int32_t mask_bits_in_ws, void* ws, int64_t ws_bytes, usc_stream_t s) {
   USC_REQUIRE(L >= 1 && L <= kMaxL && S >= 1 && B >= 1 && H >= 1 && E == H * HD,
               "usc_attn_bwd: needs head dim 16 and at most 128 queries");
   USC_REQUIRE(q && k && v && mask && o && lse && dO && dq && dk && dv && ws && ws_bytes >= usc_attn_ws_bytes(L, S, B, H),
@@ -601,11 +605,11 @@ int usc_attn_bwd(const float* q, const float* k, const float* v, const uint8_t* 
   p.mbits = bits;
   p.dq_part = (float*)w;
   w += (int64_t)B * H * p.nsplit * 4 * kMaxL * HD * 4;
-  float* D = (float*)w;                                    // re-uses the (m, l) area: B*H*128 floats fit
-  p.D = D; p.lse = (float*)lse; p.dO = dO; p.dq = dq; p.dk = dk; p.dv = dv;
-  hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)ceil_div((int64_t)B * S, 4)), dim3(256), 0, st, mask, (int64_t)B * S, (int)L, bits);
-  hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)ceil_div((int64_t)B * H * L, 256)), dim3(256), 0, st, dO, o, (int)L,
-                     (int)B, (int)H, (int)E, D);
+  p.D = nullptr; p.O = o; p.lse = (float*)lse; p.dO = dO; p.dq = dq; p.dk = dk; p.dv = dv;
+  // mask_bits_in_ws: `ws` is the forward call's workspace and still holds the packed mask at its start (the forward's
+  // partial sums behind it are dead: this call overwrites them)
+  if (!mask_bits_in_ws)
+    hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)ceil_div((int64_t)B * S, 4)), dim3(256), 0, st, mask, (int64_t)B * S, (int)L, bits);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H, p.nsplit), dim3(256), 0, st, p);
   hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)ceil_div((int64_t)B * H * L, 4)), dim3(256), 0, st, p);
   USC_CHECK_LAUNCH("usc_attn_bwd");

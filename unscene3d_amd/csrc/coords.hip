@@ -223,7 +223,7 @@ using namespace usc;
 extern "C" {
 
 const char* usc_last_error(void) { return g_err; }
-int usc_abi_version(void) { return 1; }
+int usc_abi_version(void) { return 2; }   // 2: usc_attn_bwd takes mask_bits_in_ws (round 3)
 
 int usc_device_count(void) {
   int n = 0;

@@ -34,4 +34,29 @@ class GenericMLP(nn.Module):
                     nn.init.xavier_uniform_(p)
 
     def forward(self, x):
-        return self.layers(x)
+        fast = self._linear_chain(x)
+        return self.layers(x) if fast is None else fast
+
+    def _linear_chain(self, x):
+        """Conv1d(kernel 1) over [B, C, L] == a linear layer over the L*B rows of [L, B, C]: on the device the
+        stack runs on the few-row linear kernels (ReLU in the same launch) instead of the library's convolution —
+        whose backward for this 128x128x1 filter is MIOpen's naive direct kernel.  None when the stack is anything
+        other than Conv1d(k=1) / ReLU on f32 HIP tensors (the stock modules run then)."""
+        import torch
+        from ... import ops
+        if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3):
+            return None
+        mods = list(self.layers)
+        plan, i = [], 0
+        while i < len(mods):
+            m = mods[i]
+            if not (isinstance(m, nn.Conv1d) and m.kernel_size == (1,) and m.stride == (1,) and m.groups == 1
+                    and m.padding == (0,) and m.in_channels % 32 == 0 and m.out_channels % 32 == 0):
+                return None
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            plan.append((m, relu))
+            i += 2 if relu else 1
+        h = x.permute(0, 2, 1)                                          # [B, L, C] rows
+        for m, relu in plan:
+            h = ops.linear(h, m.weight.view(m.out_channels, m.in_channels), m.bias, relu=relu)
+        return h.permute(0, 2, 1)

@@ -1055,21 +1055,20 @@ class _MaskedCrossAttention(torch.autograd.Function):
         ws = _ws(wsb, q.device)
         check(lib.usc_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(m8), L, S, B, num_heads, E, _ptr(o), _ptr(lse), _ptr(ws),
                                wsb, _stream()), "usc_attn_fwd")
-        ctx.save_for_backward(q, k, v, m8, o, lse)
+        ctx.save_for_backward(q, k, v, m8, o, lse, ws)       # ws: its head keeps the packed mask for the backward
         ctx.num_heads = num_heads
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, m8, o, lse = ctx.saved_tensors
+        q, k, v, m8, o, lse, ws = ctx.saved_tensors
         L, B, E = q.shape
         S = k.shape[0]
         do = do.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         wsb = lib.usc_attn_ws_bytes(L, S, B, ctx.num_heads)
-        ws = _ws(wsb, q.device)
         check(lib.usc_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(m8), _ptr(o), _ptr(lse), _ptr(do), L, S, B, ctx.num_heads,
-                               E, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), wsb, _stream()), "usc_attn_bwd")
+                               E, _ptr(dq), _ptr(dk), _ptr(dv), 1, _ptr(ws), wsb, _stream()), "usc_attn_bwd")
         return dq, dk, dv, None, None
 
 
