@@ -489,7 +489,8 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __re
     const int cg = (int)(j - r * CT);
     const int64_t d = idx[r];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) atomicAdd(dst + d * c + cg * VEC + v, src[r * c + cg * VEC + v]);
+    for (int v = 0; v < VEC; ++v) unsafeAtomicAdd(dst + d * c + cg * VEC + v, src[r * c + cg * VEC + v]);   // the hardware's
+    // global_atomic_add_f32 (plain atomicAdd on float compiles to a compare-and-swap loop: 0.9 TB/s on a permutation)
   }
 }
 

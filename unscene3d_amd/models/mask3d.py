@@ -268,13 +268,10 @@ class Mask3D(nn.Module):
                 rand_idx, mask_idx = [], []
                 for k, pcd_size in enumerate(sizes):
                     if pcd_size <= curr_sample_size:      # take everything, pad with row 0 and mask the padding
-                        idx = torch.zeros(curr_sample_size, dtype=torch.long, device=queries.device)
-                        midx = torch.ones(curr_sample_size, dtype=torch.bool, device=queries.device)
-                        idx[:pcd_size] = torch.arange(pcd_size, device=queries.device)
-                        midx[:pcd_size] = False
+                        idx, midx = _padded_index(pcd_size, curr_sample_size, queries.device)
                     else:                                  # random subset, nothing masked
                         idx = self.randperm(pcd_size, queries.device)[:curr_sample_size]
-                        midx = torch.zeros(curr_sample_size, dtype=torch.bool, device=queries.device)
+                        midx = _padded_index(curr_sample_size, curr_sample_size, queries.device)[1]
                     rand_idx.append(idx)
                     mask_idx.append(midx)
 
@@ -311,7 +308,9 @@ class Mask3D(nn.Module):
 
                 # a query whose sampled keys are all masked attends to everything (reference :346)
                 batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
-                if bufs is not None:
+                if all(n > curr_sample_size for n in sizes):
+                    pass                                   # every scene was sampled: no padding rows to mask
+                elif bufs is not None:
                     torch.logical_or(batched_attn, _stack(mask_idx)[..., None], out=batched_attn)
                 else:
                     batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
@@ -515,6 +514,26 @@ class _DecoderPass(nn.Module):
 
 
 _FUSED_ATTN_MASK = os.environ.get("USC3D_FUSED_ATTN_MASK", "1") != "0"
+
+
+_PAD_CACHE = {}
+
+
+def _padded_index(n, size, device):
+    """(idx i64[size] = 0..n-1 then zeros, mask bool[size] = False for the first n, True for the padding): constants
+    of (n, size), kept per device instead of being rebuilt from five small fills / copies per scene and pass (the
+    callers only read them)."""
+    key = (int(n), int(size), str(device))
+    hit = _PAD_CACHE.get(key)
+    if hit is None:
+        if len(_PAD_CACHE) > 256:
+            _PAD_CACHE.clear()
+        idx = torch.zeros(size, dtype=torch.long, device=device)
+        midx = torch.ones(size, dtype=torch.bool, device=device)
+        idx[:n] = torch.arange(n, device=device)
+        midx[:n] = False
+        hit = _PAD_CACHE[key] = (idx, midx)
+    return hit
 
 
 def _stack(tensors):
