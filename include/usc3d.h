@@ -400,6 +400,12 @@ int usc_gather_rows(const float* src, int32_t c, const int64_t* idx, int64_t n,
 int usc_scatter_add_rows(const float* src, int32_t c, const int64_t* idx,
                          int64_t n, float* dst, usc_stream_t s);
 
+/* dst[idx[i],:] = src[i,:] for an index set the CALLER knows to be free of duplicates (a permutation,
+ * torch.randperm(n)[:k] — the decoder's sampled keys, models/mask3d.py:325): plain 16-byte stores, no atomics;
+ * with a zeroed dst this is the backward of usc_gather_rows at gather bandwidth.  Duplicates would race. */
+int usc_scatter_rows_unique(const float* src, int32_t c, const int64_t* idx,
+                            int64_t n, float* dst, usc_stream_t s);
+
 /* ------------------------------------------------------------------------
  * Q3  segment mean — replaces torch_scatter.scatter_mean(src, index, dim=0)
  * (models/mask3d.py:12,223; trainer/trainer.py:449) forward + backward.

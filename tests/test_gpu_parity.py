@@ -1338,3 +1338,27 @@ def test_mask_module_several_scenes_equals_the_table_path(device, monkeypatch):
         assert a[0].dtype == torch.bool and torch.equal(a[0], b[0])
         assert all(torch.equal(u, v) for u, v in zip(a[1], b[1]))
         assert 0.05 < float(a[0].float().mean()) < 0.95
+
+
+@pytest.mark.parametrize("c", [96, 128, 19])
+def test_gather_rows_backward_unique_and_atomic_paths_agree(device, c):
+    """The backward of a row gather: plain stores for an index set without duplicates (`unique=True`: the decoder's
+    torch.randperm(n)[:k] keys) == the float-atomic scatter-add == index_add on the CPU; duplicates only through the
+    atomic path."""
+    from unscene3d_amd import ops
+    g = torch.Generator().manual_seed(c)
+    n, k = 5000, 1800
+    src = torch.randn(n, c, generator=g)
+    idx = torch.randperm(n, generator=g)[:k]
+    dy = torch.randn(k, c, generator=g)
+    exp = torch.zeros(n, c).index_add_(0, idx, dy)
+    for unique in (True, False):
+        s = src.to(device).requires_grad_(True)
+        out = ops.gather_rows(s, idx.to(device), unique=unique)
+        assert torch.equal(out.cpu(), src[idx])
+        out.backward(dy.to(device))
+        assert torch.equal(s.grad.cpu(), exp)
+    dup = torch.cat([idx[:100], idx[:100]])
+    s = src.to(device).requires_grad_(True)
+    ops.gather_rows(s, dup.to(device)).backward(torch.ones(200, c, device=device))
+    assert float(s.grad[idx[:100].to(device)].min()) == 2.0 and float(s.grad.sum()) == 200.0 * c

@@ -125,7 +125,11 @@ for n, C in ((N, 96), (N, 64), (N, 32), (coarse.n, 96), (9402, 128), (2222, 256)
 
         def f_scatter(i):
             check(lib.usc_scatter_add_rows(x[i].data_ptr(), C, perm.data_ptr(), n, dst[i].data_ptr(), stream()))
-        rep(f"scatter_add_rows (permutation)     {tag}", 12 * n * C + 8 * n, timed([lambda i=i: f_scatter(i) for i in range(R)]))
+        rep(f"scatter_add_rows (atomics)         {tag}", 12 * n * C + 8 * n, timed([lambda i=i: f_scatter(i) for i in range(R)]))
+
+        def f_scatter_u(i):
+            check(lib.usc_scatter_rows_unique(x[i].data_ptr(), C, perm.data_ptr(), n, dst[i].data_ptr(), stream()))
+        rep(f"scatter_rows_unique (permutation)  {tag}", 8 * n * C + 8 * n, timed([lambda i=i: f_scatter_u(i) for i in range(R)]))
         del dst
     del x, dy
 R = copies(400 * N)

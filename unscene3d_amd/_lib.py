@@ -87,6 +87,7 @@ SIGNATURES = {
     "usc_avgpool_down2_ex": (C.c_int, [_p, _i32, _i32, _p, _p, _i64, _p, _p, _p]),
     "usc_gather_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_scatter_add_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
+    "usc_scatter_rows_unique": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_segment_csr_ws_bytes": (_i64, [_i64, _i64]),
     "usc_segment_csr": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _p]),
     "usc_segment_mean_fwd": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _p]),

@@ -294,15 +294,16 @@ class Mask3D(nn.Module):
                     gidx = rand_idx[0] if n_scenes == 1 else torch.cat(
                         [rand_idx[k] + slices[k].start for k in range(n_scenes)])
                     feats_l = aux[hlevel].F.contiguous()
-                    batched_aux = ops.gather_rows(feats_l, gidx, out=bufs[2].view(-1, feats_l.shape[1])).view(bufs[2].shape)
+                    batched_aux = ops.gather_rows(feats_l, gidx, out=bufs[2].view(-1, feats_l.shape[1]),
+                                                  unique=all(n > curr_sample_size for n in sizes)).view(bufs[2].shape)
                     batched_attn = torch.index_select(attn_mask.F, 0, gidx,
                                                       out=bufs[3].view(-1, bufs[3].shape[2])).view(bufs[3].shape)
                     for k in range(n_scenes):
                         torch.index_select(pos_encodings_pcd[hlevel][0][k], 0, rand_idx[k], out=bufs[4][k])
                     batched_pos_enc = bufs[4]
                 else:
-                    batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k])
-                                          for k in range(n_scenes)])
+                    batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k],
+                                                          unique=sizes[k] > curr_sample_size) for k in range(n_scenes)])
                     batched_attn = _stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
                     batched_pos_enc = _stack([pos_encodings_pcd[hlevel][0][k][rand_idx[k], :] for k in range(n_scenes)])
 

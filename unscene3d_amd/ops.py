@@ -595,7 +595,7 @@ def avgpool_down2(feats, nbr2, row_of=None, threshold=False):
 
 class _GatherRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, idx, out=None):
+    def forward(ctx, src, idx, out=None, unique=False):
         src = src.contiguous()
         idx = idx.contiguous()
         if out is None:
@@ -606,7 +606,7 @@ class _GatherRows(torch.autograd.Function):
         check(lib.usc_gather_rows(_ptr(src), src.shape[1], _ptr(idx), idx.shape[0], _ptr(out), _stream()),
               "usc_gather_rows")
         ctx.save_for_backward(idx)
-        ctx.n_src = src.shape[0]
+        ctx.n_src, ctx.unique = src.shape[0], bool(unique)
         return out
 
     @staticmethod
@@ -614,22 +614,24 @@ class _GatherRows(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         dout = dout.contiguous()
         dsrc = torch.zeros((ctx.n_src, dout.shape[1]), dtype=torch.float32, device=dout.device)
-        check(lib.usc_scatter_add_rows(_ptr(dout), dout.shape[1], _ptr(idx), idx.shape[0], _ptr(dsrc), _stream()),
-              "usc_scatter_add_rows")
-        return dsrc, None, None
+        fn = lib.usc_scatter_rows_unique if ctx.unique else lib.usc_scatter_add_rows
+        check(fn(_ptr(dout), dout.shape[1], _ptr(idx), idx.shape[0], _ptr(dsrc), _stream()), "usc_scatter_add_rows")
+        return dsrc, None, None, None
 
 
-def gather_rows(src, idx, out=None):
-    """out[j] = src[idx[j]]; `out` (optional): the caller's buffer (e.g. a HIP-graph input) instead of a new tensor."""
+def gather_rows(src, idx, out=None, unique=False):
+    """out[j] = src[idx[j]]; `out` (optional): the caller's buffer (e.g. a HIP-graph input) instead of a new tensor.
+    unique: the caller guarantees that idx holds no duplicates (a permutation / torch.randperm(n)[:k]); the backward
+    pass then scatters with plain stores instead of float atomics."""
     _chk(src, torch.float32, "src")
     _chk(idx, torch.int64, "idx")
-    return _GatherRows.apply(src, idx, out)
+    return _GatherRows.apply(src, idx, out, unique)
 
 
 def gather_rows_i32(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """Row gather of an int32 table (coordinates) through the same kernel (bit pattern copy)."""
     _chk(src, torch.int32, "src")
-    return _GatherRows.apply(src.view(torch.float32), idx.contiguous()).view(torch.int32)
+    return _GatherRows.apply(src.view(torch.float32), idx.contiguous(), None, False).view(torch.int32)
 
 
 @dataclass
