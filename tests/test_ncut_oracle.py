@@ -66,3 +66,27 @@ def test_oracle_aggregate_features_matches_reference():
             agg, uniq = NR.aggregate_features(z[f"{case}/feats"], z[f"{case}/seg"], z[f"{case}/conn"], mode)
             assert np.array_equal(uniq, z[f"{case}/uniq"])
             np.testing.assert_allclose(agg, z[f"{case}/{mode}"], rtol=2e-6, atol=1e-7)
+
+
+def test_host_blob_logic_equals_the_reference_scan():
+    """unscene3d_amd.pseudo_masks.ncut.separate_segments (cached neighbour sets, owner lookup, the reference's
+    positional scan only for an id that touches several blobs) against the oracle's restatement of the reference loop
+    (pseudo_masks/unscene3d_pseudo_main.py:181-250) on random directed and symmetric segment graphs: the same blob
+    for the arg-max seed — including the scan's skip-after-merge quirk."""
+    from unscene3d_amd.pseudo_masks import ncut
+
+    rng = np.random.default_rng(3)
+    for t in range(300):
+        S = int(rng.integers(5, 120))
+        E = int(rng.integers(0, 6 * S))
+        uniq = np.sort(rng.choice(400, S, replace=False))
+        conn = np.stack([rng.choice(uniq, E), rng.choice(uniq, E)], 1) if E else np.zeros((0, 2), np.int64)
+        if t % 2 == 0 and E:
+            conn = np.concatenate([conn, conn[:, ::-1]])
+        vec = rng.standard_normal(S)
+        bip = vec > vec.mean()
+        exp = NR._separate(bip, vec, uniq, conn)
+        nbs = ncut.neighbour_sets(uniq, conn)
+        assert nbs == {int(s): set(conn[conn[:, 0] == s, 1].tolist()) for s in uniq}
+        assert ncut.separate_segments(bip, vec, uniq, conn, mode="max") == exp
+        assert ncut.separate_segments(bip, vec, uniq, conn, mode="max", neighbours=nbs) == exp
