@@ -257,12 +257,12 @@ def test_conv1x1_with_bias(device):
     assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("n", [7777, 2222, 507, 3])       # two launches | one-launch statistics | one launch both ways
 @pytest.mark.parametrize("c,relu,res", [(32, True, False), (96, True, True), (256, False, False), (100, False, True)])
-def test_batch_norm_act(device, c, relu, res):
+def test_batch_norm_act(device, c, relu, res, n):
     from unscene3d_amd import ops
 
     g = torch.Generator().manual_seed(c)
-    n = 7777
     x = torch.randn(n, c, generator=g) * 3 + 1
     r = torch.randn(n, c, generator=g) if res else None
     gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)

@@ -5,6 +5,7 @@
 // stable counting-sort CSR so that every floating-point sum has a fixed order.
 // All kernels move 16 B per lane where the channel count allows it.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "scan.h"
@@ -148,43 +149,138 @@ struct BnFwdOut {
   int64_t n;
   int64_t* num_batches_tracked;   // incremented once per call when not NULL (nn.BatchNorm's counter)
 };
+__device__ inline void bn_finalize_channel(int ch, double s1, double s2, const BnFwdOut& o) {
+  const double n = (double)o.n;
+  const double m = s1 / n;
+  double var = s2 / n - m * m;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)m;
+  const float invstd = (float)(1.0 / sqrt(var + (double)o.eps));
+  const float sc = o.gamma[ch] * invstd;
+  o.mean[ch] = mean;
+  o.invstd[ch] = invstd;
+  o.scale[ch] = sc;
+  o.shift[ch] = o.beta[ch] - mean * sc;
+  if (o.running_mean) {
+    const double unbiased = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
+    o.running_mean[ch] = (1.f - o.momentum) * o.running_mean[ch] + o.momentum * mean;
+    o.running_var[ch] = (1.f - o.momentum) * o.running_var[ch] + o.momentum * (float)unbiased;
+  }
+  if (ch == 0 && o.num_batches_tracked) *o.num_batches_tracked += 1;
+}
 __global__ __launch_bounds__(64) void bn_fwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int c,
                                                             BnFwdOut o) {
   const int ch = blockIdx.x;
   double s1, s2;
   reduce_partials(partial, nblocks, c, ch, s1, s2);
-  if ((threadIdx.x & 63) == 0) {
-    const double n = (double)o.n;
-    const double m = s1 / n;
-    double var = s2 / n - m * m;
-    if (var < 0.0) var = 0.0;
-    const float mean = (float)m;
-    const float invstd = (float)(1.0 / sqrt(var + (double)o.eps));
-    const float sc = o.gamma[ch] * invstd;
-    o.mean[ch] = mean;
-    o.invstd[ch] = invstd;
-    o.scale[ch] = sc;
-    o.shift[ch] = o.beta[ch] - mean * sc;
-    if (o.running_mean) {
-      const double unbiased = var * (n / (n > 1.0 ? n - 1.0 : 1.0));
-      o.running_mean[ch] = (1.f - o.momentum) * o.running_mean[ch] + o.momentum * mean;
-      o.running_var[ch] = (1.f - o.momentum) * o.running_var[ch] + o.momentum * (float)unbiased;
-    }
-    if (ch == 0 && o.num_batches_tracked) *o.num_batches_tracked += 1;
-  }
+  if ((threadIdx.x & 63) == 0) bn_finalize_channel(ch, s1, s2, o);
+}
+struct BnBwdOut {
+  float* dgamma; float* dbeta; float* mean_g; float* mean_gx;
+  int64_t n;
+  int training, accumulate;
+};
+__device__ inline void bn_finalize_channel(int ch, double sg, double sgx, const BnBwdOut& o) {
+  o.dbeta[ch] = o.accumulate ? o.dbeta[ch] + (float)sg : (float)sg;    // accumulate: into the parameters' .grad buffers
+  o.dgamma[ch] = o.accumulate ? o.dgamma[ch] + (float)sgx : (float)sgx;
+  o.mean_g[ch] = o.training ? (float)(sg / (double)o.n) : 0.f;
+  o.mean_gx[ch] = o.training ? (float)(sgx / (double)o.n) : 0.f;
 }
 __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblocks, int c,
-                                                            int64_t n, int training, int accumulate,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ mean_g, float* __restrict__ mean_gx) {
+                                                            BnBwdOut o) {
   const int ch = blockIdx.x;
   double sg, sgx;
   reduce_partials(partial, nblocks, c, ch, sg, sgx);
-  if ((threadIdx.x & 63) == 0) {
-    dbeta[ch] = accumulate ? dbeta[ch] + (float)sg : (float)sg;      // accumulate: into the parameters' .grad buffers
-    dgamma[ch] = accumulate ? dgamma[ch] + (float)sgx : (float)sgx;
-    mean_g[ch] = training ? (float)(sg / (double)n) : 0.f;
-    mean_gx[ch] = training ? (float)(sgx / (double)n) : 0.f;
+  if ((threadIdx.x & 63) == 0) bn_finalize_channel(ch, sg, sgx, o);
+}
+
+// Few-row maps (the U-Net's three coarsest levels: 507 ... 2 222 rows at 150k voxels): sums and finalisation in ONE
+// launch.  A block owns four channels (one float4 column); its 256 threads stride the rows, then wave 0 folds the
+// 256 x 8 partials in a fixed order (thread-major blocks of 8, then a 3-step shuffle tree) and finalises.  The two
+// launches this replaces cost 9.4 us at 507 rows against ~5 us for the one; the statistics are the same f64 sums.
+// measured (profiles/r03_hbm_bound_kernels.txt): statistics 9.4 -> 4.2 us at 507 rows, 9.8 -> 8.0 at 2 222, slower from
+// 9 402; the backward reduce (three inputs) 11.6 -> 5.3 us at 507 rows but 11.9 -> 13.4 at 2 222
+static int64_t bn_small_rows(bool backward) {
+  static const int64_t knob = [] {
+    const char* e = getenv("USC3D_BN_SMALL_ROWS");   // measurement knob; 0 = always the two-launch form
+    return e ? (int64_t)atoll(e) : (int64_t)-1;
+  }();
+  return knob >= 0 ? knob : (backward ? 1024 : 4096);
+}
+template <int MODE, typename OUT>
+__global__ __launch_bounds__(256) void bn_small_kernel(StatArgs a, OUT o) {
+  __shared__ double sh[8][256 + 2];
+  // workgroups go round-robin over the 8 XCDs (each with its own L2): give XCD x the CONTIGUOUS column groups
+  // [x*G/8, (x+1)*G/8) so that the 128-byte lines it pulls are used whole instead of 16 bytes at a time by 8 XCDs
+  const int G = gridDim.x, b = blockIdx.x;
+  const int grp = (G % 8 == 0) ? (b % 8) * (G / 8) + b / 8 : b;
+  const int c = a.c, ch0 = grp * 4, tid = threadIdx.x;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  float mu[4], is[4];
+  if (MODE == STAT_BN_BWD) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      mu[v] = a.mean[ch0 + v];
+      is[v] = a.invstd[ch0 + v];
+    }
+  }
+  for (int64_t r0 = tid; r0 < a.n; r0 += 256 * kStatUnroll) {
+    float4 xv[kStatUnroll], yv[kStatUnroll], ov[kStatUnroll];
+#pragma unroll
+    for (int u = 0; u < kStatUnroll; ++u) {
+      const int64_t r = r0 + u * 256;
+      if (r < a.n) {
+        const int64_t off = r * c + ch0;
+        xv[u] = *reinterpret_cast<const float4*>(a.x + off);
+        if (MODE == STAT_BN_BWD) {
+          yv[u] = *reinterpret_cast<const float4*>(a.y + off);
+          if (a.y_out) ov[u] = *reinterpret_cast<const float4*>(a.y_out + off);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kStatUnroll; ++u) {
+      if (r0 + u * 256 < a.n) {
+        const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+        if (MODE == STAT_XY) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            s1[v] += (double)xs[v];
+            s2[v] += (double)xs[v] * (double)xs[v];
+          }
+        } else {
+          const float gs[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+          const float os[4] = {ov[u].x, ov[u].y, ov[u].z, ov[u].w};
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            float g = gs[v];
+            if (a.y_out && !(os[v] > 0.f)) g = 0.f;
+            const float xhat = (xs[v] - mu[v]) * is[v];
+            s1[v] += (double)g;
+            s2[v] += (double)g * (double)xhat;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    sh[v][tid] = s1[v];
+    sh[4 + v][tid] = s2[v];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int k = tid >> 3, p = tid & 7;      // value k (s1[0..3], s2[0..3]), eighth p of the 256 partials
+    double t = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) t += sh[k][j * 8 + p];
+    t += __shfl_xor(t, 1, 64);
+    t += __shfl_xor(t, 2, 64);
+    t += __shfl_xor(t, 4, 64);
+    const double second = __shfl(t, (tid + 32) & 63, 64);   // lane 8v: s1[v]; lane 8v+32: s2[v]
+    if (tid < 32 && p == 0) {
+      bn_finalize_channel(ch0 + k, t, second, o);
+    }
   }
 }
 
@@ -683,10 +779,15 @@ int usc_bn_forward_stats(const float* x, int64_t n, int32_t c, const float* gamm
   USC_REQUIRE(x && gamma && beta && mean && invstd && scale && shift && ws && n >= 1, "usc_bn_forward_stats: bad argument");
   USC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "usc_bn_forward_stats: running stats mismatch");
   StatArgs a{x, nullptr, nullptr, nullptr, nullptr, n, (int)c};
+  BnFwdOut o{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n, num_batches_tracked};
+  if (n <= bn_small_rows(false) && c % 4 == 0 && c >= 4) {
+    hipLaunchKernelGGL((bn_small_kernel<STAT_XY, BnFwdOut>), dim3((unsigned)(c / 4)), dim3(256), 0, as_stream(s), a, o);
+    USC_CHECK_LAUNCH("usc_bn_forward_stats");
+    return USC_OK;
+  }
   int nb = 0;
   int rc = launch_colstats_partials<STAT_XY>(a, ws, ws_bytes, as_stream(s), "usc_bn_forward_stats", &nb);
   if (rc) return rc;
-  BnFwdOut o{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n, num_batches_tracked};
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c, o);
   USC_CHECK_LAUNCH("usc_bn_forward_stats");
   return USC_OK;
@@ -708,11 +809,16 @@ int usc_bn_backward_reduce(const float* x, const float* dy, const float* y_out, 
   USC_REQUIRE(x && dy && mean && invstd && dgamma && dbeta && mean_g && mean_gxhat && ws && n >= 1,
               "usc_bn_backward_reduce: bad argument");
   StatArgs a{x, dy, y_out, mean, invstd, n, (int)c};
+  BnBwdOut o{dgamma, dbeta, mean_g, mean_gxhat, n, (int)training, (int)accumulate};
+  if (n <= bn_small_rows(true) && c % 4 == 0 && c >= 4) {
+    hipLaunchKernelGGL((bn_small_kernel<STAT_BN_BWD, BnBwdOut>), dim3((unsigned)(c / 4)), dim3(256), 0, as_stream(s), a, o);
+    USC_CHECK_LAUNCH("usc_bn_backward_reduce");
+    return USC_OK;
+  }
   int nb = 0;
   int rc = launch_colstats_partials<STAT_BN_BWD>(a, ws, ws_bytes, as_stream(s), "usc_bn_backward_reduce", &nb);
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c,
-                     n, (int)training, (int)accumulate, dgamma, dbeta, mean_g, mean_gxhat);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)c), dim3(64), 0, as_stream(s), (const double*)ws, nb, (int)c, o);
   USC_CHECK_LAUNCH("usc_bn_backward_reduce");
   return USC_OK;
 }
