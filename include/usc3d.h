@@ -406,6 +406,18 @@ int usc_scatter_add_rows(const float* src, int32_t c, const int64_t* idx,
 int usc_scatter_rows_unique(const float* src, int32_t c, const int64_t* idx,
                             int64_t n, float* dst, usc_stream_t s);
 
+/* The decoder's key sampling of one pass (reference models/mask3d.py:306-346: three row gathers by the sampled
+ * indices, `attn[attn.sum(1) == K] = False`, `attn |= padding`), two launches:
+ *   out_feats[b,k,:] = feats[idx[b*K+k],:]   out_pos likewise (pos may be NULL)   f32, c and p multiples of 4
+ *   out_mask[b,k,:]  = mask[idx[b*K+k],:] (bool bytes [n,q], q <= 128), then
+ *     - a query column that is masked in ALL K gathered rows of its scene is cleared in the scene's real rows,
+ *     - rows k >= n_valid[b] (padding; their idx repeats a real row) are fully masked.
+ * n_valid: HOST array i32[n_scenes] (n_scenes <= 16).  ws: usc_sample_keys_ws_bytes(). */
+int64_t usc_sample_keys_ws_bytes(int32_t n_scenes, int32_t K, int32_t q);
+int usc_sample_keys(const float* feats, int32_t c, const uint8_t* mask, int32_t q, const float* pos, int32_t p,
+                    const int64_t* idx, int32_t n_scenes, int32_t K, const int32_t* n_valid, float* out_feats,
+                    uint8_t* out_mask, float* out_pos, void* ws, int64_t ws_bytes, usc_stream_t s);
+
 /* ------------------------------------------------------------------------
  * Q3  segment mean — replaces torch_scatter.scatter_mean(src, index, dim=0)
  * (models/mask3d.py:12,223; trainer/trainer.py:449) forward + backward.
@@ -548,6 +560,13 @@ int usc_linear_bwd_ex(const float* dy, const float* y_relu, const float* x,
                       const float* x2, const float* W, int32_t M, int32_t N,
                       int32_t K, float* dx, const float* dx_add, float* dW,
                       float* db, int32_t accumulate, usc_stream_t s);
+/* ... and with a second addend and a second output: dx = dy W + dx_add + dx_add2, dx_b = dy W + dx_add (each optional).
+ * One product feeding two gradients — the layer input's, which also collects a residual path (dx_add2), and the
+ * positional term's, which does not (models/mask3d.py:485-494: `tgt + pos` into the projection, `tgt` into the
+ * residual) — without an extra add launch. */
+int usc_linear_bwd_ex2(const float* dy, const float* y_relu, const float* x, const float* x2, const float* W, int32_t M,
+                       int32_t N, int32_t K, float* dx, const float* dx_add, const float* dx_add2, float* dx_b, float* dW,
+                       float* db, int32_t accumulate, usc_stream_t s);
 /* out[c] (+)= sum over the n rows of x f32[n, c]: the bias gradient of a linear
  * layer over many rows (the 3 200 / 12 800 sampled voxels of a decoder pass,
  * models/mask3d.py:351-352 lin_squeeze and the key / value projections of

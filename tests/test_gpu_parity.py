@@ -1340,6 +1340,119 @@ def test_mask_module_several_scenes_equals_the_table_path(device, monkeypatch):
         assert 0.05 < float(a[0].float().mean()) < 0.95
 
 
+@pytest.mark.parametrize("kind", ["cross", "self", "self_no_pos", "ffn"])
+def test_residual_routed_through_the_projection_node(device, kind):
+    """in_proj(..., residual=True) / linear(..., passthrough=True) hand the query input back as an extra output; the
+    gradient that arrives there (the block's residual connection, reference models/mask3d.py:493-494, :523-524,
+    :543-544) must be summed into the input's gradient — and NOT into the positional term's."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(31)
+    E, L, S, B = 128, 100, 300, 2
+    if kind == "ffn":
+        x = torch.randn(L, B, E, generator=g)
+        W, b = torch.randn(256, E, generator=g) * 0.1, torch.randn(256, generator=g)
+        gy, gr = torch.randn(L, B, 256, generator=g), torch.randn(L, B, E, generator=g)
+        xr, Wr, br = (t.clone().requires_grad_() for t in (x, W, b))
+        (torch.relu(xr @ Wr.T + br) * gy).sum().backward()
+        xr.grad += gr
+        xd, Wd, bd = (_dev(t, device).requires_grad_() for t in (x, W, b))
+        y, res = ops.linear(xd, Wd, bd, relu=True, passthrough=True)
+        assert res.data_ptr() == xd.data_ptr()
+        ((y * _dev(gy, device)).sum() + (res * _dev(gr, device)).sum()).backward()
+        for a, r in ((xd, xr), (Wd, Wr), (bd, br)):
+            assert rel_err(a.grad, r.grad) < 2e-6
+        return
+    W, b = torch.randn(3 * E, E, generator=g) * 0.1, torch.randn(3 * E, generator=g)
+    xq = torch.randn(L, B, E, generator=g)
+    pq = None if kind == "self_no_pos" else torch.randn(L, B, E, generator=g)
+    if kind == "cross":
+        xk, pk = torch.randn(S, B, E, generator=g), torch.randn(S, B, E, generator=g)
+    gq, gr = torch.randn(L, B, E, generator=g), torch.randn(L, B, E, generator=g)
+    n_k = S if kind == "cross" else L
+    gk, gv = torch.randn(n_k, B, E, generator=g), torch.randn(n_k, B, E, generator=g)
+
+    def run(lib_path):
+        dev = device if lib_path else "cpu"
+        t = lambda a: None if a is None else a.to(dev).clone().requires_grad_()
+        Wt, bt, xqt, pqt = t(W), t(b), t(xq), t(pq)
+        xkt, pkt = (t(xk), t(pk)) if kind == "cross" else (xqt, pqt)
+        if lib_path:
+            q, k, v, res = ops.in_proj(xqt, xkt, xkt, Wt, bt, pos_q=pqt, pos_k=pkt, residual=True)
+            assert res.data_ptr() == xqt.data_ptr()
+        else:
+            wp = lambda a, c: a if c is None else a + c
+            q = wp(xqt, pqt) @ Wt[:E].T + bt[:E]
+            k = wp(xkt, pkt) @ Wt[E:2 * E].T + bt[E:2 * E]
+            v = xkt @ Wt[2 * E:].T + bt[2 * E:]
+            res = xqt
+        ((q * gq.to(dev)).sum() + (k * gk.to(dev)).sum() + (v * gv.to(dev)).sum() + (res * gr.to(dev)).sum()).backward()
+        out = [Wt.grad, bt.grad, xqt.grad] + ([] if pqt is None else [pqt.grad])
+        if kind == "cross":
+            out += [xkt.grad, pkt.grad]
+        return [o.cpu() for o in out]
+
+    for a, r in zip(run(True), run(False)):
+        assert rel_err(a, r) < 2e-6
+
+
+
+@pytest.mark.parametrize("n_scenes,K,sizes", [(1, 200, [507]), (3, 64, [40, 64, 300]), (2, 800, [2222, 801])])
+def test_sample_keys_equals_the_reference_steps(device, n_scenes, K, sizes):
+    """ops.sample_keys (two launches) == the reference's per-pass sequence (models/mask3d.py:306-346): gather features /
+    attention masks / positional encodings by the sampled indices, clear the mask column of a query whose K keys are
+    all masked, mask the padding keys; and its gradient == index_add of the sampled rows."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(K + n_scenes)
+    Q, C, P = 100, 96, 128
+    n = sum(sizes)
+    feats = torch.randn(n, C, generator=g)
+    pos = torch.randn(n, P, generator=g)
+    mask = torch.rand(n, Q, generator=g) < 0.5
+    mask[:, 3] = True                    # a query masked everywhere -> must end up attending to every real key
+    mask[:, 77] = True
+    off, idx, n_valid, pad = 0, [], [], []
+    for s_ in sizes:
+        if s_ <= K:
+            ix = torch.cat([torch.arange(s_), torch.zeros(K - s_, dtype=torch.int64)])
+            pad.append(torch.arange(K) >= s_)
+        else:
+            ix = torch.randperm(s_, generator=g)[:K]
+            pad.append(torch.zeros(K, dtype=torch.bool))
+        idx.append(ix + off)
+        n_valid.append(min(s_, K))
+        off += s_
+    gidx = torch.cat(idx)
+    # reference steps on the CPU
+    fr = feats.clone().requires_grad_()
+    ra = fr[gidx].view(n_scenes, K, C)
+    rm = mask[gidx].view(n_scenes, K, Q).clone()
+    rm.permute(0, 2, 1)[rm.sum(1) == K] = False
+    rm = torch.logical_or(rm, torch.stack(pad)[..., None])
+    rp = pos[gidx].view(n_scenes, K, P)
+    dy = torch.randn(n_scenes, K, C, generator=g)
+    ra.backward(dy)
+
+    fd = _dev(feats, device).requires_grad_()
+    unique = all(s_ > K for s_ in sizes)
+    for outs in (None, (torch.empty(n_scenes, K, C, device=device), torch.empty(n_scenes, K, Q, dtype=torch.bool, device=device),
+                        torch.empty(n_scenes, K, P, device=device))):
+        fd.grad = None
+        a, m, p_ = ops.sample_keys(fd, _dev(mask, device), _dev(pos, device), _dev(gidx, device), n_scenes, K, n_valid,
+                                   outs=outs, unique=unique)
+        assert torch.equal(a.detach().cpu(), ra.detach()) and torch.equal(p_.cpu(), rp)
+        assert torch.equal(m.cpu(), rm)
+        assert not m.requires_grad and not p_.requires_grad
+        if outs is not None:
+            assert a.data_ptr() == outs[0].data_ptr() and m.data_ptr() == outs[1].data_ptr()
+        a.backward(_dev(dy, device))
+        assert rel_err(fd.grad, fr.grad) < 1e-6
+    # column 3 was masked in every row: cleared in the real rows, still set in the padding rows
+    for b in range(n_scenes):
+        assert not m[b, :n_valid[b], 3].any() and m[b, n_valid[b]:, 3].all()
+
+
 @pytest.mark.parametrize("c", [96, 128, 19])
 def test_gather_rows_backward_unique_and_atomic_paths_agree(device, c):
     """The backward of a row gather: plain stores for an index set without duplicates (`unique=True`: the decoder's

@@ -88,6 +88,8 @@ SIGNATURES = {
     "usc_gather_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_scatter_add_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_scatter_rows_unique": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
+    "usc_sample_keys_ws_bytes": (_i64, [_i32, _i32, _i32]),
+    "usc_sample_keys": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     "usc_segment_csr_ws_bytes": (_i64, [_i64, _i64]),
     "usc_segment_csr": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i64, _p]),
     "usc_segment_mean_fwd": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _p]),
@@ -135,6 +137,7 @@ SIGNATURES = {
     "usc_add_layernorm_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f32, _p, _p, _p, _p, _p]),
     "usc_linear_fwd_ex": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "usc_linear_bwd_ex": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p]),
+    "usc_linear_bwd_ex2": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "usc_layernorm_bwd_ws_bytes": (_i64, [_i64, _i32]),
     "usc_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
     "usc_affine_rows": (C.c_int, [_p, _i32, _i64, _i32, _p, _p, _p]),

@@ -190,7 +190,8 @@ __device__ inline int acc_row16(int reg, int half) { return (reg & 3) + 8 * (reg
 // summed through LDS in wave order (deterministic), each wave finalising four of the sixteen accumulator rows.
 __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int wave, int lane, float* __restrict__ out,
                                          int64_t ld, int row0, int col0, int max_row, const float* __restrict__ bias,
-                                         int accumulate = 0, int relu = 0, const float* __restrict__ add = nullptr) {
+                                         int accumulate = 0, int relu = 0, const float* __restrict__ add = nullptr,
+                                         const float* __restrict__ add2 = nullptr, float* __restrict__ out_b = nullptr) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
@@ -204,6 +205,8 @@ __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int w
       float* dst = out + (int64_t)row * ld + col0 + i;
       float o = v + (bias ? bias[col0 + i] : 0.f) + (accumulate ? *dst : 0.f);
       if (add) o += add[(int64_t)row * ld + col0 + i];
+      if (out_b) out_b[(int64_t)row * ld + col0 + i] = o;      // the sum without add2 (second consumer of the product)
+      if (add2) o += add2[(int64_t)row * ld + col0 + i];
       *dst = relu ? fmaxf(o, 0.f) : o;
     }
   }
@@ -253,11 +256,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 // NEXT chunk's operands in flight while the matrix cores work on the current one (one wave per SIMD: nothing else
 // hides the ~1 us load latency, and with 8 chunks per wave for the 1024-wide FFN the loop was 8 dependent round trips).
 // ymask (optional): the layer's forward output after its fused ReLU — dy counts only where it is > 0;
-// dx_add (optional, [M,K]): added to the result (the other gradient path into the same input).
+// dx_add (optional, [M,K]): added to the result (the other gradient path into the same input);
+// dx_b (optional, [M,K]): also receives dy W + dx_add, while dx receives dy W + dx_add + dx_add2 — the product feeds
+// two gradients (the layer input's, which also has a residual path, and the positional term's, which has not).
 template <bool EX>
 __device__ inline void linear_dx_tile(const float* __restrict__ dy, const float* __restrict__ ymask,
                                       const float* __restrict__ W, int M, int N, int K, float* __restrict__ dx,
-                                      const float* __restrict__ dx_add, int c0, int m0, float (*red)[16][64]) {
+                                      const float* __restrict__ dx_add, const float* __restrict__ dx_add2,
+                                      float* __restrict__ dx_b, int c0, int m0, float (*red)[16][64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int m = m0 + i;
   const float* ya = dy + (int64_t)(m < M ? m : 0) * N + 4 * h;
@@ -302,7 +308,8 @@ __device__ inline void linear_dx_tile(const float* __restrict__ dy, const float*
       for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[4 * t + j], acc);
     }
   }
-  tile_reduce_store(acc, red, wave, lane, dx, K, m0, c0, M, nullptr, 0, 0, EX ? dx_add : nullptr);
+  tile_reduce_store(acc, red, wave, lane, dx, K, m0, c0, M, nullptr, 0, 0, EX ? dx_add : nullptr,
+                    EX ? dx_add2 : nullptr, EX ? dx_b : nullptr);
 }
 
 // dW[N,K] = dy[M,N]^T x[M,K],  db[N] = sum_m dy[m][N]   for the tile (c0, n0); the tiles with c0 == 0 also write db
@@ -375,8 +382,9 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
                                                         const float* __restrict__ x, const float* __restrict__ x2,
                                                         const float* __restrict__ W, int M, int N, int K, int dx_tiles,
                                                         int accumulate, float* __restrict__ dx,
-                                                        const float* __restrict__ dx_add, float* __restrict__ dW,
-                                                        float* __restrict__ db) {
+                                                        const float* __restrict__ dx_add,
+                                                        const float* __restrict__ dx_add2, float* __restrict__ dx_b,
+                                                        float* __restrict__ dW, float* __restrict__ db) {
   // EX = false: the plain layer (no ymask / x2 / dx_add) — the extra operands cost 50 % in this latency-bound kernel
   // when merely tested per element, so the plain form is its own instantiation
   __shared__ float red[4][16][64];
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
   const int kt = K / 32;
   int b = blockIdx.x;
   if (b < dx_tiles) {
-    linear_dx_tile<EX>(dy, ymask, W, M, N, K, dx, dx_add, (b % kt) * 32, (b / kt) * 32, red);
+    linear_dx_tile<EX>(dy, ymask, W, M, N, K, dx, dx_add, dx_add2, dx_b, (b % kt) * 32, (b / kt) * 32, red);
   } else {
     b -= dx_tiles;
     linear_dw_tile<EX>(dy, ymask, x, x2, M, N, K, accumulate, dW, db, (b % kt) * 32, (b / kt) * 32, red, bred);
@@ -460,24 +468,31 @@ int usc_linear_fwd_ex(const float* x, const float* x2, const float* W, const flo
 
 int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M, int32_t N, int32_t K, float* dx, float* dW,
                    float* db, int32_t accumulate, usc_stream_t s) {
-  return usc_linear_bwd_ex(dy, nullptr, x, nullptr, W, M, N, K, dx, nullptr, dW, db, accumulate, s);
+  return usc_linear_bwd_ex2(dy, nullptr, x, nullptr, W, M, N, K, dx, nullptr, nullptr, nullptr, dW, db, accumulate, s);
 }
 
 int usc_linear_bwd_ex(const float* dy, const float* y_relu, const float* x, const float* x2, const float* W, int32_t M,
                       int32_t N, int32_t K, float* dx, const float* dx_add, float* dW, float* db, int32_t accumulate,
                       usc_stream_t s) {
+  return usc_linear_bwd_ex2(dy, y_relu, x, x2, W, M, N, K, dx, dx_add, nullptr, nullptr, dW, db, accumulate, s);
+}
+
+int usc_linear_bwd_ex2(const float* dy, const float* y_relu, const float* x, const float* x2, const float* W, int32_t M,
+                       int32_t N, int32_t K, float* dx, const float* dx_add, const float* dx_add2, float* dx_b, float* dW,
+                       float* db, int32_t accumulate, usc_stream_t s) {
   USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_bwd: N, K must be multiples of 32");
   USC_REQUIRE(dy && x && W, "usc_linear_bwd: null pointer");
+  USC_REQUIRE(dx || !(dx_add || dx_add2 || dx_b), "usc_linear_bwd: dx_add / dx_add2 / dx_b need dx");
   hipStream_t st = usc::as_stream(s);
   const int dx_tiles = dx ? (K / 32) * ((M + 31) / 32) : 0;
   const int dw_tiles = dW ? (K / 32) * (N / 32) : 0;
   if (dx_tiles + dw_tiles > 0) {
-    if (y_relu || x2 || dx_add)
+    if (y_relu || x2 || dx_add || dx_add2 || dx_b)
       hipLaunchKernelGGL(usc::linear_bwd_kernel<true>, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, y_relu, x, x2, W,
-                         (int)M, (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dW, db);
+                         (int)M, (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dx_add2, dx_b, dW, db);
     else
       hipLaunchKernelGGL(usc::linear_bwd_kernel<false>, dim3(dx_tiles + dw_tiles), dim3(256), 0, st, dy, y_relu, x, x2, W,
-                         (int)M, (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dW, db);
+                         (int)M, (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dx_add2, dx_b, dW, db);
   }
   USC_CHECK_LAUNCH("usc_linear_bwd");
   return USC_OK;

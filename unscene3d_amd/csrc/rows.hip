@@ -328,6 +328,119 @@ static int launch_colstats_partials(const StatArgs& a, void* ws, int64_t ws_byte
 }
 
 // ---------------------------------------------------------------------------
+// The decoder's key sampling (reference models/mask3d.py:306-346), per pass: rows idx[] of the level's feature table,
+// of its thresholded attention-mask table and of its positional encodings -> the [B, K, .] inputs of the pass; then
+// "a query whose sampled keys are ALL masked attends to everything" (:346) and "padding keys are masked" (:343).
+// Two launches instead of three gathers, a sum, a compare, an indexed store and an OR.
+//   sample_keys_kernel   grid (ceil(K/16), B), 4 rows per wave, all loads of the 4 rows issued before the stores:
+//                        copies the three rows, ANDs the mask bytes of the block's rows -> part[b][blk][q]; padding
+//                        rows (k >= n_valid[b]; they repeat a real row) enter the AND with their gathered bits and
+//                        are stored as all-masked
+//   sample_fix_kernel    same grid: every workgroup ANDs the scene's partials (words, 8 groups of lanes) and clears
+//                        the all-masked columns in its own real rows — at random init several queries are masked
+//                        everywhere on the fine levels, so the clearing must not be left to one workgroup
+constexpr int kSampleRows = 16;       // rows per workgroup (4 waves x 4 rows)
+constexpr int kSampleMaxQ = 128;
+constexpr int kSampleMaxScenes = 16;
+struct SampleArgs {
+  const float* feats; const unsigned char* mask; const float* pos; const int64_t* idx;
+  float* out_feats; unsigned char* out_mask; float* out_pos; unsigned char* part;
+  int c, q, p, K, nblk, qs;           // qs: q rounded up to a multiple of 4 (row stride of part)
+  int n_valid[kSampleMaxScenes];
+};
+
+__global__ __launch_bounds__(256) void sample_keys_kernel(SampleArgs a) {
+  __shared__ unsigned char acc[4][kSampleMaxQ];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, k0 = blockIdx.x * kSampleRows + wave * 4;
+  const int c4 = a.c >> 2, p4 = a.p >> 2;
+  const int nvalid = a.n_valid[b];
+  const bool has_pos = a.pos != nullptr;
+  // straight-line code (rows past K are clamped to the last row and only their stores are skipped): the 4 rows'
+  // loads are all in flight before the first store
+  int64_t src[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = k0 + r < a.K ? k0 + r : a.K - 1;
+    src[r] = a.idx[(int64_t)b * a.K + k];
+  }
+  float4 f0[4], f1[4], q0[4], q1[4];
+  unsigned char ma[4], mb[4];
+  const bool fa = lane < c4, fb = lane + 64 < c4, pa = has_pos && lane < p4, pb = has_pos && lane + 64 < p4;
+  const bool qa = lane < a.q, qb = lane + 64 < a.q;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float4* f = reinterpret_cast<const float4*>(a.feats + src[r] * a.c);
+    const float4* ps = reinterpret_cast<const float4*>(a.pos + src[r] * a.p);
+    const unsigned char* ms = a.mask + src[r] * a.q;
+    f0[r] = fa ? f[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    f1[r] = fb ? f[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    q0[r] = pa ? ps[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    q1[r] = pb ? ps[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+    ma[r] = qa ? (ms[lane] ? 1 : 0) : 1;
+    mb[r] = qb ? (ms[lane + 64] ? 1 : 0) : 1;
+  }
+  unsigned char m0 = 1, m1 = 1;       // AND of this wave's rows, bytes lane and lane + 64
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool live = k0 + r < a.K;
+    const int64_t o = (int64_t)b * a.K + (live ? k0 + r : 0);
+    float4* fo = reinterpret_cast<float4*>(a.out_feats + o * a.c);
+    float4* po = reinterpret_cast<float4*>(a.out_pos + o * a.p);
+    unsigned char* mo = a.out_mask + o * a.q;
+    const bool pad = k0 + r >= nvalid;
+    if (live && fa) fo[lane] = f0[r];
+    if (live && fb) fo[lane + 64] = f1[r];
+    if (live && pa) po[lane] = q0[r];
+    if (live && pb) po[lane + 64] = q1[r];
+    if (live && qa) mo[lane] = pad ? 1 : ma[r];
+    if (live && qb) mo[lane + 64] = pad ? 1 : mb[r];
+    m0 &= live ? ma[r] : (unsigned char)1;
+    m1 &= live ? mb[r] : (unsigned char)1;
+  }
+  acc[wave][lane] = m0;
+  acc[wave][lane + 64] = m1;
+  __syncthreads();
+  if (threadIdx.x < a.qs) {
+    const int t = threadIdx.x;
+    a.part[((int64_t)b * a.nblk + blockIdx.x) * a.qs + t] = acc[0][t] & acc[1][t] & acc[2][t] & acc[3][t];
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_fix_kernel(SampleArgs a) {
+  __shared__ unsigned int red[8][kSampleMaxQ / 4];
+  __shared__ unsigned char all_masked[kSampleMaxQ];
+  const int b = blockIdx.y, t = threadIdx.x;
+  const int w = t & 31, g = t >> 5, qw = a.qs >> 2;
+  unsigned int v = 0xFFFFFFFFu;
+  if (w < qw) {
+    const unsigned int* pp = reinterpret_cast<const unsigned int*>(a.part + (int64_t)b * a.nblk * a.qs) + w;
+    for (int j = g; j < a.nblk; j += 8) v &= pp[(int64_t)j * qw];
+  }
+  red[g][w] = v;
+  __syncthreads();
+  int any = 0;
+  if (t < qw) {
+    unsigned int r = red[0][t];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) r &= red[j][t];
+    r &= 0x01010101u;
+    reinterpret_cast<unsigned int*>(all_masked)[t] = r;
+    // bytes past q in the last word come from the (all-ones) padding of part: ignore them
+    const int nb = a.q - 4 * t < 4 ? a.q - 4 * t : 4;
+    any = (r & (nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u))) != 0;
+  }
+  if (!__syncthreads_or(any)) return;          // the usual case later in training: every query sees a key
+  const int k0 = blockIdx.x * kSampleRows;
+  const int nv = a.n_valid[b] < a.K ? a.n_valid[b] : a.K;
+  int rows = nv - k0;
+  if (rows > kSampleRows) rows = kSampleRows;
+  unsigned char* m = a.out_mask + ((int64_t)b * a.K + k0) * a.q;
+  for (int e = t; e < rows * a.q; e += 256)
+    if (all_masked[e % a.q]) m[e] = 0;
+}
+
+// ---------------------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift,
@@ -904,6 +1017,36 @@ int usc_gather_rows(const float* src, int32_t c, const int64_t* idx, int64_t n, 
     hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(stream_grid(n * c, 256)), dim3(256), 0, as_stream(s), src, (int)c,
                        idx, n, out);
   USC_CHECK_LAUNCH("usc_gather_rows");
+  return USC_OK;
+}
+
+int64_t usc_sample_keys_ws_bytes(int32_t n_scenes, int32_t K, int32_t q) {
+  return (int64_t)n_scenes * ceil_div((int64_t)K, (int64_t)usc::kSampleRows) * ((q + 3) / 4 * 4);
+}
+
+int usc_sample_keys(const float* feats, int32_t c, const uint8_t* mask, int32_t q, const float* pos, int32_t p,
+                    const int64_t* idx, int32_t n_scenes, int32_t K, const int32_t* n_valid, float* out_feats,
+                    uint8_t* out_mask, float* out_pos, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(n_scenes >= 1 && n_scenes <= usc::kSampleMaxScenes && K >= 1 && c >= 4 && c % 4 == 0 && q >= 1 &&
+                  c <= 512 && q <= usc::kSampleMaxQ && (pos == nullptr || (p >= 4 && p % 4 == 0 && p <= 512)),
+              "usc_sample_keys: unsupported sizes (scenes <= 16, queries <= 128, channel counts multiples of 4 up to 512)");
+  USC_REQUIRE(feats && mask && idx && n_valid && out_feats && out_mask && ws && (pos == nullptr || out_pos),
+              "usc_sample_keys: null pointer");
+  usc::SampleArgs a{};
+  a.feats = feats; a.mask = mask; a.pos = pos; a.idx = idx;
+  a.out_feats = out_feats; a.out_mask = out_mask; a.out_pos = out_pos; a.part = (unsigned char*)ws;
+  a.c = c; a.q = q; a.p = p; a.K = K;
+  a.nblk = (int)ceil_div((int64_t)K, (int64_t)usc::kSampleRows);
+  a.qs = (q + 3) / 4 * 4;
+  USC_REQUIRE(((uintptr_t)ws & 3) == 0, "usc_sample_keys: workspace must be 4-byte aligned");
+  USC_REQUIRE(ws_bytes >= usc_sample_keys_ws_bytes(n_scenes, K, q), "usc_sample_keys: workspace too small");
+  for (int b = 0; b < n_scenes; ++b) {
+    USC_REQUIRE(n_valid[b] >= 1, "usc_sample_keys: a scene without rows");
+    a.n_valid[b] = n_valid[b];
+  }
+  hipLaunchKernelGGL(usc::sample_keys_kernel, dim3((unsigned)a.nblk, (unsigned)n_scenes), dim3(256), 0, as_stream(s), a);
+  hipLaunchKernelGGL(usc::sample_fix_kernel, dim3((unsigned)a.nblk, (unsigned)n_scenes), dim3(256), 0, as_stream(s), a);
+  USC_CHECK_LAUNCH("usc_sample_keys");
   return USC_OK;
 }
 

@@ -25,6 +25,10 @@ from .modules.helpers_3detr import GenericMLP
 from .position_embedding import PositionEmbeddingCoordsSine
 
 SINGLE_POINT_ERROR = "only a single point gives nans in cross-attention"   # trainer.py:125 string-matches this
+# the residual connection of a decoder block routed through the block's first projection node (one autograd add per
+# block and pass less: 36 launches per step)
+_RESIDUAL_IN_PROJECTION = os.environ.get("USC3D_RESIDUAL_IN_PROJECTION", "1") == "1"
+_FUSED_KEY_SAMPLING = os.environ.get("USC3D_FUSED_KEY_SAMPLING", "1") == "1"
 _GATHER_INTO_GRAPH_INPUTS = os.environ.get("USC3D_GATHER_INTO_GRAPH_INPUTS", "1") == "1"
 
 
@@ -158,7 +162,8 @@ class Mask3D(nn.Module):
         return out
 
     @torch.no_grad()
-    def precompute_geometry(self, x, raw_coordinates, point2segment=None, num_segments=None, n_levels=5):
+    def precompute_geometry(self, x, raw_coordinates, point2segment=None, num_segments=None, n_levels=5,
+                            is_eval=False):
         """Everything of the forward pass that depends only on the scene's GEOMETRY — coordinates, raw coordinates,
         segment ids — and on no learnt parameter (reference :205-241): the pooled raw coordinates of every level, their
         Fourier encodings, the segment CSRs, the farthest-point query seeds and their encodings.  ~0.7 ms of
@@ -192,8 +197,56 @@ class Mask3D(nn.Module):
             maxs = _stack([m[1] for m in mm])
             geo.update(fps_idx=fps_idx, sampled_coords=sampled_coords,
                        query_pos_enc=self.pos_enc(sampled_coords.float(), input_range=[mins, maxs]))     # B, d, Q
+        # the cross-attention key samples of all passes (reference :325 draws them inside the decoder loop; they depend
+        # on the level sizes only): ~9 launches each (arange, random keys, sort, de-duplication) taken off the
+        # decoder's critical path.  `forward` consumes them ONCE (a second forward over the same maps draws again).
+        geo["key_samples"] = self._draw_key_samples(coords, is_eval)
         cm.geometry = geo
         return geo
+
+    def _graph_key(self):
+        g = getattr(self, "_graphed_passes", None)
+        return None if g is None else id(g)
+
+    def _draw_key_samples(self, coords, is_eval):
+        """Per decoder pass (decoder-major, level-minor: the order the reference draws in): the number of keys, the
+        per-scene row indices (random subset or everything + padding) and padding masks, the batch-wide row index and
+        whether every scene was sub-sampled (reference :306-343)."""
+        dev = coords[0].F.device
+        level_sizes = [[f.shape[0] for f in lv.decomposed_features] for lv in coords]
+        slices = [lv.coordinate_manager.batch_slices(lv._ts()) for lv in coords]
+        graphed = getattr(self, "_graphed_passes", None) is not None
+        passes = []
+        for decoder_counter in range(self.num_decoders):
+            for i, hlevel in enumerate(self.hlevels):
+                sizes = level_sizes[hlevel]
+                curr = max(sizes)
+                if not (self.max_sample_size or is_eval):
+                    curr = min(curr, self.sample_sizes[hlevel])
+                if graphed:
+                    want = self._graph_shapes[decoder_counter * self.num_levels + i][2][1]
+                    if curr < want:
+                        # a level smaller than the captured key count: pad up to it (row 0, masked like the padding of
+                        # a ragged batch) so the captured pass still applies.  Masked keys carry softmax weight 0: the
+                        # pass output is that of the unpadded keys, and the all-masked-row rule is unchanged because
+                        # the padding repeats row 0's mask bits.
+                        curr = want
+                rand_idx, mask_idx = [], []
+                for pcd_size in sizes:
+                    if pcd_size <= curr:              # take everything, pad with row 0 and mask the padding
+                        idx, midx = _padded_index(pcd_size, curr, dev)
+                    else:                             # random subset, nothing masked
+                        idx = self.randperm(pcd_size, dev)[:curr]
+                        midx = _padded_index(curr, curr, dev)[1]
+                    rand_idx.append(idx)
+                    mask_idx.append(midx)
+                gidx = None
+                if all(isinstance(sl, slice) for sl in slices[hlevel]):      # scenes are contiguous row ranges
+                    gidx = rand_idx[0] if len(sizes) == 1 else torch.cat(
+                        [rand_idx[k] + slices[hlevel][k].start for k in range(len(sizes))])
+                passes.append({"k": curr, "rand_idx": rand_idx, "mask_idx": mask_idx, "gidx": gidx,
+                               "all_sampled": all(n > curr for n in sizes), "sizes": sizes})
+        return {"passes": passes, "is_eval": bool(is_eval), "graph_key": self._graph_key()}
 
     def forward(self, x, point2segment=None, raw_coordinates=None, is_eval=False, num_segments=None):
         """`num_segments` (optional, one int per scene): the number of segments = point2segment.max() + 1 when the
@@ -239,6 +292,10 @@ class Mask3D(nn.Module):
             queries = self.query_feat.weight.unsqueeze(0).repeat(n_scenes, 1, 1)
             query_pos = self.query_pos.weight.unsqueeze(1).repeat(1, n_scenes, 1)
 
+        samples = geo.pop("key_samples", None)         # drawn with the geometry (prefetch stream), used once
+        if samples is None or samples["is_eval"] != bool(is_eval) or samples["graph_key"] != self._graph_key():
+            samples = self._draw_key_samples(coords, is_eval)
+
         predictions_class, predictions_mask = [], []
         p2s_arg = point2segment if self.train_on_segments else None
         for decoder_counter in range(self.num_decoders):
@@ -253,27 +310,13 @@ class Mask3D(nn.Module):
                 sizes = [f.shape[0] for f in decomposed_aux]
                 if min(sizes) == 1:
                     raise RuntimeError(SINGLE_POINT_ERROR)
-                curr_sample_size = max(sizes)
-                if not (self.max_sample_size or is_eval):
-                    curr_sample_size = min(curr_sample_size, self.sample_sizes[hlevel])
+                plan = samples["passes"][decoder_counter * self.num_levels + i]
+                if plan["sizes"] != sizes:
+                    raise RuntimeError(f"key samples were drawn for level sizes {plan['sizes']}, the backbone produced "
+                                       f"{sizes}")
+                curr_sample_size, rand_idx, mask_idx = plan["k"], plan["rand_idx"], plan["mask_idx"]
                 graph_shapes = (self._graph_shapes[decoder_counter * self.num_levels + i]
                                 if getattr(self, "_graphed_passes", None) is not None else None)
-                if graph_shapes is not None and curr_sample_size < graph_shapes[2][1]:
-                    # a level smaller than the captured key count: pad up to it (row 0, masked like the padding of a
-                    # ragged batch below) so the captured pass still applies.  Masked keys carry softmax weight 0:
-                    # the pass output is that of the unpadded keys, and the all-masked-row rule below is unchanged
-                    # because the padding repeats row 0's mask bits.
-                    curr_sample_size = graph_shapes[2][1]
-
-                rand_idx, mask_idx = [], []
-                for k, pcd_size in enumerate(sizes):
-                    if pcd_size <= curr_sample_size:      # take everything, pad with row 0 and mask the padding
-                        idx, midx = _padded_index(pcd_size, curr_sample_size, queries.device)
-                    else:                                  # random subset, nothing masked
-                        idx = self.randperm(pcd_size, queries.device)[:curr_sample_size]
-                        midx = _padded_index(curr_sample_size, curr_sample_size, queries.device)[1]
-                    rand_idx.append(idx)
-                    mask_idx.append(midx)
 
                 step_fn = self._decoder_pass(decoder_counter, dec, i)
                 bufs = None
@@ -284,18 +327,35 @@ class Mask3D(nn.Module):
                             (n_scenes, curr_sample_size, pos_encodings_pcd[hlevel][0][0].shape[1]))
                     if tuple(tuple(h) for h in have) != tuple(tuple(w) for w in want):
                         step_fn = self._eager_pass(dec, i)
-                    elif _GATHER_INTO_GRAPH_INPUTS:
-                        slices = aux[hlevel].coordinate_manager.batch_slices(aux[hlevel]._ts())
-                        if all(isinstance(sl, slice) for sl in slices):      # scenes are contiguous row ranges
-                            bufs = step_fn.input_buffers    # gather straight into the captured pass's input buffers
-                if bufs is not None:
+                    elif _GATHER_INTO_GRAPH_INPUTS and plan["gidx"] is not None:
+                        bufs = step_fn.input_buffers    # gather straight into the captured pass's input buffers
+                feats_l = aux[hlevel].F
+                fused = (_FUSED_KEY_SAMPLING and plan["gidx"] is not None and feats_l.is_cuda
+                         and feats_l.dtype == torch.float32 and n_scenes <= 16 and attn_mask.F.dtype == torch.bool
+                         and attn_mask.F.shape[1] <= 128 and feats_l.shape[1] % 4 == 0
+                         and pos_encodings_pcd[hlevel][0][0].shape[1] % 4 == 0)
+                if fused:
+                    # two launches: the three row gathers (straight into the captured pass's input buffers when there
+                    # are any), the all-masked-query rule (reference :346) and the padding mask (:343)
+                    if n_scenes == 1:
+                        pos_l = pos_encodings_pcd[hlevel][0][0]
+                    else:
+                        cat = geo.setdefault("pos_cat", {})
+                        if hlevel not in cat:
+                            cat[hlevel] = torch.cat(pos_encodings_pcd[hlevel][0])
+                        pos_l = cat[hlevel]
+                    outs = None if bufs is None else (bufs[2], bufs[3], bufs[4])
+                    batched_aux, batched_attn, batched_pos_enc = ops.sample_keys(
+                        feats_l.contiguous(), attn_mask.F.contiguous(), pos_l.contiguous(), plan["gidx"], n_scenes,
+                        curr_sample_size, [min(n, curr_sample_size) for n in sizes], outs=outs,
+                        unique=plan["all_sampled"])
+                elif bufs is not None:
                     # ONE gather for the whole batch: rows of the level's feature / mask tables addressed by
                     # scene offset + sampled index, written into the [B, K, .] input buffers of the captured pass
-                    gidx = rand_idx[0] if n_scenes == 1 else torch.cat(
-                        [rand_idx[k] + slices[k].start for k in range(n_scenes)])
-                    feats_l = aux[hlevel].F.contiguous()
+                    gidx = plan["gidx"]
+                    feats_l = feats_l.contiguous()
                     batched_aux = ops.gather_rows(feats_l, gidx, out=bufs[2].view(-1, feats_l.shape[1]),
-                                                  unique=all(n > curr_sample_size for n in sizes)).view(bufs[2].shape)
+                                                  unique=plan["all_sampled"]).view(bufs[2].shape)
                     batched_attn = torch.index_select(attn_mask.F, 0, gidx,
                                                       out=bufs[3].view(-1, bufs[3].shape[2])).view(bufs[3].shape)
                     for k in range(n_scenes):
@@ -307,14 +367,17 @@ class Mask3D(nn.Module):
                     batched_attn = _stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
                     batched_pos_enc = _stack([pos_encodings_pcd[hlevel][0][k][rand_idx[k], :] for k in range(n_scenes)])
 
-                # a query whose sampled keys are all masked attends to everything (reference :346)
-                batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
-                if all(n > curr_sample_size for n in sizes):
-                    pass                                   # every scene was sampled: no padding rows to mask
-                elif bufs is not None:
-                    torch.logical_or(batched_attn, _stack(mask_idx)[..., None], out=batched_attn)
+                if fused:
+                    pass
                 else:
-                    batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
+                    # a query whose sampled keys are all masked attends to everything (reference :346)
+                    batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
+                    if plan["all_sampled"]:
+                        pass                               # every scene was sampled: no padding rows to mask
+                    elif bufs is not None:
+                        torch.logical_or(batched_attn, _stack(mask_idx)[..., None], out=batched_attn)
+                    else:
+                        batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
 
                 rec = getattr(self, "attn_mask_record", None)
                 if rec is not None:          # parity tests: the thresholded masks are discrete decisions
@@ -443,7 +506,7 @@ def _mask_logits(feats, mask_embed):
 
 
 def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None, mask_bsl=None, pos_q=None,
-                        pos_k=None):
+                        pos_k=None, residual=False):
     """nn.MultiheadAttention.forward(query + pos_q, key + pos_k, value, attn_mask=…, need_weights=False)[0] for the
     sequence-first layout, dropout 0 and a boolean mask (True = masked), with the input / output projections
     through ops.in_proj / ops.linear (same parameters, same state_dict); the positional adds of the reference
@@ -452,15 +515,23 @@ def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask
     S = key.shape[0]
     H = mha.num_heads
     hd = E // H
-    q, k, v = ops.in_proj(query, key, value, mha.in_proj_weight, mha.in_proj_bias, pos_q=pos_q, pos_k=pos_k)
+    # residual: -> (output, query'), query' = `query` routed through the projection node so that the gradient of the
+    # block's residual connection is summed inside the projection's input-gradient launch (no separate add)
+    res = None
+    if residual:
+        q, k, v, res = ops.in_proj(query, key, value, mha.in_proj_weight, mha.in_proj_bias, pos_q=pos_q, pos_k=pos_k,
+                                   residual=True)
+    else:
+        q, k, v = ops.in_proj(query, key, value, mha.in_proj_weight, mha.in_proj_bias, pos_q=pos_q, pos_k=pos_k)
+    done = (lambda o: (o, res)) if residual else (lambda o: o)
     if mask_bsl is not None and hd == 16 and L <= 128:
         # `mask_bsl` = the decoder's bool[B, S, L] mask (same for every head): fused HIP kernels, no score tensor
         out = ops.masked_cross_attention(q, k, v, mask_bsl, H)
-        return ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+        return done(ops.linear(out, mha.out_proj.weight, mha.out_proj.bias))
     if mask_bsl is None and attn_mask is None and hd == 16 and L == S and L <= 128:
         # the decoder's self attention (100 queries): one HIP launch each way instead of the library's fused kernels
         out = ops.self_attention(q, k, v, H)
-        return ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+        return done(ops.linear(out, mha.out_proj.weight, mha.out_proj.bias))
     if mask_bsl is not None:
         attn_mask = mask_bsl.repeat_interleave(H, dim=0).permute(0, 2, 1)
     q = q.reshape(L, B * H, hd).transpose(0, 1).reshape(B, H, L, hd)
@@ -478,7 +549,7 @@ def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask
                                alpha=1.0 / (hd ** 0.5))
         out = torch.bmm(torch.softmax(scores, dim=-1), v.reshape(B * H, S, hd)).reshape(B, H, L, hd)
     out = out.permute(2, 0, 1, 3).reshape(L, B, E)
-    return ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    return done(ops.linear(out, mha.out_proj.weight, mha.out_proj.bias))
 
 
 class LayerNorm(nn.LayerNorm):
@@ -591,8 +662,12 @@ class SelfAttentionLayer(nn.Module):
         # need_weights=False: same output; skips materialising/averaging the [B,Q,K] attention weights the
         # reference computes and discards (`[0]`), and lets PyTorch take its fused SDPA path
         if tgt_key_padding_mask is None and self.self_attn.dropout == 0.0 and src.is_cuda:
-            upd = multihead_attention(self.self_attn, src, src, src, attn_mask=tgt_mask, pos_q=query_pos,
-                                      pos_k=query_pos)
+            if not self.normalize_before and _RESIDUAL_IN_PROJECTION:
+                upd, tgt = multihead_attention(self.self_attn, src, src, src, attn_mask=tgt_mask, pos_q=query_pos,
+                                               pos_k=query_pos, residual=True)
+            else:
+                upd = multihead_attention(self.self_attn, src, src, src, attn_mask=tgt_mask, pos_q=query_pos,
+                                          pos_k=query_pos)
         else:
             q = k = _with_pos(src, query_pos)
             upd = self.self_attn(q, k, value=src, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask,
@@ -620,8 +695,12 @@ class CrossAttentionLayer(nn.Module):
         if memory_mask is None and memory_mask_bsl is not None and not src.is_cuda:
             memory_mask = memory_mask_bsl.repeat_interleave(self.multihead_attn.num_heads, dim=0).permute(0, 2, 1)
         if memory_key_padding_mask is None and self.multihead_attn.dropout == 0.0 and src.is_cuda:
-            upd = multihead_attention(self.multihead_attn, src, memory, memory, attn_mask=memory_mask,
-                                      mask_bsl=memory_mask_bsl, pos_q=query_pos, pos_k=pos)
+            if not self.normalize_before and _RESIDUAL_IN_PROJECTION:
+                upd, tgt = multihead_attention(self.multihead_attn, src, memory, memory, attn_mask=memory_mask,
+                                               mask_bsl=memory_mask_bsl, pos_q=query_pos, pos_k=pos, residual=True)
+            else:
+                upd = multihead_attention(self.multihead_attn, src, memory, memory, attn_mask=memory_mask,
+                                          mask_bsl=memory_mask_bsl, pos_q=query_pos, pos_k=pos)
         else:
             upd = self.multihead_attn(query=_with_pos(src, query_pos), key=_with_pos(memory, pos), value=memory,
                                       attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask,
@@ -646,7 +725,12 @@ class FFNLayer(nn.Module):
         src = self.norm(tgt) if self.normalize_before else tgt
         if src.is_cuda and src.dtype == torch.float32 and self.activation is F.relu and (self.dropout.p == 0.0
                                                                                           or not self.training):
-            hidden = ops.linear(src, self.linear1.weight, self.linear1.bias, relu=True)   # ReLU in the same launch
+            if not self.normalize_before and _RESIDUAL_IN_PROJECTION:
+                # ReLU in the same launch; `tgt` comes back through the layer's node: the residual's gradient is summed
+                # inside linear1's input-gradient launch
+                hidden, tgt = ops.linear(src, self.linear1.weight, self.linear1.bias, relu=True, passthrough=True)
+            else:
+                hidden = ops.linear(src, self.linear1.weight, self.linear1.bias, relu=True)   # ReLU in the same launch
         else:
             hidden = self.dropout(self.activation(self.linear1(src)))
         return _residual_norm(self, tgt, self.linear2(hidden))

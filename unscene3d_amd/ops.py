@@ -628,6 +628,70 @@ def gather_rows(src, idx, out=None, unique=False):
     return _GatherRows.apply(src, idx, out, unique)
 
 
+class _SampleKeys(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, mask, pos, idx, n_scenes, K, n_valid, outs, unique):
+        c, q = feats.shape[1], mask.shape[1]
+        p = 0 if pos is None else pos.shape[1]
+        dev = feats.device
+        if outs is None:
+            of = torch.empty((n_scenes, K, c), dtype=torch.float32, device=dev)
+            om = torch.empty((n_scenes, K, q), dtype=torch.bool, device=dev)
+            op = None if pos is None else torch.empty((n_scenes, K, p), dtype=torch.float32, device=dev)
+        else:
+            # fresh tensor objects over the caller's storage: the objects returned from here get autograd metadata
+            of, om, op = (None if o is None else o.detach() for o in outs)
+            want = ((n_scenes, K, c), (n_scenes, K, q)) + (() if pos is None else ((n_scenes, K, p),))
+            have = (tuple(of.shape), tuple(om.shape)) + (() if pos is None else (tuple(op.shape),))
+            if have != want or of.dtype != torch.float32 or om.dtype != torch.bool or not of.is_contiguous() \
+                    or not om.is_contiguous() or (op is not None and (
+                        op.dtype != torch.float32 or not op.is_contiguous())):
+                raise RuntimeError(f"sample_keys: output buffers {have} do not fit {want} (contiguous f32 / bool / f32): "
+                                   f"dtypes {of.dtype}, {om.dtype}, {None if op is None else op.dtype}; "
+                                   f"strides {of.stride()}, {om.stride()}")
+        import ctypes
+        nv = (ctypes.c_int32 * n_scenes)(*[int(v) for v in n_valid])
+        wsb = lib.usc_sample_keys_ws_bytes(n_scenes, K, q)
+        ws = _ws(wsb, dev)
+        check(lib.usc_sample_keys(_ptr(feats), c, _ptr(mask), q, _ptr(pos), p, _ptr(idx), n_scenes, K, nv, _ptr(of),
+                                  _ptr(om), _ptr(op), _ptr(ws), ws.numel(), _stream()), "usc_sample_keys")
+        ctx.save_for_backward(idx)
+        ctx.n_src, ctx.unique = feats.shape[0], bool(unique)
+        ctx.mark_non_differentiable(om)
+        if op is not None:
+            ctx.mark_non_differentiable(op)
+            return of, om, op
+        return of, om
+
+    @staticmethod
+    def backward(ctx, dfeats, *_):
+        (idx,) = ctx.saved_tensors
+        dfeats = dfeats.contiguous().view(idx.shape[0], -1)
+        dsrc = torch.zeros((ctx.n_src, dfeats.shape[1]), dtype=torch.float32, device=dfeats.device)
+        fn = lib.usc_scatter_rows_unique if ctx.unique else lib.usc_scatter_add_rows
+        check(fn(_ptr(dfeats), dfeats.shape[1], _ptr(idx), idx.shape[0], _ptr(dsrc), _stream()), "usc_scatter_add_rows")
+        return (dsrc,) + (None,) * 8
+
+
+def sample_keys(feats, mask, pos, idx, n_scenes, K, n_valid, outs=None, unique=False):
+    """The cross-attention keys of one decoder pass (reference models/mask3d.py:306-346) in two launches:
+    rows `idx` (i64[n_scenes*K], batch-wide row numbers) of the level's features f32[n,c], thresholded attention
+    masks bool[n,Q] and positional encodings f32[n,p] (or None) -> ([B,K,c], bool[B,K,Q], [B,K,p]); a query column
+    masked in all K rows of its scene is cleared; rows k >= n_valid[b] (padding) are fully masked.
+    outs: the caller's three buffers (e.g. the inputs of a captured pass).  Gradient: features only (scatter;
+    `unique` as in gather_rows)."""
+    _chk(feats, torch.float32, "feats")
+    _chk(mask, torch.bool, "mask")
+    _chk(idx, torch.int64, "idx")
+    if pos is not None:
+        _chk(pos, torch.float32, "pos")
+        if pos.shape[0] != feats.shape[0]:
+            raise RuntimeError("sample_keys: pos and feats must have the same rows")
+    if mask.shape[0] != feats.shape[0] or idx.shape[0] != n_scenes * K or len(n_valid) != n_scenes:
+        raise RuntimeError("sample_keys: inconsistent sizes")
+    return _SampleKeys.apply(feats, mask, pos, idx, int(n_scenes), int(K), list(n_valid), outs, unique)
+
+
 def gather_rows_i32(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     """Row gather of an int32 table (coordinates) through the same kernel (bit pattern copy)."""
     _chk(src, torch.int32, "src")
@@ -882,11 +946,26 @@ def col_sum(x2, out, accumulate=False):
     return out
 
 
-def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False, add=None, y_relu=None, dx_add=None):
+def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False, add=None, y_relu=None, dx_add=None,
+             dx_add2=None, want_dx_b=False):
     """-> dx (or None); writes (accumulate: adds) dW_out [N,K] and db_out [N] (row-block views are fine).
-    add: the layer's input was x2 + add; y_relu: its output after the fused ReLU; dx_add: added to dx."""
+    add: the layer's input was x2 + add; y_relu: its output after the fused ReLU; dx_add: added to dx.
+    dx_add2 / want_dx_b: -> (dx, dx_b) with dx = dy W + dx_add + dx_add2 and dx_b = dy W + dx_add (usc_linear_bwd_ex2)."""
     M, N = dy2.shape
     K = x2.shape[1]
+    if want_dx_b or dx_add2 is not None:
+        if not need_dx:
+            return (None, None) if want_dx_b else None
+        if _small_linear_ok(M, K, N):
+            dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device)
+            dx_b = torch.empty_like(dx) if want_dx_b else None
+            check(lib.usc_linear_bwd_ex2(_ptr(dy2), _ptr(y_relu), _ptr(x2), _ptr(add), _ptr(W), M, N, K, _ptr(dx),
+                                         _ptr(dx_add), _ptr(dx_add2), _ptr(dx_b), _ptr(dW_out), _ptr(db_out),
+                                         int(accumulate), _stream()), "usc_linear_bwd")
+        else:
+            dx_b = _lin_bwd(dy2, x2, W, dW_out, db_out, True, accumulate, add, y_relu, dx_add)
+            dx = dx_b if dx_add2 is None else dx_b + dx_add2
+        return (dx, dx_b) if want_dx_b else dx
     if _small_linear_ok(M, K, N):
         dx = torch.empty((M, K), dtype=torch.float32, device=dy2.device) if need_dx else None
         check(lib.usc_linear_bwd_ex(_ptr(dy2), _ptr(y_relu), _ptr(x2), _ptr(add), _ptr(W), M, N, K, _ptr(dx),
@@ -922,16 +1001,19 @@ def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False, add=Non
 
 class _LinearRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, relu=False):
+    def forward(ctx, x, W, b, relu=False, passthrough=False):
         x2 = x.contiguous().view(-1, x.shape[-1])
         y = _lin_fwd(x2, W, b, relu=relu)
         ctx.save_for_backward(x2, W, y if relu else None)
         ctx.has_bias, ctx.shape = b is not None, x.shape
         ctx.w_param, ctx.b_param = W, b
-        return y.view(*x.shape[:-1], W.shape[0])
+        y = y.view(*x.shape[:-1], W.shape[0])
+        # passthrough: x is handed back as a second output; whatever gradient arrives there (the residual path around
+        # the layer) is added inside the input-gradient launch instead of by a separate autograd add
+        return (y, x) if passthrough else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x2, W, y_relu = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, W.shape[0])
         tw = _grad_target(ctx.w_param)
@@ -942,18 +1024,22 @@ class _LinearRows(torch.autograd.Function):
         else:
             dW = torch.empty_like(W)
             db = torch.empty(W.shape[0], dtype=torch.float32, device=W.device) if ctx.has_bias else None
-        dx = _lin_bwd(dy2, x2, W, dW, db, need_dx=ctx.needs_input_grad[0], accumulate=in_place, y_relu=y_relu)
+        dres2 = None if dres is None else dres.contiguous().view(-1, x2.shape[1])
+        dx = _lin_bwd(dy2, x2, W, dW, db, need_dx=ctx.needs_input_grad[0], accumulate=in_place, y_relu=y_relu,
+                      dx_add=dres2)
         if in_place:
             dW = db = None
             _grad_written(ctx.w_param, ctx.b_param if ctx.has_bias else None)
-        return (None if dx is None else dx.view(ctx.shape)), dW, db, None
+        return (None if dx is None else dx.view(ctx.shape)), dW, db, None, None
 
 
-def linear(x, W, b=None, relu=False):
+def linear(x, W, b=None, relu=False, passthrough=False):
     """F.linear(x, W, b) (relu: followed by ReLU, in the same launch on the few-row kernels) for f32 HIP tensors;
-    few-row inputs run on the wave-per-tile MFMA kernels of decoder.hip."""
+    few-row inputs run on the wave-per-tile MFMA kernels of decoder.hip.
+    passthrough: -> (y, x'), x' = x as an output of the same autograd node: use it for the residual connection
+    around the layer, its gradient is then summed inside the layer's input-gradient launch."""
     _chk(W, torch.float32, "W")
-    return _LinearRows.apply(x, W, b, relu)
+    return _LinearRows.apply(x, W, b, relu, passthrough)
 
 
 class _InProj(torch.autograd.Function):
@@ -966,7 +1052,7 @@ class _InProj(torch.autograd.Function):
     separate tensors added by autograd."""
 
     @staticmethod
-    def forward(ctx, xq, xk, xv, W, b, pos_q, pos_k):
+    def forward(ctx, xq, xk, xv, W, b, pos_q, pos_k, residual=False):
         E = W.shape[1]
         xs = [t.contiguous().view(-1, E) for t in (xq, xk, xv)]
         ps = [None if t is None else t.contiguous().view(-1, E) for t in (pos_q, pos_k, None)]
@@ -986,12 +1072,16 @@ class _InProj(torch.autograd.Function):
         # or one tensor) — also when a term was folded into the many-row input above
         ctx.same_qk, ctx.same_kv = same(xq, xk), same(xk, xv)
         ctx.same_pos = (pos_q is None and pos_k is None) or same(pos_q, pos_k)
-        return tuple(o.view(*shp[:-1], E) for o, shp in zip(outs, ctx.shapes))
+        out = tuple(o.view(*shp[:-1], E) for o, shp in zip(outs, ctx.shapes))
+        # residual: xq is handed back as a fourth output (the `tgt + attention(tgt ...)` residual of the decoder
+        # blocks); its gradient joins the query input's inside the input-gradient launches
+        return out + (xq,) if residual else out
 
     @staticmethod
-    def backward(ctx, dq, dk, dv):
+    def backward(ctx, dq, dk, dv, dres=None):
         x0, x1, x2, W, p0, p1 = ctx.saved_tensors
         E = W.shape[1]
+        dres2 = None if dres is None else dres.contiguous().view(-1, E)
         tw, tb = _grad_target(ctx.w_param), _grad_target(ctx.b_param)
         in_place = tw is not None and tb is not None
         if in_place:
@@ -1006,6 +1096,37 @@ class _InProj(torch.autograd.Function):
             return _lin_bwd(dyj.contiguous().view(-1, E), xj, W[j * E:(j + 1) * E], dW[j * E:(j + 1) * E],
                             db[j * E:(j + 1) * E], need_dx=need_dx, accumulate=in_place, add=pj, dx_add=dx_add)
 
+        if dres2 is not None and ctx.same_qk and ctx.same_kv and ctx.same_pos and need[0]:
+            # self attention with the residual: v (+ residual) first, then k, then q on top of both; the q launch also
+            # writes the sum WITHOUT the v/residual part — the positional term's gradient
+            gv = bwd(2, dv, x2, None, True, dx_add=dres2)
+            gk = bwd(1, dk, x1, p1, True)
+            gx, gpos = _lin_bwd(dq.contiguous().view(-1, E), x0, W[:E], dW[:E], db[:E], need_dx=True,
+                                accumulate=in_place, add=p0, dx_add=gk, dx_add2=gv, want_dx_b=True)
+            out_x = (gx, None, None)
+            out_p = (gpos if need_pq else None, None)
+        elif dres2 is not None and not ctx.same_qk and need[0]:
+            # cross attention with the residual: the query product feeds d(tgt) (+ residual) and d(query_pos)
+            gk = bwd(1, dk, x1, p1, need[1] or need_pk)
+            gq, gq_pos = _lin_bwd(dq.contiguous().view(-1, E), x0, W[:E], dW[:E], db[:E], need_dx=True,
+                                  accumulate=in_place, add=p0, dx_add2=dres2, want_dx_b=True)
+            chain_v = ctx.same_kv and gk is not None
+            gv = bwd(2, dv, x2, None, need[2], dx_add=gk if chain_v else None)
+            out_x = (gq, gv, None) if chain_v else (gq, gk, gv)
+            out_p = (gq_pos if need_pq else None, gk if need_pk else None)
+        else:
+            out_x, out_p = _InProj._backward_plain(ctx, bwd, dq, dk, dv, x0, x1, x2, p0, p1, need, need_pq, need_pk)
+            if dres2 is not None and need[0]:          # shapes the fused forms above do not cover
+                out_x = (dres2 if out_x[0] is None else out_x[0] + dres2,) + tuple(out_x[1:])
+        if in_place:
+            dW = db = None
+            _grad_written(ctx.w_param, ctx.b_param)
+        gx = tuple(None if (g is None or not n) else g.view(shp) for g, n, shp in zip(out_x, need, ctx.shapes))
+        gp = tuple(None if g is None else g.view(shp) for g, shp in zip(out_p, ctx.pos_shapes))
+        return gx + (dW, db) + gp + (None,)
+
+    @staticmethod
+    def _backward_plain(ctx, bwd, dq, dk, dv, x0, x1, x2, p0, p1, need, need_pq, need_pk):
         # k first, then q on top of it when they share the input (and the positional term); v last on top of both
         # when it shares the input too: one summed tensor per distinct input
         gk = bwd(1, dk, x1, p1, need[1] or need_pk)
@@ -1024,15 +1145,10 @@ class _InProj(torch.autograd.Function):
             gv = bwd(2, dv, x2, None, need[2], dx_add=gk if chain_v else None)
             out_x = (gq, gv, None) if chain_v else (gq, gk, gv)
             out_p = (gq if need_pq else None, gk if need_pk else None)
-        if in_place:
-            dW = db = None
-            _grad_written(ctx.w_param, ctx.b_param)
-        gx = tuple(None if (g is None or not n) else g.view(shp) for g, n, shp in zip(out_x, need, ctx.shapes))
-        gp = tuple(None if g is None else g.view(shp) for g, shp in zip(out_p, ctx.pos_shapes))
-        return gx + (dW, db) + gp
+        return out_x, out_p
 
 
-def in_proj(xq, xk, xv, W, b, pos_q=None, pos_k=None):
+def in_proj(xq, xk, xv, W, b, pos_q=None, pos_k=None, residual=False):
     _chk(W, torch.float32, "in_proj_weight")
     _chk(b, torch.float32, "in_proj_bias")
     # the kernels read the positional term row for row: no broadcasting (a [Q,1,E] term with B > 1 would be read
@@ -1041,7 +1157,7 @@ def in_proj(xq, xk, xv, W, b, pos_q=None, pos_k=None):
         raise RuntimeError(f"in_proj: pos_q {tuple(pos_q.shape)} must have the shape of the query input {tuple(xq.shape)}")
     if pos_k is not None and pos_k.shape != xk.shape:
         raise RuntimeError(f"in_proj: pos_k {tuple(pos_k.shape)} must have the shape of the key input {tuple(xk.shape)}")
-    return _InProj.apply(xq, xk, xv, W, b, pos_q, pos_k)
+    return _InProj.apply(xq, xk, xv, W, b, pos_q, pos_k, residual)
 
 
 class _MaskedCrossAttention(torch.autograd.Function):
