@@ -28,6 +28,7 @@ SINGLE_POINT_ERROR = "only a single point gives nans in cross-attention"   # tra
 # the residual connection of a decoder block routed through the block's first projection node (one autograd add per
 # block and pass less: 36 launches per step)
 _RESIDUAL_IN_PROJECTION = os.environ.get("USC3D_RESIDUAL_IN_PROJECTION", "1") == "1"
+_LAZY_HOST_COPIES = os.environ.get("USC3D_LAZY_HOST_COPIES", "1") == "1"
 _FUSED_KEY_SAMPLING = os.environ.get("USC3D_FUSED_KEY_SAMPLING", "1") == "1"
 _GATHER_INTO_GRAPH_INPUTS = os.environ.get("USC3D_GATHER_INTO_GRAPH_INPUTS", "1") == "1"
 
@@ -399,7 +400,7 @@ class Mask3D(nn.Module):
             "pred_logits": predictions_class[-1],
             "pred_masks": predictions_mask[-1],
             "aux_outputs": self._set_aux_loss(predictions_class, predictions_mask),
-            "sampled_coords": sampled_coords.detach().cpu().numpy() if sampled_coords is not None else None,
+            "sampled_coords": _host_array(sampled_coords) if sampled_coords is not None else None,
             "backbone_features": pcd_features,
         }
 
@@ -477,6 +478,43 @@ class Mask3D(nn.Module):
     @torch.jit.unused
     def _set_aux_loss(self, outputs_class, outputs_seg_masks):
         return [{"pred_logits": a, "pred_masks": b} for a, b in zip(outputs_class[:-1], outputs_seg_masks[:-1])]
+
+
+class HostArrayLater:
+    """The query seed coordinates as the reference returns them — a numpy array (models/mask3d.py:467) — without making
+    the host wait for the whole forward pass: the device-to-host copy goes into pinned memory behind the forward's
+    kernels and is waited for when somebody LOOKS at the array (np.asarray, indexing, .numpy()).  A blocking copy
+    here was the one host/device synchronisation left on the training step's compute stream: the host could not issue
+    the criterion and the backward pass until the device had drained, and the device then idled while they were being
+    issued."""
+
+    def __init__(self, t):
+        t = t.detach()
+        self._host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        self._host.copy_(t, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self.shape, self.dtype = tuple(t.shape), self._host.numpy().dtype
+
+    def numpy(self):
+        self._event.synchronize()
+        return self._host.numpy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, i):
+        return self.numpy()[i]
+
+    def __len__(self):
+        return self.shape[0]
+
+
+def _host_array(t):
+    if t.is_cuda and _LAZY_HOST_COPIES:
+        return HostArrayLater(t)
+    return t.detach().cpu().numpy()
 
 
 class Linear(nn.Linear):
