@@ -556,6 +556,11 @@ int usc_linear_bwd(const float* dy, const float* x, const float* W, int32_t M,
 int usc_linear_fwd_ex(const float* x, const float* x2, const float* W,
                       const float* b, int32_t M, int32_t N, int32_t K,
                       int32_t relu, float* y, usc_stream_t s);
+/* ... writing y as an [M_pad, N] table whose rows M..M_pad-1 are zero: the 100 query embeddings of the mask module
+ * (models/mask3d.py:425) zero-extended to the 128 rows the following product's kernels want, in the producing launch
+ * (was: a fill and a copy per call, and a slice copy on the way back). */
+int usc_linear_fwd_pad(const float* x, const float* x2, const float* W, const float* b, int32_t M, int32_t N, int32_t K,
+                       int32_t relu, float* y, int32_t M_pad, usc_stream_t s);
 int usc_linear_bwd_ex(const float* dy, const float* y_relu, const float* x,
                       const float* x2, const float* W, int32_t M, int32_t N,
                       int32_t K, float* dx, const float* dx_add, float* dW,

@@ -1340,6 +1340,28 @@ def test_mask_module_several_scenes_equals_the_table_path(device, monkeypatch):
         assert 0.05 < float(a[0].float().mean()) < 0.95
 
 
+def test_linear_zero_extended_rows(device):
+    """ops.linear(..., pad_rows_to=P): rows M..P-1 of the result are zero, the gradient of those rows is dropped
+    (the mask module's 100 query embeddings zero-extended to 128, reference models/mask3d.py:425)."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    x, W, b = torch.randn(1, 100, 128, generator=g), torch.randn(128, 128, generator=g) * 0.1, torch.randn(128, generator=g)
+    gy = torch.randn(1, 128, 128, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_() for t in (x, W, b))
+    yr = torch.nn.functional.pad(xr @ Wr.T + br, (0, 0, 0, 28))
+    (yr * gy).sum().backward()
+    xd, Wd, bd = (_dev(t, device).requires_grad_() for t in (x, W, b))
+    y = ops.linear(xd, Wd, bd, pad_rows_to=128)
+    assert y.shape == (1, 128, 128) and not y[0, 100:].any()
+    assert rel_err(y.detach(), yr.detach()) < 2e-6
+    (y * _dev(gy, device)).sum().backward()
+    for a, r in ((xd, xr), (Wd, Wr), (bd, br)):
+        assert rel_err(a.grad, r.grad) < 2e-6
+    with pytest.raises(RuntimeError):
+        ops.linear(torch.randn(5000, 128, device=device), Wd, bd, pad_rows_to=5024)
+
+
 @pytest.mark.parametrize("kind", ["cross", "self", "self_no_pos", "ffn"])
 def test_residual_routed_through_the_projection_node(device, kind):
     """in_proj(..., residual=True) / linear(..., passthrough=True) hand the query input back as an extra output; the

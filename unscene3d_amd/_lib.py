@@ -136,6 +136,7 @@ SIGNATURES = {
     "usc_layernorm_fwd": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _p, _p, _p, _p]),
     "usc_add_layernorm_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f32, _p, _p, _p, _p, _p]),
     "usc_linear_fwd_ex": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
+    "usc_linear_fwd_pad": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p]),
     "usc_linear_bwd_ex": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p]),
     "usc_linear_bwd_ex2": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "usc_layernorm_bwd_ws_bytes": (_i64, [_i64, _i32]),

@@ -191,7 +191,8 @@ __device__ inline int acc_row16(int reg, int half) { return (reg & 3) + 8 * (reg
 __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int wave, int lane, float* __restrict__ out,
                                          int64_t ld, int row0, int col0, int max_row, const float* __restrict__ bias,
                                          int accumulate = 0, int relu = 0, const float* __restrict__ add = nullptr,
-                                         const float* __restrict__ add2 = nullptr, float* __restrict__ out_b = nullptr) {
+                                         const float* __restrict__ add2 = nullptr, float* __restrict__ out_b = nullptr,
+                                         int zero_rows_to = 0) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
   __syncthreads();
@@ -208,6 +209,8 @@ __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int w
       if (out_b) out_b[(int64_t)row * ld + col0 + i] = o;      // the sum without add2 (second consumer of the product)
       if (add2) o += add2[(int64_t)row * ld + col0 + i];
       *dst = relu ? fmaxf(o, 0.f) : o;
+    } else if (row < zero_rows_to) {
+      out[(int64_t)row * ld + col0 + i] = 0.f;       // padding rows of a table the caller wants zero-extended
     }
   }
 }
@@ -216,7 +219,7 @@ __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int w
 // x2 (optional): the input rows are x + x2 (positional encodings, models/mask3d.py:485,517); relu: y = max(y, 0)
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2,
                                                         const float* __restrict__ W, const float* __restrict__ b, int M,
-                                                        int N, int K, int relu, float* __restrict__ y) {
+                                                        int N, int K, int relu, float* __restrict__ y, int Mpad) {
   __shared__ float red[4][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
       for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[j], acc);
     }
   }
-  tile_reduce_store(acc, red, wave, lane, y, N, m0, n0, M, b, 0, relu);
+  tile_reduce_store(acc, red, wave, lane, y, N, m0, n0, M, b, 0, relu, nullptr, nullptr, nullptr, Mpad);
 }
 
 // dx[M,K] = dy[M,N] W[N,K]   for the 32x32 tile (c0, m0); N % 32 == 0.  The four waves split N; every wave keeps the
@@ -458,10 +461,16 @@ int usc_linear_fwd(const float* x, const float* W, const float* b, int32_t M, in
 
 int usc_linear_fwd_ex(const float* x, const float* x2, const float* W, const float* b, int32_t M, int32_t N, int32_t K,
                       int32_t relu, float* y, usc_stream_t s) {
+  return usc_linear_fwd_pad(x, x2, W, b, M, N, K, relu, y, M, s);
+}
+
+int usc_linear_fwd_pad(const float* x, const float* x2, const float* W, const float* b, int32_t M, int32_t N, int32_t K,
+                       int32_t relu, float* y, int32_t M_pad, usc_stream_t s) {
   USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_fwd: N, K must be multiples of 32");
+  USC_REQUIRE(M_pad >= M, "usc_linear_fwd_pad: M_pad < M");
   USC_REQUIRE(x && W && y, "usc_linear_fwd: null pointer");
-  hipLaunchKernelGGL(usc::linear_fwd_kernel, dim3(N / 32, (M + 31) / 32), dim3(256), 0, usc::as_stream(s), x, x2, W, b,
-                     (int)M, (int)N, (int)K, (int)relu, y);
+  hipLaunchKernelGGL(usc::linear_fwd_kernel, dim3(N / 32, (M_pad + 31) / 32), dim3(256), 0, usc::as_stream(s), x, x2, W, b,
+                     (int)M, (int)N, (int)K, (int)relu, y, (int)M_pad);
   USC_CHECK_LAUNCH("usc_linear_fwd");
   return USC_OK;
 }

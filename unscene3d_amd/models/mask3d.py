@@ -28,6 +28,7 @@ SINGLE_POINT_ERROR = "only a single point gives nans in cross-attention"   # tra
 # the residual connection of a decoder block routed through the block's first projection node (one autograd add per
 # block and pass less: 36 launches per step)
 _RESIDUAL_IN_PROJECTION = os.environ.get("USC3D_RESIDUAL_IN_PROJECTION", "1") == "1"
+_PADDED_MASK_EMBED = os.environ.get("USC3D_PADDED_MASK_EMBED", "1") == "1"
 _LAZY_HOST_COPIES = os.environ.get("USC3D_LAZY_HOST_COPIES", "1") == "1"
 _FUSED_KEY_SAMPLING = os.environ.get("USC3D_FUSED_KEY_SAMPLING", "1") == "1"
 _GATHER_INTO_GRAPH_INPUTS = os.environ.get("USC3D_GATHER_INTO_GRAPH_INPUTS", "1") == "1"
@@ -408,8 +409,18 @@ class Mask3D(nn.Module):
                     point2segment=None, coords=None, defer_class=False):
         query_feat = self.decoder_norm(query_feat)
         head = self.mask_embed_head
+        Q = query_feat.shape[-2]
+        q_pad = (-Q) % 32
         if query_feat.is_cuda and query_feat.dtype == torch.float32:      # Linear + ReLU in one launch
-            mask_embed = head[2](ops.linear(query_feat, head[0].weight, head[0].bias, relu=True))
+            hidden = ops.linear(query_feat, head[0].weight, head[0].bias, relu=True)
+            if (q_pad and _PADDED_MASK_EMBED and query_feat.dim() == 3 and query_feat.shape[0] == 1
+                    and isinstance(head[2], Linear) and head[2].out_features % 32 == 0):
+                # one scene: the embeddings come out zero-extended to a multiple of 32 rows (what the logits product
+                # below wants) from the launch that computes them
+                mask_embed = ops.linear(hidden, head[2].weight, head[2].bias, pad_rows_to=Q + q_pad)
+                mask_embed = _PaddedRows(mask_embed, Q)
+            else:
+                mask_embed = head[2](hidden)
         else:
             mask_embed = head(query_feat)
         # defer_class: hand back the normalised queries; forward() runs the class head ONCE over all 13 calls' queries
@@ -526,15 +537,31 @@ class Linear(nn.Linear):
         return super().forward(x)
 
 
+class _PaddedRows:
+    """mask_embed[i] -> (the zero-extended [Qp, d] table of scene i, Q)."""
+
+    def __init__(self, table, q):
+        self.table, self.q = table, q
+
+    def __getitem__(self, i):
+        return (self.table[i], self.q)
+
+
 def _mask_logits(feats, mask_embed):
     """feats [S, d] @ mask_embed[Q, d]^T -> [S, Q] (reference mask3d.py:425,430).  On the device the Q query
     embeddings are padded to a multiple of 32 so that the product runs on this library's row GEMM kernels (forward,
     d feats, d mask_embed); the padded columns are cut off again as a view."""
-    Q = mask_embed.shape[0]
-    if not (feats.is_cuda and feats.dtype == torch.float32 and feats.shape[1] % 32 == 0):
-        return feats @ mask_embed.T
-    pad = (-Q) % 32
-    W = F.pad(mask_embed, (0, 0, 0, pad)) if pad else mask_embed
+    if isinstance(mask_embed, tuple):          # already zero-extended by the producing launch (_PaddedRows)
+        W, Q = mask_embed
+        pad = W.shape[0] - Q
+        if not (feats.is_cuda and feats.dtype == torch.float32 and feats.shape[1] % 32 == 0):
+            return feats @ W[:Q].T
+    else:
+        Q = mask_embed.shape[0]
+        if not (feats.is_cuda and feats.dtype == torch.float32 and feats.shape[1] % 32 == 0):
+            return feats @ mask_embed.T
+        pad = (-Q) % 32
+        W = F.pad(mask_embed, (0, 0, 0, pad)) if pad else mask_embed
     out = ops.linear(feats, W.contiguous())
     if not pad:
         return out

@@ -912,16 +912,20 @@ def _rows_gemm_ok(rows, n_in, n_out):
     return rows > SMALL_ROWS and n_in % 32 == 0 and n_out % 32 == 0
 
 
-def _lin_fwd(x2, W, b, add=None, relu=False):
+def _lin_fwd(x2, W, b, add=None, relu=False, pad_rows_to=None):
     """y = (x2 [+ add]) W^T + b [then ReLU] for contiguous f32 x2 [M,K], W [N,K] (a contiguous row block is fine);
-    `add` / `relu` are folded into the launch on the few-row kernels and applied separately elsewhere."""
+    `add` / `relu` are folded into the launch on the few-row kernels and applied separately elsewhere.
+    pad_rows_to: y gets that many rows, the extra ones zero (few-row kernels only)."""
     M, K = x2.shape
     N = W.shape[0]
     if _small_linear_ok(M, K, N):
-        y = torch.empty((M, N), dtype=torch.float32, device=x2.device)
-        check(lib.usc_linear_fwd_ex(_ptr(x2), _ptr(add), _ptr(W), _ptr(b), M, N, K, int(relu), _ptr(y), _stream()),
+        Mp = M if pad_rows_to is None else int(pad_rows_to)
+        y = torch.empty((Mp, N), dtype=torch.float32, device=x2.device)
+        check(lib.usc_linear_fwd_pad(_ptr(x2), _ptr(add), _ptr(W), _ptr(b), M, N, K, int(relu), _ptr(y), Mp, _stream()),
               "usc_linear_fwd")
         return y
+    if pad_rows_to is not None:
+        raise RuntimeError("linear: pad_rows_to needs the few-row kernels (rows <= 1024, widths multiples of 32)")
     if add is not None:
         x2 = x2 + add
     if relu:
@@ -1001,8 +1005,17 @@ def _lin_bwd(dy2, x2, W, dW_out, db_out, need_dx=True, accumulate=False, add=Non
 
 class _LinearRows(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, relu=False, passthrough=False):
+    def forward(ctx, x, W, b, relu=False, passthrough=False, pad_rows_to=None):
         x2 = x.contiguous().view(-1, x.shape[-1])
+        ctx.rows = x2.shape[0]
+        if pad_rows_to is not None:
+            if relu or passthrough or x2.shape[0] != x.shape[-2] or pad_rows_to < x2.shape[0]:
+                raise RuntimeError("linear: pad_rows_to is for one [.., M, K] table, M <= pad_rows_to, without relu")
+            y = _lin_fwd(x2, W, b, pad_rows_to=pad_rows_to)
+            ctx.save_for_backward(x2, W, None)
+            ctx.has_bias, ctx.shape = b is not None, x.shape
+            ctx.w_param, ctx.b_param = W, b
+            return y.view(*x.shape[:-2], int(pad_rows_to), W.shape[0])
         y = _lin_fwd(x2, W, b, relu=relu)
         ctx.save_for_backward(x2, W, y if relu else None)
         ctx.has_bias, ctx.shape = b is not None, x.shape
@@ -1015,7 +1028,7 @@ class _LinearRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dres=None):
         x2, W, y_relu = ctx.saved_tensors
-        dy2 = dy.contiguous().view(-1, W.shape[0])
+        dy2 = dy.contiguous().view(-1, W.shape[0])[:ctx.rows]       # [:rows]: drops the zero-extension rows, if any
         tw = _grad_target(ctx.w_param)
         tb = _grad_target(ctx.b_param) if ctx.has_bias else None
         in_place = tw is not None and (tb is not None or not ctx.has_bias)
@@ -1030,16 +1043,18 @@ class _LinearRows(torch.autograd.Function):
         if in_place:
             dW = db = None
             _grad_written(ctx.w_param, ctx.b_param if ctx.has_bias else None)
-        return (None if dx is None else dx.view(ctx.shape)), dW, db, None, None
+        return (None if dx is None else dx.view(ctx.shape)), dW, db, None, None, None
 
 
-def linear(x, W, b=None, relu=False, passthrough=False):
+def linear(x, W, b=None, relu=False, passthrough=False, pad_rows_to=None):
     """F.linear(x, W, b) (relu: followed by ReLU, in the same launch on the few-row kernels) for f32 HIP tensors;
     few-row inputs run on the wave-per-tile MFMA kernels of decoder.hip.
     passthrough: -> (y, x'), x' = x as an output of the same autograd node: use it for the residual connection
-    around the layer, its gradient is then summed inside the layer's input-gradient launch."""
+    around the layer, its gradient is then summed inside the layer's input-gradient launch.
+    pad_rows_to: x is ONE table [.., M, K]; y comes back as [.., pad_rows_to, N] with zero rows appended (the
+    gradient of those rows is dropped)."""
     _chk(W, torch.float32, "W")
-    return _LinearRows.apply(x, W, b, relu, passthrough)
+    return _LinearRows.apply(x, W, b, relu, passthrough, pad_rows_to)
 
 
 class _InProj(torch.autograd.Function):
