@@ -275,6 +275,16 @@ typedef struct usc_bn {
  * caller's order: on the coarse U-Net levels the input-gradient and weight-gradient
  * launches are latency-bound and run side by side.  Results are unchanged. */
 int usc_set_side_stream(usc_stream_t side);
+/* Optional: the weight-gradient LANE, a second stream of the caller with its own scratch (NULL lane: off; per device).
+ * usc_conv_backward / usc_conv_bn_act_backward then queue the weight gradient of a map with <= max_rows rows (only
+ * the accumulate-into-a-gradient-buffer form) on the lane behind one event of the caller's stream and return WITHOUT
+ * waiting for it; the input-gradient chain of the backward pass is not held up, the latency-bound weight-gradient
+ * launches of the coarse U-Net levels run beside it.  The caller keeps x, dy and dW alive and untouched until it has
+ * called usc_wgrad_lane_join(s) — `s` then waits for everything queued on the lane so far (end of the backward pass,
+ * and before a gradient bucket is handed to a collective).  Results are unchanged (same kernels, same order per
+ * gradient buffer). */
+int usc_set_wgrad_lane(usc_stream_t lane, void* lane_ws, int64_t lane_ws_bytes, int64_t max_rows);
+int usc_wgrad_lane_join(usc_stream_t s);
 /* Scratch bytes covering forward AND backward of one convolution / one unit. */
 int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin,
                           int32_t cout);

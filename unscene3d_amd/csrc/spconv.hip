@@ -970,12 +970,14 @@ static int wgrad_full_ct(int ctiles, int NBf) {
 }
 static int64_t wgrad_full_splits(int K, int ctiles, int cb, int CT, int NBf, int64_t n_rows) {
   const int64_t blocks_per_split = (int64_t)K * (ctiles / CT) * (cb / NBf);
-  int64_t S = 512 / blocks_per_split;                         // one round of 2 workgroups per CU
+  static const int target = getenv("USC3D_WGRAD_TARGET_BLOCKS") ? atoi(getenv("USC3D_WGRAD_TARGET_BLOCKS")) : 512;
+  static const int rows_per = getenv("USC3D_WGRAD_ROWS_PER_SPLIT") ? atoi(getenv("USC3D_WGRAD_ROWS_PER_SPLIT")) : 4096;
+  int64_t S = target / blocks_per_split;                      // 512: one round of 2 workgroups per CU
   // USC3D_WGRAD_ONE_SLICE_FROM=<blocks>: no pair split (and no reduction launch) once a single slice already has that
   // many workgroups (experiment knob)
   static const int one_from = getenv("USC3D_WGRAD_ONE_SLICE_FROM") ? atoi(getenv("USC3D_WGRAD_ONE_SLICE_FROM")) : 0;
   if (one_from > 0 && blocks_per_split >= one_from) S = 1;
-  const int64_t by_rows = n_rows / (K > 1 ? 4096 : 256) + 1;   // identity pairs (dense layers): 64 rows per wave suffice
+  const int64_t by_rows = n_rows / (K > 1 ? rows_per : 256) + 1;   // identity pairs (dense layers): 64 rows per wave suffice
   if (S > by_rows) S = by_rows;
   if (S > 64) S = 64;
   if (S < 1) S = 1;

@@ -85,6 +85,22 @@ SideStream g_side[16];
 constexpr int64_t kForkMaxRows = 24576;   // larger maps fill the chip on their own (and the tile-compacted kernel
                                           // sizes its tiles for whole rounds of 256 CUs)
 
+// ---- the weight-gradient lane -----------------------------------------------------------------------------------
+// The join of the fork above put the caller's stream behind the side stream once per convolution, and that cost more
+// than the overlap returned.  The lane never joins inside a call: the weight gradient of a small map is queued on the
+// lane stream behind ONE event of the caller's stream (everything it reads is ready at that point) and the call
+// returns; the input-gradient chain — the critical path of the backward pass — carries on, and the latency-bound
+// weight-gradient launches of the coarse levels fill the CUs it leaves idle.  The caller joins once, when the
+// gradients are needed (usc_wgrad_lane_join), keeps x / dy / dW alive until then, and gives the lane its own scratch.
+struct Lane { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; void* ws = nullptr; int64_t ws_bytes = 0;
+              int64_t max_rows = 0; bool dirty = false; };
+Lane g_lane[16];
+Lane* lane_for_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  return g_lane[dev].st ? &g_lane[dev] : nullptr;
+}
+
 SideStream* side_for_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -128,6 +144,44 @@ int usc_set_side_stream(usc_stream_t side) {
     }
   }
   e.st = as_stream(side);
+  return USC_OK;
+}
+
+int usc_set_wgrad_lane(usc_stream_t lane, void* lane_ws, int64_t lane_ws_bytes, int64_t max_rows) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+    set_error("usc_set_wgrad_lane: unsupported device index");
+    return USC_ERR_ARG;
+  }
+  Lane& e = g_lane[dev];
+  if (!lane) {
+    e.st = nullptr;
+    return USC_OK;
+  }
+  USC_REQUIRE(lane_ws && lane_ws_bytes > 0 && max_rows > 0, "usc_set_wgrad_lane: the lane needs its own scratch and a row bound");
+  if (!e.fork) {
+    if (hipEventCreateWithFlags(&e.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e.join, hipEventDisableTiming) != hipSuccess) {
+      set_error("usc_set_wgrad_lane: hipEventCreate failed");
+      return USC_ERR_LAUNCH;
+    }
+  }
+  e.st = as_stream(lane);
+  e.ws = lane_ws;
+  e.ws_bytes = lane_ws_bytes;
+  e.max_rows = max_rows;
+  e.dirty = false;
+  return USC_OK;
+}
+
+int usc_wgrad_lane_join(usc_stream_t s) {
+  Lane* lane = lane_for_current_device();
+  if (!lane || !lane->dirty) return USC_OK;
+  if (hipEventRecord(lane->join, lane->st) != hipSuccess || hipStreamWaitEvent(as_stream(s), lane->join, 0) != hipSuccess) {
+    set_error("usc_wgrad_lane_join: joining the lane failed");
+    return USC_ERR_LAUNCH;
+  }
+  lane->dirty = false;
   return USC_OK;
 }
 
@@ -184,6 +238,26 @@ int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t c
   const int K = m->K;
   USC_REQUIRE(x && W && dy, "usc_conv_backward: null pointer");
   WsCursor cur{(char*)ws, ws ? ws_bytes : 0, 0};
+  // lane: the weight gradient queued on the lane stream, joined by the caller at the end of the backward pass
+  if (dW && dW_accumulate && x && dy) {
+    Lane* lane = lane_for_current_device();
+    const int64_t rows = m->nbr ? m->pair_capacity : sh.n_in;
+    const int64_t b = usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows);
+    if (lane && sh.n_in > 0 && sh.n_in <= lane->max_rows && sh.n_out <= lane->max_rows && b <= lane->ws_bytes &&
+        (!m->nbr || (m->pair_in && m->pair_out && m->koff)) &&
+        hipEventRecord(lane->fork, as_stream(s)) == hipSuccess && hipStreamWaitEvent(lane->st, lane->fork, 0) == hipSuccess) {
+      usc_stream_t ls = (usc_stream_t)lane->st;
+      lane->dirty = true;
+      if (!m->nbr)
+        rc = usc_spconv_wgrad(x, cin, dy, cout, 1, nullptr, nullptr, nullptr, sh.n_in, dW, 1, lane->ws, b, ls);
+      else if (kind == USC_CONV_UP)
+        rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_out, m->pair_in, m->koff, rows, dW, 1, lane->ws, b, ls);
+      else
+        rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_in, m->pair_out, m->koff, rows, dW, 1, lane->ws, b, ls);
+      if (rc) return rc;
+      dW = nullptr;          // done (queued); the rest of this call is the input gradient on the caller's stream
+    }
+  }
   // fork: the weight gradient on the side stream while this stream runs the input gradient
   SideStream* side = (dx && dW && sh.n_in > 0 && sh.n_in <= kForkMaxRows && sh.n_out <= kForkMaxRows) ? side_for_current_device() : nullptr;
   hipStream_t wst = as_stream(s);

@@ -110,6 +110,11 @@ class BucketedGradReducer:
     def _launch(self, b):
         import torch.distributed as dist
         s, e = self.bounds[b]
+        if self.flat.is_cuda:
+            # weight gradients queued on the lane stream (units.py) are not in this stream's order yet: the collective
+            # reads the bucket in the order of the current stream
+            from . import units
+            units.join_lane(self.flat.device)
         self.handles.append(dist.all_reduce(self.flat[s:e], async_op=True))
         self.launched[b] = True
 

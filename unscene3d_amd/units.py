@@ -28,8 +28,61 @@ ENABLED = os.environ.get("USC3D_NATIVE_UNITS", "1") == "1"
 # 37.3 ms per step without, 39.0 ms with (20 k voxels: 33.2 vs 35.8) — two event records and two stream waits per
 # unit cost the host and the device more than the overlap of two ~30 us launches returns.  Off by default.
 FORK_WGRAD = os.environ.get("USC3D_FORK_WGRAD", "0") == "1"
+# The weight-gradient lane (usc_set_wgrad_lane): weight gradients of maps up to LANE_MAX_ROWS rows are queued on a second
+# stream and joined ONCE, at the end of the backward pass (and before a gradient bucket goes to a collective) — the
+# input-gradient chain is not held up by them.  0 rows = off, the default: measured on the bench scene (same box,
+# alternating runs) 26.28 ms per step without the lane, 26.73 / 26.91 / 26.95 / 27.13 / 27.22 ms with the bound at
+# 3 000 / 10 000 / 24 576 / 50 000 / all rows — the step is bound by the device's one chain of dependent launches, and
+# a second queue competing for the CUs (plus one event record per convolution on the chain) lengthens it.
+LANE_MAX_ROWS = int(os.environ.get("USC3D_WGRAD_LANE_MAX_ROWS", "0"))
+LANE_WS_BYTES = 192 << 20
 SAME, DOWN, UP = 0, 1, 2
 _SIDE = {}     # device index -> torch.cuda.Stream handed to usc_set_side_stream
+_LANE = {}     # device index -> (stream, scratch tensor) handed to usc_set_wgrad_lane, or None
+_LANE_JOIN_QUEUED = set()
+
+
+def _lane(device):
+    """(stream, scratch) of the device's weight-gradient lane, or None when it is switched off."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _LANE:
+        if LANE_MAX_ROWS > 0 and not FORK_WGRAD:
+            st = torch.cuda.Stream(device=device)
+            ws = torch.empty(LANE_WS_BYTES, dtype=torch.uint8, device=device)
+            check(lib.usc_set_wgrad_lane(st.cuda_stream, ws.data_ptr(), ws.numel(), LANE_MAX_ROWS), "usc_set_wgrad_lane")
+            _LANE[key] = (st, ws)
+        else:
+            _LANE[key] = None
+    return _LANE[key]
+
+
+def join_lane(device=None):
+    """The current stream waits for every weight gradient queued on the lane so far (no-op without a lane)."""
+    key = torch.cuda.current_device() if device is None or device.index is None else device.index
+    if _LANE.get(key) is not None:
+        check(lib.usc_wgrad_lane_join(ops._stream()), "usc_wgrad_lane_join")
+
+
+def _join_lane_after_backward(key):
+    _LANE_JOIN_QUEUED.discard(key)
+    with torch.cuda.device(key):
+        join_lane()
+
+
+def _lane_hold(device, n_in, n_out, in_place_dW, *tensors):
+    """Called by a unit's backward before the native call: when that call will queue its weight gradient on the lane,
+    the tensors it reads there are kept away from the allocator until the lane is past them, and the join at the end
+    of this backward pass is queued (once).  -> True when the lane will be used."""
+    lane = _lane(device)
+    if lane is None or not in_place_dW or n_in <= 0 or max(n_in, n_out) > LANE_MAX_ROWS:
+        return False
+    for t in tensors:
+        t.record_stream(lane[0])
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _LANE_JOIN_QUEUED:
+        _LANE_JOIN_QUEUED.add(key)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_lane_after_backward(key))
+    return True
 
 
 def _ensure_side_stream(device):
@@ -164,6 +217,7 @@ def unit_backward(x, W3, bn, kmap, kind, y, stats, out_relu, dout, dy_buf, want_
         dx_accumulate = False
     _ensure_side_stream(dev)
     tW = ops._grad_target(W_param)
+    _lane_hold(dev, n_in, n_out, tW is not None, x, dy_buf)
     tg, tb = ops._grad_target(g_param), ops._grad_target(b_param)
     bn_in_place = tg is not None and tb is not None
     dW = tW if tW is not None else torch.empty(W_param.shape, dtype=torch.float32, device=dev)
@@ -252,19 +306,23 @@ class _BasicBlock(torch.autograd.Function):
         bn1, bn2, bnd = ctx.bns
         dout = dout.contiguous()
         need_dx = ctx.needs_input_grad[0]
-        dy = torch.empty_like(y2)                 # d(conv output) scratch, shared by the units (same shape)
+        dy = torch.empty_like(y2)                 # d(conv output) scratch, shared by the units (same shape) ...
+        # ... unless their weight gradients go to the lane: each then reads its own dy after this function has moved on
+        lane_on = _lane(x.device) is not None and x.shape[0] <= LANE_MAX_ROWS
+        dy1 = torch.empty_like(y2) if lane_on else dy
+        dyd = torch.empty_like(y2) if (lane_on and Wdc is not None) else dy
         # unit 2: dout -> (d a1, d residual)
         da1, dres, dW2, dg2, db2 = unit_backward(a1, W2c, bn2, ctx.kmap, SAME, y2, st2, out, dout, dy, True, None,
                                                  False, True, W2, g2, b2)
         dWd = dgd = dbd = None
         if Wdc is None:
             # identity residual: conv1's input gradient is accumulated straight onto the residual gradient
-            dx, _, dW1, dg1, db1 = unit_backward(x, W1c, bn1, ctx.kmap, SAME, y1, st1, a1, da1, dy, False, dres, True,
+            dx, _, dW1, dg1, db1 = unit_backward(x, W1c, bn1, ctx.kmap, SAME, y1, st1, a1, da1, dy1, False, dres, True,
                                                  need_dx, W1, g1, b1)
         else:
-            dx, _, dW1, dg1, db1 = unit_backward(x, W1c, bn1, ctx.kmap, SAME, y1, st1, a1, da1, dy, False, None, False,
+            dx, _, dW1, dg1, db1 = unit_backward(x, W1c, bn1, ctx.kmap, SAME, y1, st1, a1, da1, dy1, False, None, False,
                                                  need_dx, W1, g1, b1)
-            dx, _, dWd, dgd, dbd = unit_backward(x, Wdc, bnd, ctx.kmap_id, SAME, yd, std, None, dres, dy, False, dx,
+            dx, _, dWd, dgd, dbd = unit_backward(x, Wdc, bnd, ctx.kmap_id, SAME, yd, std, None, dres, dyd, False, dx,
                                                  True, need_dx, Wd, gd, bd)
             if dWd is not None and Wd.dim() == 2:
                 dWd = dWd.view(Wd.shape)
