@@ -1340,6 +1340,21 @@ def test_mask_module_several_scenes_equals_the_table_path(device, monkeypatch):
         assert 0.05 < float(a[0].float().mean()) < 0.95
 
 
+def test_host_array_later_behaves_like_the_numpy_array_it_replaces(device):
+    """Mask3D returns the query seed coordinates as the reference does (a host array, models/mask3d.py:467) without a
+    blocking copy: np.asarray / indexing / shape of the stand-in give the values of `.cpu().numpy()`."""
+    import numpy as np
+    from unscene3d_amd.models.mask3d import HostArrayLater, _host_array
+
+    t = torch.randn(2, 100, 3, device=device)
+    h = _host_array(t)
+    assert isinstance(h, HostArrayLater) and h.shape == (2, 100, 3) and len(h) == 2 and h.dtype == np.float32
+    ref = t.cpu().numpy()
+    assert np.array_equal(np.asarray(h), ref) and np.array_equal(h[1, :5], ref[1, :5]) and np.array_equal(h.numpy(), ref)
+    assert np.array_equal(np.asarray(h, dtype=np.float64), ref.astype(np.float64))
+    assert isinstance(_host_array(t.cpu()), np.ndarray)
+
+
 def test_linear_zero_extended_rows(device):
     """ops.linear(..., pad_rows_to=P): rows M..P-1 of the result are zero, the gradient of those rows is dropped
     (the mask module's 100 query embeddings zero-extended to 128, reference models/mask3d.py:425)."""

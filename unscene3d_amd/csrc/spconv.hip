@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 // stride-12 loads.  Cross-wave reduction through one LDS tile in three ordered rounds (deterministic).
 template <int CT, int NB>
 __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
-  extern __shared__ float red[];  // [CT*NB*16 regs][64 lanes]
+  extern __shared__ float red[];  // [4 waves][NB*16 regs][64 lanes]
   constexpr int NA = CT * NB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -840,6 +840,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
   float aX[4][CT], aY[4][CT], bX[4][NB], bY[4][NB];
   int id1 = load_idx(cb), id2 = load_idx(cb + 8);
   load_rows(id1, aX, bX);
+#ifdef USC_ABLATE_WG_LOOP
+  if (p.cin < 0)
+#endif
   for (int64_t q = cb; q < ce; q += 16) {
     const int id3 = load_idx(q + 16);
     load_rows(id2, aY, bY);
@@ -848,43 +851,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
     load_rows(id3, aX, bX);
     if (q + 8 < ce) run(aY, bY);
   }
+  // (three row buffers with the ids four batches ahead measured 7 % SLOWER: the loop is bound by the matrix-core pipe that
+  //  two resident workgroups share — 1.8 GFLOP = 11 us at peak for the 507-row 256->256 layer, 15 us measured — not by
+  //  its loads)
 
-  // ordered reduction: wave 3 -> LDS, wave 2 adds, wave 1 adds, wave 0 adds and writes the partial slice
-  for (int w = 3; w >= 1; --w) {
-    if (wave == w) {
-#pragma unroll
-      for (int t = 0; t < NA; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* slot = red + (t * 16 + r) * 64 + lane;
-          *slot = (w == 3 ? 0.f : *slot) + acc[t][r];
-        }
-    }
-    __syncthreads();
+#ifdef USC_ABLATE_WG_EPI
+  if (p.cin > 0) {
+    if (wave == 0 && lane == 0) p.partial[((int64_t)s * p.K + k) * cin * cout + ci0 * cout + co0] = acc[0][0] + acc[NA - 1][15];
+    return;
   }
-  if (wave == 0) {
-    if (p.direct && p.accumulate) {       // one split: added straight into dW (no partial slice, no reduction launch)
-      float* dst = p.direct + (int64_t)k * cin * cout;
+#endif
+  // Reduction over the four waves, in the fixed order w0 + ((w3 + w2) + w1) per element, one input-channel tile (ct)
+  // at a time: every wave parks the tile's NB*16 accumulators in LDS, then wave w sums accumulator rows 4w .. 4w+3
+  // over the four waves and writes them — all four waves add and store (the first version let wave 3, 2, 1 add in
+  // turn and wave 0 write everything with 4-byte stores: 7 us of a 35 us launch on the 507-row level), and a lane's NB
+  // columns of one row are adjacent in dW: one 16-byte store for NB = 4.
+  float* dst = (p.direct ? p.direct : p.partial + (int64_t)s * p.K * cin * cout) + (int64_t)k * cin * cout;
+  const bool rmw = p.direct && p.accumulate;   // one split: added straight into dW (no partial slice, no reduction launch)
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(dst) & (NB * 4 - 1)) == 0;
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+  for (int ct = 0; ct < CT; ++ct) {
+    if (ct) __syncthreads();
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ci = ci0 + CT * acc_row(r, h) + ct;
-            dst[(int64_t)ci * cout + co0 + NB * i + nb] += acc[ct * NB + nb][r] + red[((ct * NB + nb) * 16 + r) * 64 + lane];
-          }
-    } else {
-      float* dst = p.direct ? p.direct + (int64_t)k * cin * cout : p.partial + ((int64_t)s * p.K + k) * cin * cout;
+      for (int r = 0; r < 16; ++r) red[((wave * NB + nb) * 16 + r) * 64 + lane] = acc[ct * NB + nb][r];
+    __syncthreads();
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
+    for (int rr = 0; rr < 4; ++rr) {
+      const int r = 4 * wave + rr;
+      float v[NB];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb) {
+        float t = red[((3 * NB + nb) * 16 + r) * 64 + lane];
+        t += red[((2 * NB + nb) * 16 + r) * 64 + lane];
+        t += red[((1 * NB + nb) * 16 + r) * 64 + lane];
+        v[nb] = red[(nb * 16 + r) * 64 + lane] + t;
+      }
+      const int ci = ci0 + CT * acc_row(r, h) + ct;
+      float* o = dst + (int64_t)ci * cout + co0 + NB * i;
+      if (NB == 4 && vec_ok) {
+        float4 w4 = make_float4(v[0], v[1], v[2 % NB], v[3 % NB]);
+        if (rmw) {
+          const float4 old = *reinterpret_cast<const float4*>(o);
+          w4.x += old.x; w4.y += old.y; w4.z += old.z; w4.w += old.w;
+        }
+        *reinterpret_cast<float4*>(o) = w4;
+      } else if (NB == 2 && vec_ok) {
+        float2 w2 = make_float2(v[0], v[1 % NB]);
+        if (rmw) {
+          const float2 old = *reinterpret_cast<const float2*>(o);
+          w2.x += old.x; w2.y += old.y;
+        }
+        *reinterpret_cast<float2*>(o) = w2;
+      } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ci = ci0 + CT * acc_row(r, h) + ct;
-            dst[(int64_t)ci * cout + co0 + NB * i + nb] = acc[ct * NB + nb][r] + red[((ct * NB + nb) * 16 + r) * 64 + lane];
-          }
+        for (int nb = 0; nb < NB; ++nb) o[nb] = rmw ? o[nb] + v[nb] : v[nb];
+      }
     }
   }
 }
@@ -1225,7 +1248,7 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
     p.S = (int)S;
     if (S == 1) { p.direct = dW; p.accumulate = accumulate; }   // one slice: written (added) straight into dW
     dim3 grid((unsigned)(K * S), (unsigned)(ctiles / CT), (unsigned)(cb / NBf));
-    const size_t lds = (size_t)CT * NBf * 16 * 64 * sizeof(float);
+    const size_t lds = (size_t)4 * NBf * 16 * 64 * sizeof(float);   // four waves x one input-channel tile
 #define USC_WF(C, N) if (CT == C && NBf == N) { \
       static bool attr_set = false; auto kfn = wgrad_full_kernel<C, N>; \
       if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; } \
