@@ -571,6 +571,12 @@ int usc_linear_fwd_ex(const float* x, const float* x2, const float* W,
  * (was: a fill and a copy per call, and a slice copy on the way back). */
 int usc_linear_fwd_pad(const float* x, const float* x2, const float* W, const float* b, int32_t M, int32_t N, int32_t K,
                        int32_t relu, float* y, int32_t M_pad, usc_stream_t s);
+/* ... several projections of ONE input in one launch: W [N,K] is a stack of N/split_cols weight matrices (the packed
+ * in_proj_weight of nn.MultiheadAttention), y comes back as [N/split_cols][M][split_cols] (each projection its own
+ * contiguous matrix) and the positional term x2 enters the output columns < x2_cols only — the q, k, v of a
+ * self-attention block (models/mask3d.py:507-517: q = k = tgt + query_pos, v = tgt), three launches before. */
+int usc_linear_fwd_split(const float* x, const float* x2, const float* W, const float* b, int32_t M, int32_t N, int32_t K,
+                         int32_t x2_cols, int32_t split_cols, float* y, usc_stream_t s);
 int usc_linear_bwd_ex(const float* dy, const float* y_relu, const float* x,
                       const float* x2, const float* W, int32_t M, int32_t N,
                       int32_t K, float* dx, const float* dx_add, float* dW,
@@ -582,6 +588,12 @@ int usc_linear_bwd_ex(const float* dy, const float* y_relu, const float* x,
 int usc_linear_bwd_ex2(const float* dy, const float* y_relu, const float* x, const float* x2, const float* W, int32_t M,
                        int32_t N, int32_t K, float* dx, const float* dx_add, const float* dx_add2, float* dx_b, float* dW,
                        float* db, int32_t accumulate, usc_stream_t s);
+/* Backward of usc_linear_fwd_split for the self-attention projections (split_cols = E, N = 3E, x2_cols = 2E), one launch:
+ * dy3 [3][M][E] = dq | dk | dv;  dx = dq Wq + dk Wk + dv Wv (+ dres: the block's residual path);  dx_b (optional) =
+ * dq Wq + dk Wk, the positional term's gradient;  dW [3E][E] and db [3E] written or (accumulate) added to, with the
+ * positional term in the q and k rows only. */
+int usc_qkv_proj_bwd(const float* dy3, const float* x, const float* pos, const float* W, int32_t M, int32_t E, float* dx,
+                     float* dx_b, const float* dres, float* dW, float* db, int32_t accumulate, usc_stream_t s);
 /* out[c] (+)= sum over the n rows of x f32[n, c]: the bias gradient of a linear
  * layer over many rows (the 3 200 / 12 800 sampled voxels of a decoder pass,
  * models/mask3d.py:351-352 lin_squeeze and the key / value projections of

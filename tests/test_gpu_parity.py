@@ -1377,6 +1377,38 @@ def test_linear_zero_extended_rows(device):
         ops.linear(torch.randn(5000, 128, device=device), Wd, bd, pad_rows_to=5024)
 
 
+@pytest.mark.parametrize("with_pos", [True, False])
+def test_self_attention_block_projections_one_launch_each_way(device, with_pos):
+    """q, k, v of a self-attention block from ONE launch (usc_linear_fwd_split) and their backward from one
+    (usc_qkv_proj_bwd; the attention core hands dq | dk | dv over as one table) — with the block's residual routed
+    through the node — against the same composition in plain PyTorch on the CPU (reference models/mask3d.py:507-524)."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(77)
+    E, L, B, H = 128, 100, 2, 8
+    W, b = torch.randn(3 * E, E, generator=g) * 0.1, torch.randn(3 * E, generator=g) * 0.1
+    x, pos = torch.randn(L, B, E, generator=g), (torch.randn(L, B, E, generator=g) if with_pos else None)
+    go, gr = torch.randn(L, B, E, generator=g), torch.randn(L, B, E, generator=g)
+
+    def run(dev_path):
+        dev = device if dev_path else "cpu"
+        t = lambda a: None if a is None else a.to(dev).clone().requires_grad_()
+        Wt, bt, xt, pt = t(W), t(b), t(x), t(pos)
+        if dev_path:
+            q, k, v, res = ops.in_proj(xt, xt, xt, Wt, bt, pos_q=pt, pos_k=pt, residual=True)
+            o = ops.self_attention(q, k, v, H)
+        else:
+            xp = xt if pt is None else xt + pt
+            q, k, v, res = xp @ Wt[:E].T + bt[:E], xp @ Wt[E:2 * E].T + bt[E:2 * E], xt @ Wt[2 * E:].T + bt[2 * E:], xt
+            sh = lambda a: a.reshape(L, B * H, E // H).transpose(0, 1)
+            o = torch.nn.functional.scaled_dot_product_attention(sh(q), sh(k), sh(v)).transpose(0, 1).reshape(L, B, E)
+        ((o * go.to(dev)).sum() + (res * gr.to(dev)).sum()).backward()
+        return [a.grad.cpu() for a in (Wt, bt, xt) + ((pt,) if pt is not None else ())] + [o.detach().cpu()]
+
+    for a, r in zip(run(True), run(False)):
+        assert rel_err(a, r) < 5e-6
+
+
 @pytest.mark.parametrize("kind", ["cross", "self", "self_no_pos", "ffn"])
 def test_residual_routed_through_the_projection_node(device, kind):
     """in_proj(..., residual=True) / linear(..., passthrough=True) hand the query input back as an extra output; the

@@ -139,7 +139,9 @@ SIGNATURES = {
     "usc_add_layernorm_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _f32, _p, _p, _p, _p, _p]),
     "usc_linear_fwd_ex": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _p]),
     "usc_linear_fwd_pad": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _p, _i32, _p]),
+    "usc_linear_fwd_split": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "usc_linear_bwd_ex": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _i32, _p]),
+    "usc_qkv_proj_bwd": (C.c_int, [_p, _p, _p, _p, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p]),
     "usc_linear_bwd_ex2": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "usc_layernorm_bwd_ws_bytes": (_i64, [_i64, _i32]),
     "usc_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),

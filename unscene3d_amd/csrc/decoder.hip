@@ -219,13 +219,17 @@ __device__ inline void tile_reduce_store(f32x16 acc, float (*red)[16][64], int w
 // x2 (optional): the input rows are x + x2 (positional encodings, models/mask3d.py:485,517); relu: y = max(y, 0)
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x2,
                                                         const float* __restrict__ W, const float* __restrict__ b, int M,
-                                                        int N, int K, int relu, float* __restrict__ y, int Mpad) {
+                                                        int N, int K, int relu, float* __restrict__ y, int Mpad,
+                                                        int x2_cols, int split) {
+  // x2_cols: the positional term enters output columns < x2_cols only; split > 0: the output is [N/split][M][split]
+  // (column block j = n / split is its own contiguous matrix) — the q, k, v projections of a self-attention block in
+  // one launch: q = (x + pos) Wq, k = (x + pos) Wk, v = x Wv
   __shared__ float red[4][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
   const int m = m0 + i;
   const float* xa = x + (int64_t)(m < M ? m : 0) * K + 4 * h;
-  const float* xa2 = x2 ? x2 + (int64_t)(m < M ? m : 0) * K + 4 * h : nullptr;
+  const float* xa2 = (x2 && n0 < x2_cols) ? x2 + (int64_t)(m < M ? m : 0) * K + 4 * h : nullptr;
   const float* wb = W + (int64_t)(n0 + i) * K + 4 * h;
   const float keep = m < M ? 1.f : 0.f;
   f32x16 acc;
@@ -251,6 +255,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc = MFMA32(av[j], bv[j], acc);
     }
+  }
+  if (split > 0) {
+    const int j = n0 / split;
+    tile_reduce_store(acc, red, wave, lane, y + (int64_t)j * M * split, split, m0, n0 - j * split, M,
+                      b ? b + j * split : nullptr, 0, relu);
+    return;
   }
   tile_reduce_store(acc, red, wave, lane, y, N, m0, n0, M, b, 0, relu, nullptr, nullptr, nullptr, Mpad);
 }
@@ -403,6 +413,89 @@ __global__ __launch_bounds__(256) void linear_bwd_kernel(const float* __restrict
 }
 
 
+// ---- the three input projections of a self-attention block, backwards, in ONE launch (three launches before) -------
+//   dy3 [3][M][E] = dq | dk | dv,   W [3E][E] (packed in_proj_weight),   x [M][E],   pos [M][E] or NULL
+//   dx_b = dq Wq + dk Wk                  gradient of the positional term (q = k = (x + pos) W)        (optional)
+//   dx   = dq Wq + dk Wk + dv Wv + dres   gradient of x; dres (optional): the block's residual path
+//   dW[jE + n][c] (+)= sum_m dy_j[m][n] (x + [j < 2] pos)[m][c],   db[jE + n] (+)= sum_m dy_j[m][n]
+// Workgroups [0, dx_tiles) take the input-gradient tiles (two accumulators: the q/k part and the v part, so that both
+// sums come out of one pass over the 3E-long reduction), the rest the weight-gradient tiles of the three matrices.
+__device__ inline void tile_reduce4(f32x16 acc, float (*red)[16][64], int wave, int lane, float (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 4 * wave + q;
+    out[q] = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void qkv_bwd_kernel(const float* __restrict__ dy3, const float* __restrict__ x,
+                                                     const float* __restrict__ pos, const float* __restrict__ W, int M,
+                                                     int E, int dx_tiles, int accumulate, float* __restrict__ dx,
+                                                     float* __restrict__ dx_b, const float* __restrict__ dres,
+                                                     float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float red[4][16][64];
+  __shared__ float bred[4][32];
+  const int kt = E / 32;
+  int b = blockIdx.x;
+  if (b >= dx_tiles) {
+    b -= dx_tiles;
+    const int c0 = (b % kt) * 32, n0 = (b / kt) * 32, j = n0 / E;
+    linear_dw_tile<true>(dy3 + (int64_t)j * M * E, nullptr, x, j < 2 ? pos : nullptr, M, E, E, accumulate,
+                         dW + (int64_t)j * E * E, db ? db + j * E : nullptr, c0, n0 - j * E, red, bred);
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int c0 = (b % kt) * 32, m0 = (b / kt) * 32;
+  const int m = m0 + i;
+  const float keep = m < M ? 1.f : 0.f;
+  f32x16 acc_qk, acc_v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc_qk[r] = acc_v[r] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float* ya = dy3 + ((int64_t)j * M + (m < M ? m : 0)) * E + 4 * h;
+    const float* wb = W + ((int64_t)j * E + 4 * h) * E + c0 + i;
+    for (int c = wave; c < kt; c += 4) {
+      const int n0 = c * 32;
+      float4 a[4];
+      float bv[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(ya + n0 + 8 * t);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) bv[4 * t + jj] = wb[(int64_t)(n0 + 8 * t + jj) * E];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float av[4] = {a[t].x * keep, a[t].y * keep, a[t].z * keep, a[t].w * keep};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          if (j < 2) acc_qk = MFMA32(av[jj], bv[4 * t + jj], acc_qk);
+          else acc_v = MFMA32(av[jj], bv[4 * t + jj], acc_v);
+        }
+      }
+    }
+  }
+  float qk[4], vv[4];
+  tile_reduce4(acc_qk, red, wave, lane, qk);
+  tile_reduce4(acc_v, red, wave, lane, vv);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = m0 + acc_row16(4 * wave + q, h);
+    if (row < M) {
+      const int64_t o = (int64_t)row * E + c0 + i;
+      if (dx_b) dx_b[o] = qk[q];
+      float t = qk[q] + vv[q];
+      if (dres) t += dres[o];
+      dx[o] = t;
+    }
+  }
+}
+
 // Column sums of a many-row table (the bias gradient of a linear layer over 3 200 / 12 800 sampled voxels), in a fixed
 // order: 64-row partial sums, then per column 16 lanes add the partials ascending and their sums are added ascending.  No atomics, no
 // last-block semaphores: the same bits on every launch and inside captured graphs.
@@ -470,7 +563,19 @@ int usc_linear_fwd_pad(const float* x, const float* x2, const float* W, const fl
   USC_REQUIRE(M_pad >= M, "usc_linear_fwd_pad: M_pad < M");
   USC_REQUIRE(x && W && y, "usc_linear_fwd: null pointer");
   hipLaunchKernelGGL(usc::linear_fwd_kernel, dim3(N / 32, (M_pad + 31) / 32), dim3(256), 0, usc::as_stream(s), x, x2, W, b,
-                     (int)M, (int)N, (int)K, (int)relu, y, (int)M_pad);
+                     (int)M, (int)N, (int)K, (int)relu, y, (int)M_pad, (int)N, 0);
+  USC_CHECK_LAUNCH("usc_linear_fwd");
+  return USC_OK;
+}
+
+int usc_linear_fwd_split(const float* x, const float* x2, const float* W, const float* b, int32_t M, int32_t N, int32_t K,
+                         int32_t x2_cols, int32_t split_cols, float* y, usc_stream_t s) {
+  USC_REQUIRE(M >= 1 && N >= 32 && N % 32 == 0 && K >= 32 && K % 32 == 0, "usc_linear_fwd: N, K must be multiples of 32");
+  USC_REQUIRE(split_cols >= 32 && split_cols % 32 == 0 && N % split_cols == 0 && x2_cols >= 0 && x2_cols % 32 == 0,
+              "usc_linear_fwd_split: split_cols / x2_cols must be multiples of 32, split_cols a divisor of N");
+  USC_REQUIRE(x && W && y, "usc_linear_fwd: null pointer");
+  hipLaunchKernelGGL(usc::linear_fwd_kernel, dim3(N / 32, (M + 31) / 32), dim3(256), 0, usc::as_stream(s), x, x2, W, b,
+                     (int)M, (int)N, (int)K, 0, y, (int)M, (int)x2_cols, (int)split_cols);
   USC_CHECK_LAUNCH("usc_linear_fwd");
   return USC_OK;
 }
@@ -504,6 +609,18 @@ int usc_linear_bwd_ex2(const float* dy, const float* y_relu, const float* x, con
                          (int)M, (int)N, (int)K, dx_tiles, (int)accumulate, dx, dx_add, dx_add2, dx_b, dW, db);
   }
   USC_CHECK_LAUNCH("usc_linear_bwd");
+  return USC_OK;
+}
+
+int usc_qkv_proj_bwd(const float* dy3, const float* x, const float* pos, const float* W, int32_t M, int32_t E, float* dx,
+                     float* dx_b, const float* dres, float* dW, float* db, int32_t accumulate, usc_stream_t s) {
+  USC_REQUIRE(M >= 1 && E >= 32 && E % 32 == 0, "usc_qkv_proj_bwd: E must be a multiple of 32");
+  USC_REQUIRE(dy3 && x && W && dx && dW, "usc_qkv_proj_bwd: null pointer");
+  const int dx_tiles = (E / 32) * ((M + 31) / 32);
+  const int dw_tiles = (E / 32) * (3 * E / 32);
+  hipLaunchKernelGGL(usc::qkv_bwd_kernel, dim3(dx_tiles + dw_tiles), dim3(256), 0, usc::as_stream(s), dy3, x, pos, W, (int)M,
+                     (int)E, dx_tiles, (int)accumulate, dx, dx_b, dres, dW, db);
+  USC_CHECK_LAUNCH("usc_qkv_proj_bwd");
   return USC_OK;
 }
 

@@ -1057,6 +1057,9 @@ def linear(x, W, b=None, relu=False, passthrough=False, pad_rows_to=None):
     return _LinearRows.apply(x, W, b, relu, passthrough, pad_rows_to)
 
 
+FUSED_QKV = os.environ.get("USC3D_FUSED_QKV", "1") == "1"
+
+
 class _InProj(torch.autograd.Function):
     """q, k, v = the three input projections of nn.MultiheadAttention from its packed in_proj_weight [3E,E] /
     in_proj_bias [3E] (reference: nn.MultiheadAttention inside models/mask3d.py:491-605).  One Function so that the
@@ -1074,7 +1077,19 @@ class _InProj(torch.autograd.Function):
         for j in range(2):     # many-row inputs (the sampled voxels): no fused add on those kernels, keep the sum
             if ps[j] is not None and not _small_linear_ok(xs[j].shape[0], E, E):
                 xs[j], ps[j] = xs[j] + ps[j], None
-        outs = [_lin_fwd(xs[j], W[j * E:(j + 1) * E], b[j * E:(j + 1) * E], add=ps[j]) for j in range(3)]
+        def same_t(a, c):
+            return a.data_ptr() == c.data_ptr() and a.shape == c.shape
+        if (FUSED_QKV and same_t(xs[0], xs[1]) and same_t(xs[1], xs[2]) and _small_linear_ok(xs[0].shape[0], E, 3 * E)
+                and W.is_contiguous() and (ps[0] is None) == (ps[1] is None)
+                and (ps[0] is None or same_t(ps[0], ps[1]))):
+            # self attention: one launch for the three projections of the one input ([3, M, E], each its own matrix)
+            M = xs[0].shape[0]
+            y3 = torch.empty((3, M, E), dtype=torch.float32, device=W.device)
+            check(lib.usc_linear_fwd_split(_ptr(xs[0]), _ptr(ps[0]), _ptr(W), _ptr(b), M, 3 * E, E, 2 * E, E, _ptr(y3),
+                                           _stream()), "usc_linear_fwd_split")
+            outs = [y3[0], y3[1], y3[2]]
+        else:
+            outs = [_lin_fwd(xs[j], W[j * E:(j + 1) * E], b[j * E:(j + 1) * E], add=ps[j]) for j in range(3)]
         ctx.save_for_backward(xs[0], xs[1], xs[2], W, ps[0], ps[1])
         ctx.shapes = (xq.shape, xk.shape, xv.shape)
         ctx.pos_shapes = (None if pos_q is None else pos_q.shape, None if pos_k is None else pos_k.shape)
@@ -1111,7 +1126,19 @@ class _InProj(torch.autograd.Function):
             return _lin_bwd(dyj.contiguous().view(-1, E), xj, W[j * E:(j + 1) * E], dW[j * E:(j + 1) * E],
                             db[j * E:(j + 1) * E], need_dx=need_dx, accumulate=in_place, add=pj, dx_add=dx_add)
 
-        if dres2 is not None and ctx.same_qk and ctx.same_kv and ctx.same_pos and need[0]:
+        M = x0.shape[0]
+        adjacent = (dq.is_contiguous() and dk.is_contiguous() and dv.is_contiguous()
+                    and dk.data_ptr() == dq.data_ptr() + 4 * M * E and dv.data_ptr() == dk.data_ptr() + 4 * M * E)
+        if (FUSED_QKV and ctx.same_qk and ctx.same_kv and ctx.same_pos and need[0] and adjacent and W.is_contiguous()
+                and _small_linear_ok(M, 3 * E, E) and dW.is_contiguous() and db.is_contiguous()):
+            # self attention: the three projections backwards in one launch (usc_qkv_proj_bwd)
+            gx = torch.empty((M, E), dtype=torch.float32, device=W.device)
+            gpos = torch.empty_like(gx) if (need_pq and p0 is not None) else None
+            check(lib.usc_qkv_proj_bwd(_ptr(dq), _ptr(x0), _ptr(p0), _ptr(W), M, E, _ptr(gx), _ptr(gpos), _ptr(dres2),
+                                       _ptr(dW), _ptr(db), int(in_place), _stream()), "usc_qkv_proj_bwd")
+            out_x = (gx, None, None)
+            out_p = (gpos, None)
+        elif dres2 is not None and ctx.same_qk and ctx.same_kv and ctx.same_pos and need[0]:
             # self attention with the residual: v (+ residual) first, then k, then q on top of both; the q launch also
             # writes the sum WITHOUT the v/residual part — the positional term's gradient
             gv = bwd(2, dv, x2, None, True, dx_add=dres2)
@@ -1232,7 +1259,8 @@ class _SelfAttention(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         L, B, E = q.shape
         do = do.contiguous()
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        d3 = torch.empty((3,) + tuple(q.shape), dtype=torch.float32, device=q.device)   # adjacent: the fused projection
+        dq, dk, dv = d3[0], d3[1], d3[2]                                                # backward reads them as one table
         check(lib.usc_self_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(lse), _ptr(do), L, B, ctx.num_heads, E,
                                     _ptr(dq), _ptr(dk), _ptr(dv), _stream()), "usc_self_attn_bwd")
         return dq, dk, dv, None
