@@ -19,3 +19,12 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+def free_port():
+    """A TCP port nobody listens on right now (the multi-process tests rendezvous on 127.0.0.1): fixed port numbers
+    collide with a previous test's sockets still in TIME_WAIT, or with another job on a shared box."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]

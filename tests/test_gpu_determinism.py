@@ -17,6 +17,8 @@ import sys
 
 import pytest
 
+from conftest import free_port as _free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -51,7 +53,7 @@ def test_two_rank_trajectories_are_bit_reproducible_under_load(overlap):
     """Two ranks (RCCL on a multi-GPU box, else gloo on the shared device), 16 trials of four full steps each from one
     restored state, next to a third training process: loss bits and the reduced gradients of every step identical."""
     out = _torchrun([os.path.join(ROOT, "tests", "stress", "trajectory_probe.py"), "--trials", "16", "--load", "1"],
-                    29641 + int(overlap), {"USC3D_OVERLAP_ALLREDUCE": overlap})
+                    _free_port(), {"USC3D_OVERLAP_ALLREDUCE": overlap})
     res = re.findall(r"RESULT rank (\d) .*: (\d+) of (\d+) trials differ", out)
     assert sorted(r[0] for r in res) == ["0", "1"], out[-2000:]
     assert all(int(r[1]) == 0 and int(r[2]) == 15 for r in res), out[-2000:]
@@ -64,7 +66,7 @@ def test_two_rank_runs_are_bit_reproducible_across_processes():
     for k in range(3):
         for overlap in ("1", "0"):
             out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--voxels",
-                             "40000", "--dist-backend", _backend(), "--no-cpu-baseline"], 29651 + 2 * k + int(overlap),
+                             "40000", "--dist-backend", _backend(), "--no-cpu-baseline"], _free_port(),
                             {"USC3D_OVERLAP_ALLREDUCE": overlap})
             rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
             losses.add(rec["config"]["loss"])

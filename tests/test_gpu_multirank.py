@@ -9,6 +9,8 @@ import sys
 
 import pytest
 
+from conftest import free_port as _free_port
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -38,7 +40,7 @@ def test_overlapped_gradient_allreduce_equals_the_single_one():
     difference at 5e-6 after a handful of two-rank runs on a shared device had ended 5-6 ulp apart; the stress
     harness of tests/test_gpu_determinism.py — ~1 800 step sequences under load — never reproduced a differing bit,
     see DESIGN.md §6.)"""
-    a, b = _run("1", 29561), _run("0", 29563)
+    a, b = _run("1", _free_port()), _run("0", _free_port())
     la, lb = a["config"]["loss"], b["config"]["loss"]
     assert la == lb, (la, lb)
     note = a["config"]["grad_allreduce"]
@@ -49,7 +51,7 @@ def test_overlapped_gradient_allreduce_equals_the_single_one():
 def test_bench_two_ranks():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -74,7 +76,7 @@ def test_uneven_ranks_neither_hang_nor_diverge(overlap):
     weights to the bit and a finite loss."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", USC3D_OVERLAP_ALLREDUCE=overlap)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29571 + int(overlap)), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "2", "--voxels-by-rank", "150000,20000", "--eager-ranks", "1", "--dist-backend", _backend(),
            "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
