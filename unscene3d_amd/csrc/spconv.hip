@@ -38,6 +38,7 @@ struct GemmParams {
   int accumulate;
   int G;                // offset groups (blockIdx.z); >1 -> partial sums, reduced afterwards
   int TM;               // tile-compacted kernel: output rows per workgroup
+  int wt1;              // aligned kernel, K == 1: W is given as [cout][cin] (nn.Linear's layout), B[c][n] = W[n][c]
   // pairs form
   const int32_t* rows_in;
   const int32_t* rows_out;
@@ -142,10 +143,22 @@ __global__ __launch_bounds__(256) void gather_gemm_aligned_kernel(GemmParams p) 
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(arow + c0 + 8 * t);
       float b[16][NB];
+      if (p.wt1) {
+        // a lane's column n0 + NB*i + nb of B is ROW n of W: its four k-steps of a quad are one 16-byte load
+        const float* wr = p.W + (int64_t)(n0 + NB * i) * cin + 4 * h + c0;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float4 w4 = *reinterpret_cast<const float4*>(wr + (int64_t)nb * cin + 8 * t);
+            b[4 * t + 0][nb] = w4.x; b[4 * t + 1][nb] = w4.y; b[4 * t + 2][nb] = w4.z; b[4 * t + 3][nb] = w4.w;
+          }
+      } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) load_b<NB>(wk + (int64_t)(c0 + 8 * t + j) * cout, b[4 * t + j]);
+      }
       if (!valid) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1152,9 +1165,12 @@ int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const flo
     p.out = (float*)ws;
   }
   hipStream_t st = as_stream(s);
-  USC_REQUIRE(!w_transposed || pl.TM > 0,
-              "usc_spconv_gather_gemm: w_transposed is only folded into the tile-compacted kernel (usc_spconv_plan bit 12); "
+  const bool wt1 = w_transposed && K == 1 && !nbr && pl.aligned && pl.TM == 0;   // a linear layer's [cout][cin] weight
+  USC_REQUIRE(!w_transposed || pl.TM > 0 || wt1,
+              "usc_spconv_gather_gemm: w_transposed is only folded into the tile-compacted kernel (usc_spconv_plan bit 12) "
+              "and, for K = 1 on identity rows with channel counts in multiples of 32, into the row-order kernel; "
               "use usc_weight_transpose for other shapes");
+  p.wt1 = wt1 ? 1 : 0;
   if (pl.TM > 0) {
     p.TM = pl.TM;
     USC_REQUIRE(ws && ws_bytes >= (int64_t)K * cin * cout * 4, "usc_spconv_gather_gemm: workspace too small");

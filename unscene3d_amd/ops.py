@@ -248,7 +248,8 @@ def gather_gemm(feats, W, nbr, n_out, bias=None, out=None, accumulate=False, w_t
     _chk(W, torch.float32, "W")
     if w_transposed:
         K, cout, cin = W.shape
-        if not (_sorted_applies(nbr, K, cin, cout) or
+        linear_form = nbr is None and K == 1 and cin % 32 == 0 and cout % 32 == 0     # folded into the row-order kernel
+        if not (linear_form or _sorted_applies(nbr, K, cin, cout) or
                 (nbr is not None and (lib.usc_spconv_plan(0, int(n_out), cin, cout, K) >> 12) & 1)):
             W = weight_transpose(W, mirror=K > 1)
             w_transposed = False
@@ -931,8 +932,9 @@ def _lin_fwd(x2, W, b, add=None, relu=False, pad_rows_to=None):
     if relu:
         return torch.relu_(_lin_fwd(x2, W, b))
     if _rows_gemm_ok(M, K, N) and W.is_contiguous():
-        Wt = weight_transpose(W.view(1, N, K), mirror=False)          # [1, K, N]: the conv kernels' [cin, cout]
-        return gather_gemm(x2, Wt, None, M, bias=b)
+        # W [N, K] is the product's [cout][cin]: read in place by the row-order kernel (was: a transpose launch per call,
+        # 36 per training step inside the captured decoder passes)
+        return gather_gemm(x2, W.view(1, N, K), None, M, bias=b, w_transposed=True)
     return torch.addmm(b, x2, W.t()) if b is not None else x2 @ W.t()
 
 
