@@ -148,7 +148,8 @@ int usc_weight_transpose(const float* W, int32_t K, int32_t cin, int32_t cout,
  * Small maps (coarse U-Net levels) split the K offsets over extra workgroups and
  * reduce the partial sums in a fixed order through `ws`
  * (usc_spconv_gather_gemm_ws_bytes; 0 bytes when no split is planned).
- * w_transposed=1 (tile-compacted plan only, usc_spconv_plan bit 12): W is the forward
+ * w_transposed=1 (tile-compacted plan, usc_spconv_plan bit 12; also K = 1 on identity rows with cin, cout multiples of
+ * 32 — a linear layer's [cout][cin] weight read in place): W is the forward
  * conv's f32[K,cout,cin] and W'[k][c][n] = W[K-1-k][n][c] is used (stride-1 dgrad).
  * Covers: k3/s1 conv fwd and dgrad (W = usc_weight_transpose(mirror=1), or w_transposed),
  * k2/s2 conv fwd (nbr = child table), conv-transpose dgrad. */
