@@ -10,6 +10,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import ctypes
 import os
 
 import torch
@@ -650,7 +651,6 @@ class _SampleKeys(torch.autograd.Function):
                 raise RuntimeError(f"sample_keys: output buffers {have} do not fit {want} (contiguous f32 / bool / f32): "
                                    f"dtypes {of.dtype}, {om.dtype}, {None if op is None else op.dtype}; "
                                    f"strides {of.stride()}, {om.stride()}")
-        import ctypes
         nv = (ctypes.c_int32 * n_scenes)(*[int(v) for v in n_valid])
         wsb = lib.usc_sample_keys_ws_bytes(n_scenes, K, q)
         ws = _ws(wsb, dev)
