@@ -993,7 +993,11 @@ __global__ void weight_pack_kernel(const float* __restrict__ W, int K, int cin, 
 
 static int wgrad_splits(int K, int cin, int cout, int NB, int64_t n_rows) {
   const int64_t tiles = (int64_t)K * ceil_div(cin, 32) * ceil_div(cout, NB * 32);
-  int64_t S = ceil_div(2048, tiles);
+  // measured on the 128->96 layers (tools/scratch/r03/wg_target2.sh): 4.0 M pairs 902 / 776 / 730 / 745 us at 1 024 /
+  // 2 048 / 4 096 / 6 912 workgroups, 1.1 M pairs 286 / 266 / 276 / 303 us
+  static const int knob = getenv("USC3D_WGRAD_TILE_TARGET") ? atoi(getenv("USC3D_WGRAD_TILE_TARGET")) : 0;
+  const int target = knob > 0 ? knob : ((K > 1 && n_rows >= (int64_t)2 << 20) ? 4096 : 2048);
+  int64_t S = ceil_div(target, tiles);
   const int64_t by_rows = n_rows / 2048 + 1;
   if (S > by_rows) S = by_rows;
   if (S > 64) S = 64;
@@ -1008,7 +1012,12 @@ static int64_t wgrad_full_splits(int K, int ctiles, int cb, int CT, int NBf, int
   const int64_t blocks_per_split = (int64_t)K * (ctiles / CT) * (cb / NBf);
   static const int target = getenv("USC3D_WGRAD_TARGET_BLOCKS") ? atoi(getenv("USC3D_WGRAD_TARGET_BLOCKS")) : 512;
   static const int rows_per = getenv("USC3D_WGRAD_ROWS_PER_SPLIT") ? atoi(getenv("USC3D_WGRAD_ROWS_PER_SPLIT")) : 4096;
-  int64_t S = target / blocks_per_split;                      // 512: one round of 2 workgroups per CU
+  // 512: one round of 2 workgroups per CU.  The finest level (4.0 M pairs at 150 k voxels) is the exception: 64 slices
+  // of its 27 x 1 x 1 workgroups (1 728, ~0.9 MB each) measured 417 us against 451 us with 18 (86.5 vs 80 TFLOP/s) — the
+  // long pair lists leave a tail of half-empty CUs that more, shorter workgroups fill; from 1.1 M pairs down the extra
+  // slices cost more than they return (158 -> 164 us, 33 -> 38 us on the coarse levels).
+  const int64_t tgt = (K > 1 && n_rows >= (int64_t)2 << 20 && target < 2048) ? 2048 : target;
+  int64_t S = tgt / blocks_per_split;
   // USC3D_WGRAD_ONE_SLICE_FROM=<blocks>: no pair split (and no reduction launch) once a single slice already has that
   // many workgroups (experiment knob)
   static const int one_from = getenv("USC3D_WGRAD_ONE_SLICE_FROM") ? atoi(getenv("USC3D_WGRAD_ONE_SLICE_FROM")) : 0;
