@@ -185,6 +185,8 @@ def _kernel_symbol(kind, n, cin, cout, K):
     code = lib.usc_spconv_plan(kind, int(n), cin, cout, K)
     nb, aligned, compact = code & 0xFF, (code >> 8) & 1, (code >> 12) & 1
     tag = f" [n={int(n)} cin={cin} cout={cout} K={K} G={code >> 16}]" if _prof.SHAPES else ""
+    if kind == 0 and (code >> 14) & 1:
+        return "usc::stem_conv_kernel" + tag
     if kind == 0 and compact:
         return f"usc::gather_gemm_compact_kernel<{nb}>" + tag
     if kind == 2:
