@@ -221,6 +221,13 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout,
  * above assumes the maximum split count). */
 int64_t usc_spconv_wgrad_ws_bytes_rows(int32_t K, int32_t cin, int32_t cout,
                                        int64_t n_rows);
+/* Weight gradient in TABLE form for few input channels (cin <= 4, cout = 32: the 3 -> 32 stem, reference
+ * models/res16unet.py conv0p1s1):  dW[k][c][n] = sum_o in[nbr[k][o]][c] dy[o][n]  with the forward conv's neighbour
+ * table nbr i32[K, n_out].  32 / cin offsets share one MFMA tile (row m = offset, channel), 3 groups instead of 27
+ * per-offset passes with 3 useful tile rows each. */
+int64_t usc_spconv_wgrad_table_ws_bytes(int32_t K, int32_t cin, int32_t cout);
+int usc_spconv_wgrad_table(const float* in, int32_t cin, const float* dy, int32_t cout, const int32_t* nbr, int32_t K,
+                           int64_t n_out, float* dW, int32_t accumulate, void* ws, int64_t ws_bytes, usc_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Native issue path: whole convolutions and "conv -> batch norm (+ residual)

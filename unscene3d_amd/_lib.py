@@ -66,6 +66,8 @@ SIGNATURES = {
     "usc_spconv_wgrad_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p, _i64, _p]),
     "usc_spconv_wgrad_ws_bytes_rows": (_i64, [_i32, _i32, _i32, _i64]),
+    "usc_spconv_wgrad_table_ws_bytes": (_i64, [_i32, _i32, _i32]),
+    "usc_spconv_wgrad_table": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i64, _p, _i32, _p, _i64, _p]),
     "usc_set_side_stream": (C.c_int, [_p]),
     "usc_set_wgrad_lane": (C.c_int, [_p, _p, _i64, _i64]),
     "usc_wgrad_lane_join": (C.c_int, [_p]),

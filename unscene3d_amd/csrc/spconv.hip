@@ -954,6 +954,67 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
   }
 }
 
+// Weight gradient of the stem (<= 4 input channels, 32 output channels), table form: dW[k][c][n] = sum_o in[nbr[k][o]][c] dy[o][n].
+// The pair-list kernels run one offset per workgroup: a [32 x 32] MFMA tile whose M side holds 3 useful rows (131 us,
+// 2.9 TFLOP/s at 150 k voxels).  Here the M side holds 32 / cin offsets x cin channels — MFMA row m = (offset j, channel c)
+// — so ceil(K / (32 / cin)) = 3 groups replace 27 passes over the rows; dW row k*cin + c = group*per*cin + m is
+// contiguous, the groups' tiles are slices of dW itself.  Lane (i, h) feeds A[m = i][row 2t + h] = its own (offset,
+// channel) element of that row's neighbour and B[row 2t + h][n = i] = dy; S row ranges -> partial slices in dW layout,
+// summed in order by wgrad_reduce_kernel.
+constexpr int kStemSplits = 64;
+constexpr int kStemWaves = 16;      // a trip is two dependent loads (id -> element) and four MFMAs: latency hidden by waves
+__global__ __launch_bounds__(64 * kStemWaves) void stem_wgrad_kernel(const float* __restrict__ in, const float* __restrict__ dy,
+                                                                    const int32_t* __restrict__ nbr, int64_t n_out, int K,
+                                                                    int cin, float* __restrict__ partial) {
+  __shared__ float red[kStemWaves][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+  const int per = 32 / cin;                                  // offsets per group
+  const int g = blockIdx.y, s = blockIdx.x, S = gridDim.x;
+  const int j = i / cin, c = i - j * cin, k = g * per + j;
+  const bool active = j < per && k < K;
+  int64_t L = (n_out + S - 1) / S;
+  L = (L + 2 * kStemWaves - 1) / (2 * kStemWaves) * (2 * kStemWaves);
+  const int64_t r_begin = (int64_t)s * L;
+  int64_t r_end = r_begin + L;
+  if (r_end > n_out) r_end = n_out;
+  const int32_t* nk = nbr + (int64_t)(active ? k : 0) * n_out;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // four rounds in flight: ids, then the gathered elements and dy, then the matrix cores
+  for (int64_t rb = r_begin + 2 * wave; rb < r_end; rb += 8 * kStemWaves) {   // (wave-uniform trip count: MFMA needs every lane)
+    int id[4];
+    float b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t r = rb + h + 2 * kStemWaves * u;
+      const bool ok = r < r_end;
+      id[u] = (ok && active) ? nk[r] : -1;
+      b[u] = ok ? dy[r * 32 + i] : 0.f;
+    }
+    float a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = id[u] >= 0 ? in[(int64_t)id[u] * cin + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+  __syncthreads();
+  if (wave >= 4) return;
+  float* dst = partial + (int64_t)s * K * cin * 32;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 4 * wave + q;
+    const int m = acc_row(r, h);
+    float v = red[kStemWaves - 1][r][lane];
+#pragma unroll
+    for (int w = kStemWaves - 2; w >= 0; --w) v += red[w][r][lane];
+    const int row = g * per * cin + m;
+    if (m < per * cin && row < K * cin) dst[(int64_t)row * 32 + i] = v;
+  }
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, int64_t numel, int accumulate,
                                     float* __restrict__ dW) {
   // float4 per thread when the slice length allows it (every [K, cin, cout] with cout % 4 == 0), slices in s order
@@ -1289,6 +1350,27 @@ int64_t usc_spconv_wgrad_ws_bytes_rows(int32_t K, int32_t cin, int32_t cout, int
   }
 #endif
   return (int64_t)wgrad_splits(K, cin, cout, pick_nb(cout), n_rows) * numel * 4;
+}
+
+int64_t usc_spconv_wgrad_table_ws_bytes(int32_t K, int32_t cin, int32_t cout) {
+  return (int64_t)kStemSplits * K * cin * cout * 4;
+}
+
+int usc_spconv_wgrad_table(const float* in, int32_t cin, const float* dy, int32_t cout, const int32_t* nbr, int32_t K,
+                           int64_t n_out, float* dW, int32_t accumulate, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(cin >= 1 && cin <= 4 && cout == 32 && K >= 1 && K <= 32 && n_out >= 0,
+              "usc_spconv_wgrad_table: the table form covers <= 4 input channels and 32 output channels (the stem)");
+  USC_REQUIRE(in && dy && nbr && dW && ws, "usc_spconv_wgrad_table: null pointer");
+  USC_REQUIRE(ws_bytes >= usc_spconv_wgrad_table_ws_bytes(K, cin, cout), "usc_spconv_wgrad_table: workspace too small");
+  hipStream_t st = as_stream(s);
+  const int per = 32 / cin, groups = (K + per - 1) / per;
+  const int64_t numel = (int64_t)K * cin * 32;
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(kStemSplits, (unsigned)groups), dim3(64 * kStemWaves), 0, st, in, dy, nbr, n_out, (int)K,
+                     (int)cin, (float*)ws);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, kStemSplits, numel,
+                     (int)accumulate, dW);
+  USC_CHECK_LAUNCH("usc_spconv_wgrad_table");
+  return USC_OK;
 }
 
 int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, int32_t K, const int32_t* a_idx,

@@ -10,6 +10,8 @@
 //
 // Reference: models/modules/resnet_block.py:48-64 (conv -> norm -> relu / `out += residual`),
 // models/res16unet.py:231-297 (conv{0..4} / convtr{4..7} + bn + relu), models/modules/common.py:125-188.
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace usc;
@@ -202,6 +204,10 @@ static void conv_ws_parts(const usc_kmap* m, int kind, int cin, int cout, int64_
   *dgrad = align_up(*dgrad + 256, 256);
   const int64_t rows = m->nbr ? m->pair_capacity : sh.n_in;
   *wg = align_up(usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows), 256);
+  if (kind == USC_CONV_SAME && m->nbr && cin <= 4 && cout == 32) {      // the stem: table-form weight gradient
+    const int64_t t = align_up(usc_spconv_wgrad_table_ws_bytes(K, cin, cout), 256);
+    if (t > *wg) *wg = t;
+  }
 }
 
 int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin, int32_t cout) {
@@ -302,7 +308,11 @@ int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t c
     void* w = wc.take(b);
     if (!w) set_error("usc_conv_backward: workspace too small (weight gradient)");
     usc_stream_t ws_stream = (usc_stream_t)wst;
+    static const bool stem_table = !getenv("USC3D_STEM_KERNEL") || atoi(getenv("USC3D_STEM_KERNEL")) != 0;
+    const int64_t bt = usc_spconv_wgrad_table_ws_bytes(K, cin, cout);
     if (!w) rc = USC_ERR_ARG;
+    else if (stem_table && kind == USC_CONV_SAME && m->nbr && cin <= 4 && cout == 32 && K <= 32 && (char*)w + bt <= (char*)ws + ws_bytes)
+      rc = usc_spconv_wgrad_table(x, cin, dy, cout, m->nbr, K, sh.n_out, dW, dW_accumulate, w, bt, ws_stream);
     else if (!m->nbr)
       rc = usc_spconv_wgrad(x, cin, dy, cout, 1, nullptr, nullptr, nullptr, sh.n_in, dW, dW_accumulate, w, b, ws_stream);
     else if (kind == USC_CONV_UP)

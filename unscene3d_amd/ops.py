@@ -332,14 +332,28 @@ def _grad_written(*params):
                 GRAD_WRITTEN_HOOK(p)
 
 
-def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None, into=None, out=None):
+STEM_KERNEL = os.environ.get("USC3D_STEM_KERNEL", "1") != "0"
+
+
+def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None, into=None, out=None, nbr=None):
     """dW[k] = sum_{p in list k} a[a_idx[p]]^T b[b_idx[p]] -> f32[K,cin,cout]; ADDED into `into`, or WRITTEN to `out`
-    (a contiguous buffer of K*cin*cout floats), when given."""
+    (a contiguous buffer of K*cin*cout floats), when given.
+    nbr (optional): the forward conv's neighbour table i32[K, n_out] of a stride-1 conv whose pair lists these are;
+    the stem (<= 4 input channels, 32 output channels) then takes the table form (usc_spconv_wgrad_table)."""
     _chk(a, torch.float32, "a")
     _chk(b, torch.float32, "b")
     cin, cout = a.shape[1], b.shape[1]
     dW = into if into is not None else (out if out is not None else
                                         torch.empty((K, cin, cout), dtype=torch.float32, device=a.device))
+    if STEM_KERNEL and nbr is not None and cin <= 4 and cout == 32 and K <= 32 and nbr.shape == (K, b.shape[0]):
+        wsb = lib.usc_spconv_wgrad_table_ws_bytes(K, cin, cout)
+        ws = _ws(wsb, a.device)
+        with _prof.maybe(lambda: "usc::stem_wgrad_kernel" + (f" [n={b.shape[0]} cin={cin} cout={cout} K={K}]" if _prof.SHAPES else ""),
+                         lambda: _conv_cost(_prof.table_pairs(nbr), a.shape[0], b.shape[0], K, cin, cout)):
+            check(lib.usc_spconv_wgrad_table(_ptr(a), cin, _ptr(b), cout, _ptr(nbr), K, b.shape[0], _ptr(dW),
+                                             int(into is not None), _ptr(ws), ws.numel(), _stream()),
+                  "usc_spconv_wgrad_table")
+        return dW
     ws = _ws(lib.usc_spconv_wgrad_ws_bytes(K, cin, cout), a.device)
     n_rows = a.shape[0] if a_idx is None else int(a_idx.shape[0])
     # (profiling only) real pair count = koff[K]; n_rows is the capacity of the pair lists
@@ -382,7 +396,7 @@ class _ConvSame(torch.autograd.Function):
                 dW = wgrad(feats, dout, 1, into=tgt)
             else:
                 rb = ctx.get_rulebook()
-                dW = wgrad(feats, dout, K, rb.in_idx, rb.out_idx, rb.koff, into=tgt)
+                dW = wgrad(feats, dout, K, rb.in_idx, rb.out_idx, rb.koff, into=tgt, nbr=ctx.nbr)
             if tgt is not None:
                 dW = None
                 _grad_written(ctx.w_param)
