@@ -112,7 +112,7 @@ __device__ inline bool locate_tile(const GemmParams& p, int wave, int i, int& k_
 
 // Fast path: cin % 32 == 0 and cout % (32*NB) == 0 — no bounds checks inside the loop,
 // every load unconditional (invalid rows read row 0 and are zeroed with a select).
-template <int NB, bool LIST>
+template <int NB, bool LIST, bool WT = false>   // WT: K == 1, W given as [cout][cin] (a linear layer's weight), see GemmParams::wt1
 __global__ __launch_bounds__(256) void gather_gemm_aligned_kernel(GemmParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void gather_gemm_aligned_kernel(GemmParams p) 
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(arow + c0 + 8 * t);
       float b[16][NB];
-      if (p.wt1) {
+      if (WT) {
         // a lane's column n0 + NB*i + nb of B is ROW n of W: its four k-steps of a quad are one 16-byte load
         const float* wr = p.W + (int64_t)(n0 + NB * i) * cin + 4 * h + c0;
 #pragma unroll
@@ -1199,7 +1199,9 @@ static GemmPlan plan_list(int64_t max_tiles, int cin, int cout) {
 template <bool LIST>
 static void launch_gemm(const GemmPlan& pl, dim3 grid, hipStream_t st, const GemmParams& p) {
 #define USC_GG(NBv)                                                                                      \
-  if (pl.aligned)                                                                                        \
+  if (pl.aligned && p.wt1)       /* compile-time variant: a runtime test in the loop cost the plain form 35 % */ \
+    hipLaunchKernelGGL((gather_gemm_aligned_kernel<NBv, false, true>), grid, dim3(256), 0, st, p);      \
+  else if (pl.aligned)                                                                                   \
     hipLaunchKernelGGL((gather_gemm_aligned_kernel<NBv, LIST>), grid, dim3(256), 0, st, p);             \
   else                                                                                                   \
     hipLaunchKernelGGL((gather_gemm_kernel<NBv, LIST>), grid, dim3(256), 0, st, p);
