@@ -56,6 +56,8 @@ def parse(argv=None):
                          "reference's first-occurrence order, 2.3x instead of 6.9x the algorithmic bytes fetched by the "
                          "dominant conv kernel (profiles/r02_spatial_sort_sweep.txt).  0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-order", action="store_true",
+                    help="skip the second timed loop in the reference's own row order (`value_reference_order`)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the measured configuration); gloo only to smoke-test the N>1 code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices)")
@@ -66,6 +68,10 @@ def parse(argv=None):
     ap.add_argument("--rotate", type=int, default=0, metavar="N",
                     help="rotate N distinct scene sets (voxel counts spread over +-20 %% of --voxels) through the steps "
                          "instead of replaying one; per-step times p10/p50/p90 are added to the line")
+    ap.add_argument("--bucket-window", type=int, default=8, metavar="K",
+                    help="with --rotate on N > 1 ranks the scenes are drawn through datasets/sampler.py "
+                         "(DistributedSampler semantics): K steps' worth of scenes are sorted by size and dealt so that "
+                         "the ranks of a step hold scenes of similar size; 1 = plain DistributedSampler order")
     ap.add_argument("--voxels-by-rank", default=None, metavar="N0,N1,...",
                     help="scene size per rank (uneven ranks: the step of a small scene is host-bound, that of a large one "
                          "device-bound; the collectives must line up all the same); default: --voxels on every rank")
@@ -150,12 +156,34 @@ def make_mask3d_step(args, dev, rank, world):
                      else x for i, x in enumerate(sample))
     # scene sets: one per rotation slot, B scenes each; slot 0 of B = 1 is the scene of rounds 1-2 (seed 2000 + rank)
     n_sets = max(1, args.rotate)
-    sets = []
-    for j in range(n_sets):
-        scale = 1.0 if n_sets == 1 else 0.8 + 0.4 * ((j * 5) % n_sets) / max(1, n_sets - 1)   # spread, not sorted
-        seed = 2000 + rank if (B == 1 and j == 0) else 2000 + 1000 * rank + 16 * j
-        ds = SyntheticFreeMaskDataset(n_scenes=B, target_voxels=int(voxels * scale), seed=seed)
-        sets.append([resident(ds[i]) for i in range(B)])
+    sets, skew_info = [], None
+    if world > 1 and args.rotate:
+        # N ranks: ONE pool of world * rotate * B scenes (sizes spread over +-20 %), every rank draws its scenes of a
+        # step through the sampler (DistributedSampler semantics + size bucketing, datasets/sampler.py) and keeps only
+        # the scenes of its own plan resident
+        from unscene3d_amd.datasets.sampler import BucketedDistributedSampler
+        n_pool = world * n_sets * B
+        scale = 0.8 + 0.4 * ((np.arange(n_pool) * 5) % n_pool) / max(1, n_pool - 1)
+        sizes = (voxels * scale).astype(np.int64)
+        sampler = BucketedDistributedSampler(sizes, world, rank, batch_size=B, window=max(1, args.bucket_window), seed=2000)
+        plain = BucketedDistributedSampler(sizes, world, rank, batch_size=B, window=1, seed=2000)
+        mine = sampler.plan()[:, rank, :]
+        n_sets = mine.shape[0]
+        cache = {}
+        for step_ids in mine:
+            for g in step_ids:
+                if int(g) not in cache:
+                    ds = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=int(sizes[g]), seed=5000 + 16 * int(g))
+                    cache[int(g)] = resident(ds[0])
+            sets.append([cache[int(g)] for g in step_ids])
+        skew_info = {"sampler": "BucketedDistributedSampler", "bucket_window": sampler.window, "pool_scenes": n_pool,
+                     "planned_voxel_max_over_mean": sampler.imbalance(), "unbucketed_voxel_max_over_mean": plain.imbalance()}
+    else:
+        for j in range(n_sets):
+            scale = 1.0 if n_sets == 1 else 0.8 + 0.4 * ((j * 5) % n_sets) / max(1, n_sets - 1)   # spread, not sorted
+            seed = 2000 + rank if (B == 1 and j == 0) else 2000 + 1000 * rank + 16 * j
+            ds = SyntheticFreeMaskDataset(n_scenes=B, target_voxels=int(voxels * scale), seed=seed)
+            sets.append([resident(ds[i]) for i in range(B)])
     if not (args.no_graphs or eager):
         module.model.enable_decoder_graphs(batch_size=B, device=dev)
     collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(dev),
@@ -172,7 +200,7 @@ def make_mask3d_step(args, dev, rank, world):
         prefetch = ScenePrefetcher(collate, add_raw_coordinates=cfg.data.add_raw_coordinates, device=dev,
                                    precompute=module.model.precompute_geometry)
         prefetch.submit(sets[0])       # the first batch, outside the timed region like the resident raw arrays
-    state = {"k": 0}
+    state = {"k": 0, "marks": None}
 
     def step(w):
         state["k"] += 1
@@ -186,6 +214,10 @@ def make_mask3d_step(args, dev, rank, world):
         if reducer is not None:
             reducer.begin_step()
         total.backward()
+        if state["marks"] is not None:                # device-side: this rank's own work of the step is queued up to here
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            state["marks"].append(ev)
         if reducer is not None:
             reducer.finish()           # RCCL over xGMI: what backward has not already started, then wait + average
         elif w > 1:
@@ -198,13 +230,54 @@ def make_mask3d_step(args, dev, rank, world):
         return total.detach(), batch[0].coordinates.shape[0]
 
     state["sched"] = sched
+    def set_spatial_sort(shift):
+        """Switch the collate's row order (0 = the reference's first-occurrence order, datasets/utils.py:403-408) and
+        re-issue the prefetched batch in the new order."""
+        collate.spatial_sort = int(shift) if shift else False
+        if prefetch is not None:
+            prefetch.take()
+            prefetch.submit(sets[state["k"] % n_sets])
+
+    step.set_spatial_sort = set_spatial_sort
     step.scenes_per_rank = B
+    step.skew_info = skew_info
+    step.state = state
     step.reducer = reducer
     step.module = module
     step.params = params
     step.opt = opt
     step.set_sched = lambda s: state.__setitem__("sched", s)      # tools/det_probe_mr.py restarts the schedule per trial
     return step
+
+
+def _committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json), or null
+    with the reason when the figure cannot vouch for the code that just ran: the json records the sha256 of every
+    kernel source at measurement time; a kernel whose defining .hip (or a shared header) changed since reports null."""
+    import hashlib
+    import re
+    root = os.path.dirname(os.path.abspath(__file__))
+    tpath = os.path.join(root, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return {"traffic": None, "traffic_source": "no profiles/pmc_traffic.json"}
+    with open(tpath) as f:
+        table = json.load(f)
+    ent = table.get(kernel)
+    if not ent:
+        return {"traffic": None, "traffic_source": f"profiles/pmc_traffic.json has no entry for {kernel}"}
+    shas = table.get("_source_sha256")
+    if not shas:
+        return {"traffic": None, "traffic_source": "profiles/pmc_traffic.json carries no source hashes (unverifiable)"}
+    csrc = os.path.join(root, "unscene3d_amd", "csrc")
+    base = re.sub(r"<.*$", "", kernel.replace("usc::", ""))
+    need = [f for f in sorted(os.listdir(csrc)) if f.endswith(".h")]
+    need += [f for f in sorted(os.listdir(csrc)) if f.endswith(".hip")
+             and re.search(r"\b" + re.escape(base) + r"\b", open(os.path.join(csrc, f)).read())]
+    for fn in need:
+        have = hashlib.sha256(open(os.path.join(csrc, fn), "rb").read()).hexdigest()
+        if shas.get(fn) != have:
+            return {"traffic": None, "traffic_source": f"stale: {fn} changed since profiles/pmc_traffic.json was measured"}
+    return {"traffic": ent["bytes_per_launch"], "traffic_source": "profiles/pmc_traffic.json (source hashes match)"}
 
 
 def _allreduce_note(step, world):
@@ -303,22 +376,19 @@ def cpu_baseline_mask3d(sample_voxels, runs=10, warmup=3, leg_budget_s=25.0):
     3 timed passes) once it has used `leg_budget_s` seconds, so that the default bench run stays within minutes on a
     128-thread host where the restatement's many small torch ops are oversubscribed.  median / p10 / p90 / min / max;
     value scaled by voxels/150000."""
+    import oracle.criterion_ref as OC
     import oracle.mask3d_ref as OM
     from oracle import sparse_ref as R
     from unscene3d_amd.config import apply_overrides, default_config, instantiate_model
     from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
-    from unscene3d_amd.models.criterion import SetCriterion
-    from unscene3d_amd.models.matcher import HungarianMatcher
 
     cfg = apply_overrides(default_config(), ["general.num_targets=3"])
     sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=sample_voxels, seed=2999)[0]
     torch.manual_seed(1234)
     sd0 = {k: v.detach().clone() for k, v in instantiate_model(cfg).state_dict().items()}
     m = cfg.matcher
-    matcher = HungarianMatcher(m.cost_class, m.cost_mask, m.cost_dice, m.cost_noise_robust, m.num_points)
     wd = {"loss_ce": 2.0, "loss_mask": 5.0, "loss_dice": 2.0, "loss_noise_robust": 0.0}
     wd.update({f"{k}_{i}": v for i in range(12) for k, v in list(wd.items())})
-    crit = SetCriterion(3, matcher, wd, 0.1, ["labels", "masks"], -1, 3.0, 0.75, -1)
 
     def one_pass():
         sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd0.items()}
@@ -340,7 +410,8 @@ def cpu_baseline_mask3d(sample_voxels, runs=10, warmup=3, leg_budget_s=25.0):
         feats = torch.from_numpy(feats)
         out = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], [p2s], lambda n: torch.randperm(n),
                                 keep_graph=True)     # gradients reach every parameter, backbone included
-        losses = crit(out, target, "segment_mask")
+        losses = OC.set_criterion(out, target, "segment_mask", num_classes=3, eos_coef=0.1, cost_class=m.cost_class,
+                                  cost_mask=m.cost_mask, cost_dice=m.cost_dice)
         sum(v * wd[k] for k, v in losses.items() if k in wd).backward()
         return time.perf_counter() - t0, coords4.shape[0]
 
@@ -522,6 +593,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if args.rotate else None
+    own = getattr(step, "state", None) if (marks and world > 1) else None
+    if own is not None:
+        own["marks"] = []                  # per step: the point where this rank's backward is queued (before the exchange)
     if marks:
         marks[0].record()
     for k in range(args.steps):
@@ -538,6 +612,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # The same K steps once more with the collate in the REFERENCE's row order (ME.utils.sparse_quantize's
+    # first-occurrence order, datasets/utils.py:403-408): FPS starts at row 0 and key sampling indexes rows, so this is
+    # the order in which the step picks the queries / keys the reference would pick on the same raw scene.
+    ref_order = None
+    if args.mode == "mask3d" and args.spatial_sort and not args.no_reference_order and hasattr(step, "set_spatial_sort"):
+        step.set_spatial_sort(0)
+        for _ in range(max(2, args.warmup)):
+            step(world)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        for k in range(args.steps):
+            step(world)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        rdt = time.perf_counter() - r0
+        if world > 1:
+            t = torch.tensor([rdt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rdt = float(t.item())
+        ref_order = {"value_reference_order": world * getattr(step, "scenes_per_rank", 1) * args.steps / rdt,
+                     "ms_per_step_reference_order": 1e3 * rdt / args.steps}
+        step.set_spatial_sort(args.spatial_sort)
+        step(world)                         # back in the measured configuration for the instrumented step below
+
     # roofline of the dominant kernel: one extra instrumented step (HIP events around every conv launch on
     # the launch stream; not part of the timed region so that event overhead does not pollute `value`)
     # Every rank runs it (the criterion's num_masks all-reduce and the gradient all-reduce are collectives); rank 0
@@ -551,13 +654,7 @@ def main():
         if roof is not None:
             # PMC counters cannot be read from inside the process; `traffic` is the per-launch HBM byte count
             # of the same kernel from the committed rocprofv3 --pmc passes over this very command.
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    ent = json.load(f).get(roof["kernel"])
-                if ent:
-                    roof["traffic"] = ent["bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/pmc_traffic.json"
+            roof.update(_committed_traffic(roof["kernel"]))
 
     ranks_seen = None
     if world > 1:
@@ -570,15 +667,30 @@ def main():
         q = lambda f: per[min(len(per) - 1, int(round(f * (len(per) - 1))))]
         rot = {"rotated_scene_sets": args.rotate, "step_ms_p10": q(0.1), "step_ms_p50": q(0.5), "step_ms_p90": q(0.9),
                "step_ms_min": per[0], "step_ms_max": per[-1]}
+    skew = None
+    if own is not None and len(own["marks"]) == args.steps:
+        # per-rank step-time skew: how long each rank's OWN work of a step took (step start -> backward queued, device
+        # time), all-gathered; max / mean over the ranks of a step = what the gradient exchange makes the others wait
+        mine_ms = torch.tensor([marks[k].elapsed_time(own["marks"][k]) for k in range(args.steps)], device=dev)
+        own["marks"] = None
+        allr = [torch.empty_like(mine_ms) for _ in range(world)]
+        dist.all_gather(allr, mine_ms)
+        tab = torch.stack(allr).cpu().numpy()                                  # [world, steps]
+        ratio = tab.max(0) / tab.mean(0)
+        skew = {**(step.skew_info or {}), "rank_own_work_ms_mean": [float(v) for v in tab.mean(1)],
+                "step_own_work_max_over_mean": {"mean": float(ratio.mean()), "max": float(ratio.max())}}
     if rank == 0:
         line = {
             "metric": "training scenes/sec (Res16UNet34C+Mask3D, 150k voxels)",
             "value": world * spr * args.steps / dt, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, **(ref_order or {}), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.mode].format(nvox=int(nvox) // spr, spr=spr),
                        "voxels_per_scene": int(nvox) // spr, "scenes_per_gpu": spr, "global_batch": world * spr,
-                       "parallelism": f"dp{world}", **(rot or {}),
+                       "parallelism": f"dp{world}", "row_order": (f"z-order cells of {2 ** args.spatial_sort}^3 voxels "
+                                                                   f"(value); first-occurrence (value_reference_order)"
+                                                                   if args.mode == "mask3d" and args.spatial_sort else
+                                                                   "first-occurrence (reference)"), **(rot or {}), **({"rank_skew": skew} if skew else {}),
                        "loss": float(loss), "grad_allreduce": _allreduce_note(step, world),
                        **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,

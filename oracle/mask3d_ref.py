@@ -70,13 +70,17 @@ def _ln(sd, pfx, d, x):
 
 
 def mask3d_forward(sd: dict, cfg, coords4: np.ndarray, feats: torch.Tensor, raw_xyz: torch.Tensor, point2segment,
-                   randperm, dtype=torch.float32, keep_graph=False, attn_hook=None):
+                   randperm, dtype=torch.float32, keep_graph=False, attn_hook=None, is_eval=False):
     """-> dict(pred_logits, pred_masks, aux_outputs) like the reference; sd = device model state_dict.
     keep_graph: `sd` already holds CPU tensors of `dtype` (leaves with requires_grad): they are used as they are, so
     that a backward pass from the criterion fills their .grad (full-step gradient / trajectory parity).
     attn_hook(pass_index, mask bool[B,K,Q]) -> mask: lets a test look at / replace the thresholded attention mask of a
     decoder pass — a DISCRETE decision (sigmoid(mean logit) < 0.5, mask3d.py:432-436) that two fp32 evaluation orders
-    may take differently for logits within rounding of zero."""
+    may take differently for logits within rounding of zero.
+    is_eval: the validation / export forward (trainer/trainer.py:384-396 calls `forward(..., is_eval=True)` on the
+    module in eval()): batch norms use their running statistics and NO key sub-sampling happens — every voxel of a
+    level is a cross-attention key, K = the largest scene's level size (mask3d.py:297-312: `if not (self.max_sample_size
+    or is_eval)` guards the truncation), shorter scenes padded with row 0 and masked."""
     m = cfg.model
     d, Q, H = m.hidden_dim, m.num_queries, m.num_heads
     if not keep_graph:
@@ -84,7 +88,7 @@ def mask3d_forward(sd: dict, cfg, coords4: np.ndarray, feats: torch.Tensor, raw_
     bsd = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
     pyr = RU.Pyramid(coords4)
     layers = (2, 3, 4, 6, 2, 2, 2, 2)
-    pcd, aux = RU.res16unet_forward(bsd, pyr, feats.to(dtype), layers)          # aux = [s16, s8, s4, s2, s1]
+    pcd, aux = RU.res16unet_forward(bsd, pyr, feats.to(dtype), layers, is_eval=is_eval)   # aux = [s16, s8, s4, s2, s1]
 
     batch_of = [torch.as_tensor(c[:, 0].astype(np.int64)) for c in pyr.coords]     # per level
     nb = int(batch_of[0].max()) + 1
@@ -143,7 +147,9 @@ def mask3d_forward(sd: dict, cfg, coords4: np.ndarray, feats: torch.Tensor, raw_
             sizes = [len(r) for r in rows[lvl]]
             if min(sizes) == 1:
                 raise RuntimeError("only a single point gives nans in cross-attention")
-            K = min(max(sizes), m.sample_sizes[hlevel])
+            K = max(sizes)
+            if not (getattr(m, "max_sample_size", False) or is_eval):                 # reference :311-312
+                K = min(K, m.sample_sizes[hlevel])
             ridx, midx = [], []
             for b, n in enumerate(sizes):
                 if n <= K:

@@ -59,7 +59,16 @@ def _tr_conv(x, W, parent, kidx, n_fine):
     return out
 
 
+_EVAL = [False]     # set by res16unet_forward(is_eval=...): MinkowskiBatchNorm in eval() uses its running statistics
+
+
 def _bn(sd, name, x, eps=1e-5):
+    """MinkowskiBatchNorm = nn.BatchNorm1d over all rows of the batch (models/modules/common.py:22).  Training mode:
+    batch statistics; eval mode (`module.eval()`, trainer/trainer.py:384-396 runs under it): the running mean / variance
+    of the state_dict."""
+    if _EVAL[0]:
+        rm, rv = sd[name + ".bn.running_mean"].to(x.dtype), sd[name + ".bn.running_var"].to(x.dtype)
+        return F.batch_norm(x, rm, rv, sd[name + ".bn.weight"], sd[name + ".bn.bias"], training=False, eps=eps)
     return F.batch_norm(x, None, None, sd[name + ".bn.weight"], sd[name + ".bn.bias"], training=True, eps=eps)
 
 
@@ -80,8 +89,16 @@ def _layer(sd, name, x, pyr, level, nblocks):
     return x
 
 
-def res16unet_forward(sd: dict, pyr: Pyramid, feats: torch.Tensor, layers):
-    """-> (stride-1 features, [s16, s8, s4, s2, s1] block outputs)."""
+def res16unet_forward(sd: dict, pyr: Pyramid, feats: torch.Tensor, layers, is_eval: bool = False):
+    """-> (stride-1 features, [s16, s8, s4, s2, s1] block outputs).  is_eval: batch norms use running statistics."""
+    _EVAL[0] = bool(is_eval)
+    try:
+        return _forward(sd, pyr, feats, layers)
+    finally:
+        _EVAL[0] = False
+
+
+def _forward(sd, pyr, feats, layers):
     n0 = feats.shape[0]
     x = torch.relu(_bn(sd, "bn0", _gather_conv(feats, sd["conv0p1s1.kernel"], pyr.cube_map(0), n0)))
     skips = [x]

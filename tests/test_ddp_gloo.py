@@ -117,6 +117,26 @@ def _worker(rank, world, port, out):
         for h in red3._hooks:
             h.remove()
 
+        # 1e. flush(): the flag of the LAST step is looked at too (finish() alone reads it one step later), and the
+        #     message names the step
+        red4 = BucketedGradReducer(nparams, nflat, world, bucket_bytes=600)
+        for it in range(2):
+            net.zero_grad(set_to_none=False)
+            red4.begin_step()
+            net(torch.ones(4, 12)).sum().backward()
+            if it == 1 and rank == 1:
+                red4.on_grad(nparams[-1])
+            red4.finish()
+        try:
+            red4.flush()
+            flushed = False
+        except RuntimeError as err:
+            flushed = "in step 2 of this reducer" in str(err)
+        assert flushed, rank
+        red4.flush()                                   # nothing pending any more
+        for h in red4._hooks:
+            h.remove()
+
         # 2. criterion: num_masks is summed over ranks and divided by the world size
         g = torch.Generator().manual_seed(3)
         T = 2 + 3 * rank                      # 2 targets on rank 0, 5 on rank 1 -> global mean 3.5
@@ -145,3 +165,65 @@ def test_world_size_2_gloo():
     assert set(res) == {0, 1}
     for r in res.values():
         assert all(torch.isfinite(torch.tensor(v)) for v in r.values())
+
+
+def _worker8(rank, world, port, out):
+    """World size 8 (the node the metric is quoted on): ranks report DIFFERENT numbers of gradient writes for some
+    parameters (a rank whose scene is small runs a decoder pass eagerly, another replays a graph), the reducer must
+    still issue the same collectives in the same order everywhere and return the mean of the eight local gradients."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import copy
+
+        from unscene3d_amd.ddp import BucketedGradReducer, flatten_grads
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(*[torch.nn.Linear(10, 10) for _ in range(8)])
+        params = list(net.parameters())
+        flat = flatten_grads(params)
+        twin = copy.deepcopy(net)
+        tflat = flatten_grads(list(twin.parameters()))
+        red = BucketedGradReducer(params, flat, world, bucket_bytes=300)
+        nb = len(red.bounds)
+        assert nb >= 6
+        extra = {1: [params[-1]], 5: [params[-1], params[0]], 6: [params[6]] * 2}.get(rank, [])
+        for it in range(4):
+            net.zero_grad(set_to_none=False)
+            twin.zero_grad(set_to_none=False)
+            red.begin_step()
+            xin = torch.full((3, 10), 0.1 * (rank + 1) + 0.01 * it)
+            twin(xin).square().sum().backward()
+            local = tflat.clone()
+            net(xin).square().sum().backward()
+            for p in extra:
+                red.on_grad(p)                     # additional reports: counts differ between the ranks
+            red.finish()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            want = gathered[0].clone()
+            for g in gathered[1:]:
+                want += g
+            assert torch.allclose(flat, want / world, rtol=1e-6, atol=1e-9), (rank, it)
+        red.flush()
+        divergent = {red.bucket_of[id(p)] for p in (params[-1], params[0], params[6])}
+        assert not (divergent & set(red.order))            # not eligible on ANY rank
+        orders = [None] * world
+        dist.all_gather_object(orders, (red.order, red.expected))
+        assert all(o == orders[0] for o in orders)         # same plan everywhere
+        out[rank] = (len(red.order), nb)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_8_gloo_bucketed_reducer_with_differing_report_counts():
+    world = 8
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker8, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert set(res) == set(range(8))
+    n_order, nb = res[0]
+    assert 0 < n_order < nb                                 # some buckets start early, the divergent ones do not

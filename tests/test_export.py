@@ -89,6 +89,23 @@ def test_export_host_logic_matches_reference(name, monkeypatch):
     _check(results, scenes)
 
 
+@pytest.mark.parametrize("name", CASES)
+def test_export_oracle_matches_reference_golden(name):
+    """oracle/export_ref.py (the checker of the eval-mode tests) pinned by the reference's own eval_instance_step."""
+    from oracle.export_ref import export_instances_ref
+
+    scenes, general = _load(np.load(GOLD), name)
+    t = torch.from_numpy
+    res = export_instances_ref(t(np.stack([s["pred_logits"] for s in scenes])), [t(s["pred_masks"]) for s in scenes],
+                               [t(s["point2segment"]).long() for s in scenes], [t(s["inverse_map"]).long() for s in scenes],
+                               [t(s["point2segment_full"]).long() for s in scenes],
+                               np.concatenate([s["raw_coords"] for s in scenes]), general, num_classes=3, label_offset=2)
+    for r, s in zip(res, scenes):
+        assert np.array_equal(r["pred_masks"], s["out_masks"])
+        np.testing.assert_allclose(r["pred_scores"], s["out_scores"], rtol=2e-5)
+        assert np.array_equal(r["pred_classes"], s["out_classes"])
+
+
 @pytest.mark.parametrize("use_dbscan", [False, True])
 def test_export_with_no_instances(use_dbscan, monkeypatch):
     """Every query mask empty: an empty result, not an exception (the reference's torch.stack raises)."""

@@ -100,23 +100,21 @@ def _setup(device, spatial_sort, overrides=()):
 def _oracle_step(module, cfg, sd, data, target, perm_source, dtype, attn_hook=None, forced_indices=None, info=None):
     """Forward + criterion of the CPU restatement on the leaves `sd` (keep_graph) -> (total, {key: weighted loss}).
     attn_hook / forced_indices: impose the device run's discrete decisions (attention masks, assignments)."""
+    import oracle.criterion_ref as OC
     import oracle.mask3d_ref as OM
-    from unscene3d_amd.models.criterion import SetCriterion
 
     coords4 = data.coordinates.cpu().numpy()
     feats = data.features.cpu()
     p2s = [t["point2segment"].cpu() for t in target]
     out_ref = OM.mask3d_forward(sd, cfg, coords4, feats[:, :3], feats[:, 3:], p2s, perm_source, dtype=dtype,
                                 keep_graph=True, attn_hook=attn_hook)
-    tgt_cpu = [{k: v.cpu() for k, v in t.items()} for t in target]
-    crit_cpu = SetCriterion(num_classes=3, matcher=module.criterion.matcher, weight_dict=module.criterion.weight_dict,
-                            eos_coef=0.1, losses=["labels", "masks"], num_points=-1, oversample_ratio=3.0,
-                            importance_sample_ratio=0.75, class_weights=-1)    # computes in f32 (`.float()`, as the reference)
-    if info is not None:            # the oracle's OWN assignments (before any is imposed)
-        levels = [{k: v for k, v in out_ref.items() if k != "aux_outputs"}] + list(out_ref["aux_outputs"])
-        info["indices"] = crit_cpu.match_all_levels(levels, tgt_cpu, "segment_mask")
-    crit_cpu.forced_indices = forced_indices
-    losses_ref = crit_cpu(out_ref, tgt_cpu, mask_type="segment_mask")
+    tgt_cpu = [{k: v.cpu() for k, v in t.items() if torch.is_tensor(v)} for t in target]
+    m = module.criterion.matcher
+    # the criterion half of the oracle is oracle/criterion_ref.py (independent of the package, pinned by the
+    # reference's criterion.npz); it computes in f32 (`.float()`, as the reference does) whatever `dtype` is upstream
+    losses_ref = OC.set_criterion(out_ref, tgt_cpu, "segment_mask", num_classes=3, eos_coef=0.1,
+                                  cost_class=m.cost_class, cost_mask=m.cost_mask, cost_dice=m.cost_dice,
+                                  forced_indices=forced_indices, info=info)
     wd = module.criterion.weight_dict
     weighted = {k: v * wd[k] for k, v in losses_ref.items() if k in wd}
     return sum(weighted.values()), weighted
@@ -309,8 +307,11 @@ def test_collate_row_permutation_at_full_size(device):
         check_collate(batch, data, target, spatial_sort)
 
 
-def test_full_size_step_matches_the_oracle(device):
-    """The configuration bench.py times — one 150 k-voxel scene, z-order cell collate, the reference's key counts
+@pytest.mark.parametrize("spatial_sort", [5, False])
+def test_full_size_step_matches_the_oracle(device, spatial_sort):
+    """spatial_sort=5: the configuration behind bench.py's `value`; False: the reference's own first-occurrence row
+    order (bench.py's `value_reference_order`) — there FPS and key sampling pick exactly the rows the reference would.
+    The configuration bench.py times — one 150 k-voxel scene, z-order cell collate, the reference's key counts
     (200 / 800 / 3 200 / 12 800 sampled voxels per level, conf/model/mask3d.yaml), the 12 decoder passes replayed from
     captured HIP graphs — against the CPU restatement on the same state_dict and the same sampled indices: the 52
     weighted losses and their total within 1e-3 (north star), the thresholded attention masks of the 12 passes (12 800
@@ -325,7 +326,8 @@ def test_full_size_step_matches_the_oracle(device):
 
     cfg = apply_overrides(default_config(), ["general.num_targets=3", "data.batch_size=1"])
     batch = [SyntheticFreeMaskDataset(n_scenes=1, target_voxels=150_000, seed=2000)[0]]
-    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device), spatial_sort=5)
+    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device),
+                                      spatial_sort=spatial_sort)
     torch.manual_seed(1234)
     module = InstanceSegmentation(cfg).to(device).train()
     flatten_grads([p for n, p in module.named_parameters() if ".backbone.final." not in n])

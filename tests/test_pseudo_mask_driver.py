@@ -79,3 +79,20 @@ def test_scene_list_tool_end_to_end(device, tmp_path, capsys):
             assert (rows == rows[0]).all()
     assert tool.main(["--synthetic", "3", "--out", out]) == 0
     assert "0 of 3 scenes" in capsys.readouterr().out               # everything was skipped
+
+
+@pytest.mark.gpu
+def test_long_run_of_trivial_scenes_does_not_recurse(device):
+    """5 000 scenes that finish on their first step (the < 3-segment early exit of the NCut loop returns at once): the
+    slot hand-over is a loop — the round-3 recursion would have exceeded Python's stack here."""
+    import sys
+
+    from unscene3d_amd.pseudo_masks.driver import PseudoMaskDriver
+
+    def steps(scene):
+        return scene * 2
+        yield                                                   # noqa: a generator that ends before its first yield
+
+    n = max(5000, 2 * sys.getrecursionlimit())
+    out = PseudoMaskDriver(device=device, concurrent=4, scene_steps=steps).run(list(range(n)))
+    assert len(out) == n and out[n - 1] == 2 * (n - 1)

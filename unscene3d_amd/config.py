@@ -20,7 +20,10 @@ def default_config():
     return _ns({
         "general": {"num_targets": num_targets, "train_on_segments": True, "eval_on_segments": True,
                     "ignore_mask_idx": [], "max_batch_size": 99999999, "gpus": 1, "freeze_backbone": False,
-                    "decoder_id": -1, "use_dbscan": False, "dbscan_eps": 0.95, "dbscan_min_points": 1},
+                    "decoder_id": -1, "use_dbscan": False, "dbscan_eps": 0.95, "dbscan_min_points": 1,
+                    # export between self-training rounds (conf/config_base_instance_segmentation.yaml:12-44)
+                    "filter_out_instances": False, "scores_threshold": 0.1, "iou_threshold": 0.66,
+                    "topk_per_image": 100, "save_for_freemask": False, "save_dir": "saved"},
         "data": {"voxel_size": 0.02, "in_channels": 3, "num_labels": 20, "add_raw_coordinates": True,
                  "add_colors": True, "add_normals": False, "ignore_label": 255, "batch_size": 8},
         "model": {"hidden_dim": 128, "dim_feedforward": 1024, "num_queries": 100, "num_heads": 8, "num_decoders": 3,

@@ -479,7 +479,10 @@ __global__ __launch_bounds__(128) void crit_cost_kernel(CritCostArgs a) {
   for (int t = 0; t < TMAX; ++t) {
     if (t < a.T) {
       const int64_t lab = a.labels[t];
-      const float cclass = lab == 253 ? -1.f : -(expf(lg[lab] - mx) / se);
+      // a label outside [0, C) that is not the ignore id: no read past the logits; the NaN cost makes the assignment
+      // report status 1, which the host side raises on (scipy raises ValueError on such a matrix, matcher.py:163)
+      const bool bad = lab != 253 && (lab < 0 || lab >= a.C);
+      const float cclass = lab == 253 ? -1.f : bad ? NAN : -(expf(lg[lab] - mx) / se);
       const float cm = (nsum - xs[t]) / (float)a.S;
       const float cd = 1.f - (2.f * gs[t] + 1.f) / (ssum + (float)a.cnt[t] + 1.f);
       a.cmask[o + t] = cm;
@@ -505,7 +508,8 @@ __global__ __launch_bounds__(128) void crit_loss_kernel(const float* __restrict_
   __syncthreads();
   float num = 0.f, den = 0.f;
   if (q < Q) {
-    const int c = tc[q];
+    int c = tc[q];
+    if (c != 253 && (c < 0 || c >= C)) { c = 253; num = NAN; }     // invalid label: NaN loss, no out-of-range read
     tcls[(int64_t)l * Q + q] = c;
     if (c != 253) {
       const float w = class_w[c];

@@ -132,15 +132,8 @@ class BucketedGradReducer:
         # buckets; instead the value of the step before last is read (its copy finished long ago: waiting for it
         # costs nothing and bounds the host's run-ahead at two steps), at the same step on every rank.
         lag = 1 if self.flat.is_cuda else 0       # host tensors (tests): nothing runs ahead, look at the last step
-        while len(self._late_pending) > lag:
-            ev, host = self._late_pending.pop(0)
-            if ev is not None:
-                ev.synchronize()
-            if float(host[0]) > 0:
-                raise RuntimeError("BucketedGradReducer: on some rank a gradient was written after its bucket's "
-                                   "all-reduce had started (more writes per step than learned in the first step); "
-                                   "the gradients of that step are unreliable — rebuild the reducer or set "
-                                   "USC3D_OVERLAP_ALLREDUCE=0")
+        self._check_late(lag)
+        self._step_no = getattr(self, "_step_no", 0) + 1
         if self.expected is None:
             # agree across ranks: max count, and eligibility only where min == max > 0 on every rank
             cnt = torch.tensor(self.counts, dtype=torch.int64, device=self.flat.device)
@@ -172,7 +165,26 @@ class BucketedGradReducer:
             host.copy_(self._late_flag, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            self._late_pending.append((ev, host))
+            self._late_pending.append((ev, host, self._step_no))
         else:
-            self._late_pending.append((None, self._late_flag.clone()))
+            self._late_pending.append((None, self._late_flag.clone(), self._step_no))
         return self.flat
+
+    def _check_late(self, keep):
+        while len(self._late_pending) > keep:
+            ev, host, step_no = self._late_pending.pop(0)
+            if ev is not None:
+                ev.synchronize()
+            if float(host[0]) > 0:
+                raise RuntimeError(f"BucketedGradReducer: in step {step_no} of this reducer (the current one is "
+                                   f"{getattr(self, '_step_no', 0) + 1}) some rank wrote a gradient after its bucket's "
+                                   "all-reduce had started (more writes per step than learned in the first step); "
+                                   "the gradients of that step — and the optimizer steps since — are unreliable: "
+                                   "restore the last checkpoint, rebuild the reducer or set USC3D_OVERLAP_ALLREDUCE=0")
+
+    def flush(self):
+        """Look at the late-write flags of ALL finished steps, the most recent included (waits for their copies).  Call
+        before writing a checkpoint and at the end of training: `finish()` alone reads the flags with a lag of one
+        step (two on the device), so the flags of the last steps of a run would otherwise never be inspected.
+        Collective-free; every rank holds the same (MAX-reduced) flags, so every rank raises or none does."""
+        self._check_late(0)

@@ -92,6 +92,7 @@ class _FusedCriterion(torch.autograd.Function):
         ctx.scenes, ctx.den_tot, ctx.shape, ctx.class_w = scenes, den_tot, (L, B, Q, NC), crit.empty_weight
         crit.last_indices = [[(sc["src"][l], sc["tid"][l]) for sc in scenes] for l in range(L)]   # device tensors
         crit.last_lsap_status = [sc["status"] for sc in scenes]
+        crit._queue_status_check(crit.last_lsap_status)
         return table.reshape(-1)
 
     @staticmethod
@@ -143,6 +144,60 @@ class SetCriterion(nn.Module):
         self.importance_sample_ratio = importance_sample_ratio
         self.directions = directions
         self.noise_robust_projection_loss = None    # built lazily: only when loss_noise_robust != 0
+
+    # -- assignment status of the device criterion -------------------------------------------
+    # The reference stops a diverged run: scipy's linear_sum_assignment raises ValueError on a cost matrix with NaN /
+    # inf entries (matcher.py:163).  The device solver reports that case as status != 0 and the step carries on with an
+    # identity assignment, so the status words travel to pinned host memory behind the step's kernels (no
+    # synchronisation, like the reducer's late-write flag) and are looked at when the copy has landed: at the next
+    # criterion call, or in `check_lsap_status(wait=True)` (before a checkpoint / at the end of a run).
+    _STATUS_RING = 8
+
+    def _queue_status_check(self, status_tensors):
+        st = [s for s in status_tensors if s is not None and s.is_cuda]
+        if not st:
+            return
+        ring = self.__dict__.setdefault("_status_ring", [])
+        self.__dict__["_status_step"] = step = self.__dict__.get("_status_step", 0) + 1
+        n = sum(int(s.numel()) for s in st)
+        slot = None
+        for e in ring:
+            if e["free"] and e["host"].numel() >= n:
+                slot = e
+                break
+        if slot is None:
+            if len(ring) >= self._STATUS_RING:           # the host is that far ahead: wait for the oldest copy
+                self.check_lsap_status(wait=True)
+                return self._queue_status_check(status_tensors)
+            slot = {"host": torch.empty(max(n, 64), dtype=torch.int32, pin_memory=True), "event": torch.cuda.Event(),
+                    "free": True}
+            ring.append(slot)
+        off = 0
+        for s in st:
+            slot["host"][off:off + s.numel()].copy_(s.reshape(-1), non_blocking=True)
+            off += s.numel()
+        slot.update(free=False, n=n, step=step)
+        slot["event"].record()
+
+    def check_lsap_status(self, wait=False):
+        """Raise ValueError (as scipy does inside the reference's matcher) if an assignment problem of an earlier call
+        was infeasible — NaN / inf costs from diverged logits, or a target label outside [0, num_classes] ∪ {253}.
+        wait=False looks only at copies that have already landed; wait=True blocks for all pending ones."""
+        bad = None
+        for e in self.__dict__.get("_status_ring", []):
+            if e["free"]:
+                continue
+            if wait:
+                e["event"].synchronize()
+            elif not e["event"].query():
+                continue
+            e["free"] = True
+            if bool((e["host"][:e["n"]] != 0).any()) and bad is None:
+                bad = e["step"]
+        if bad is not None:
+            raise ValueError(f"matrix contains invalid numeric entries (assignment costs of criterion call {bad} of this "
+                             f"run were NaN / infinite, or a target label was out of range; the call before the current "
+                             f"one is call {self.__dict__.get('_status_step', 0)})")
 
     # -- individual losses ------------------------------------------------------------------
     def loss_labels(self, outputs, targets, indices, num_masks, mask_type, coords=None):
@@ -323,6 +378,9 @@ class SetCriterion(nn.Module):
             tm = tgt.get(mask_type)
             if tm is None or not tm.is_cuda or not (1 <= tm.shape[0] <= min(32, Q)) or "labels" not in tgt:
                 return None
+            lab = tgt["labels"]
+            if not (torch.is_tensor(lab) and lab.is_cuda and lab.numel() == tm.shape[0]):
+                return None                                  # host labels / wrong count: the operator path handles them
             ld = None
             for lv in levels:
                 t = lv["pred_masks"][b]
@@ -337,6 +395,7 @@ class SetCriterion(nn.Module):
     def forward(self, outputs, targets, mask_type, coords=None):
         final = {k: v for k, v in outputs.items() if k != "aux_outputs"}
         levels = [final] + list(outputs.get("aux_outputs", []))
+        self.check_lsap_status()                             # an earlier call's infeasible assignment -> ValueError
         tables = self._fused_tables(levels, targets, mask_type)
         if tables is not None:
             if is_dist_avail_and_initialized():     # the reference's collective (criterion.py:258-260); its result is

@@ -202,7 +202,11 @@ class Mask3D(nn.Module):
         # the cross-attention key samples of all passes (reference :325 draws them inside the decoder loop; they depend
         # on the level sizes only): ~9 launches each (arange, random keys, sort, de-duplication) taken off the
         # decoder's critical path.  `forward` consumes them ONCE (a second forward over the same maps draws again).
-        geo["key_samples"] = self._draw_key_samples(coords, is_eval)
+        # With random query initialisation (`random_queries` / `random_query_both`) the reference draws the queries
+        # BEFORE the key samples (mask3d.py:285-325): leave the draw to forward(), after its torch.rand / randn, so that a
+        # seeded run consumes the global generator in the reference's order.
+        rng_queries = (not self.non_parametric_queries) and (self.random_queries or self.random_query_both)
+        geo["key_samples"] = None if rng_queries else self._draw_key_samples(coords, is_eval)
         cm.geometry = geo
         return geo
 
@@ -260,7 +264,8 @@ class Mask3D(nn.Module):
 
         geo = getattr(x.coordinate_manager, "geometry", None)
         if geo is None or geo.get("n_levels") != len(aux):
-            geo = self.precompute_geometry(x, raw_coordinates, point2segment, num_segments, n_levels=len(aux))
+            geo = self.precompute_geometry(x, raw_coordinates, point2segment, num_segments, n_levels=len(aux),
+                                           is_eval=is_eval)
         coordinates, coords, pos_encodings_pcd = geo["coordinates"], geo["coords"], geo["pos_encodings_pcd"]
 
         mask_features = self.mask_features_head(pcd_features)

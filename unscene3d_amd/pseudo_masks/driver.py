@@ -85,16 +85,21 @@ class PseudoMaskDriver:
         slots = {}                                             # stream slot -> (scene index, generator, pending event)
 
         def advance(slot, i, gen):
-            """Resume scene i on its stream until its next copy event (or its end)."""
+            """Resume scene i on its stream until its next copy event (or its end); a scene that ends hands the slot to
+            the next one of the list.  A loop, not a recursion: a long run of scenes that finish on their first step
+            (fewer than 3 segments return at once) must not grow the Python stack."""
             with torch.cuda.stream(self._streams[slot]):
-                try:
-                    slots[slot] = (i, gen, next(gen))
-                except StopIteration as done:
-                    out[i] = done.value
-                    slots.pop(slot, None)
-                    if todo:
-                        j = todo.pop(0)
-                        advance(slot, j, self.scene_steps(scenes[j], **kw))
+                while True:
+                    try:
+                        slots[slot] = (i, gen, next(gen))
+                        return
+                    except StopIteration as done:
+                        out[i] = done.value
+                        slots.pop(slot, None)
+                        if not todo:
+                            return
+                        i = todo.pop(0)
+                        gen = self.scene_steps(scenes[i], **kw)
 
         for slot in range(min(self.concurrent, len(todo))):
             j = todo.pop(0)

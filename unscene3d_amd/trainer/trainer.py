@@ -89,6 +89,49 @@ class InstanceSegmentation(nn.Module):
         # the reference's python sum() adds in key order; torch.sum uses a tree: equal to fp32 round-off (1e-7)
         return wv.sum(), dict(zip(keys, wv.unbind(0)))
 
+    @torch.no_grad()
+    def eval_step(self, batch, batch_idx=0, label_offset=0):
+        """Validation / export step (reference trainer/trainer.py:367-443): `forward(..., is_eval=True)` — no key
+        sub-sampling (models/mask3d.py:311-312), batch norms on their running statistics when the module is in
+        eval() — the weighted validation losses, and the prediction half of `eval_instance_step` (:479-651) on the
+        device (trainer/postprocess.py).  Between self-training rounds this runs over every train + val scene to export
+        the next round's masks (`general.save_for_freemask`, :743-760).
+        -> None (skipped scene), or {"losses": {val_<k>: float}, "instances": [per scene dict]}."""
+        from .postprocess import export_instances, save_for_freemask
+        data, target, file_names = batch
+        if len(target) == 0 or data.features.shape[0] == 0:
+            return None
+        feats, raw_coordinates = data.features, None
+        if self.config.data.add_raw_coordinates:
+            raw_coordinates = feats[:, -3:].contiguous()
+            feats = feats[:, :-3].contiguous()
+        dev = next(self.parameters()).device
+        x = ME.SparseTensor(coordinates=data.coordinates, features=feats, device=dev)
+        try:
+            ns = [t.get("num_segments") for t in target]
+            output = self.forward(x, point2segment=[t["point2segment"] for t in target],
+                                  raw_coordinates=raw_coordinates, is_eval=True,
+                                  num_segments=None if any(n is None or n.is_cuda for n in ns) else ns)
+        except RuntimeError as err:
+            if err.args and err.args[0] == SINGLE_POINT_ERROR:
+                return None
+            raise
+        losses = self.criterion(output, target, mask_type=self.mask_type, coords=x.C)
+        wd = self.criterion.weight_dict
+        keys = [k for k in losses if k in wd]
+        host = torch.stack([losses[k].detach() for k in keys]).cpu().tolist()           # one read-back, not 52
+        val = {f"val_{k}": v * wd[k] for k, v in zip(keys, host)}                       # :410-416, :441
+        g = self.config.general
+        instances = export_instances(output, target, data.target_full, data.inverse_maps, raw_coordinates, g,
+                                     num_classes=self.model.num_classes, decoder_id=g.decoder_id,
+                                     train_on_segments=self.model.train_on_segments,
+                                     eval_on_segments=g.eval_on_segments, label_offset=label_offset,
+                                     full_res_coords=data.full_res_coords)
+        if getattr(g, "save_for_freemask", False):
+            for name, coords, inst in zip(file_names, data.full_res_coords, instances):
+                save_for_freemask(g.save_dir, name, coords, inst["pred_masks"])
+        return {"losses": val, "instances": instances, "output": output}
+
     def configure_optimizers(self, steps_per_epoch: int, epochs: int = None):
         o = self.config.optimizer
         optimizer = torch.optim.AdamW(self.parameters(), lr=o.lr)
