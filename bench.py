@@ -198,7 +198,8 @@ def make_mask3d_step(args, dev, rank, world):
     if not args.no_prefetch:
         from unscene3d_amd.datasets.prefetch import ScenePrefetcher
         prefetch = ScenePrefetcher(collate, add_raw_coordinates=cfg.data.add_raw_coordinates, device=dev,
-                                   precompute=module.model.precompute_geometry)
+                                   precompute=module.model.precompute_geometry,
+                                   threaded=os.environ.get("USC3D_PREFETCH_THREAD", "1") == "1")
         prefetch.submit(sets[0])       # the first batch, outside the timed region like the resident raw arrays
     state = {"k": 0, "marks": None}
 
@@ -239,6 +240,7 @@ def make_mask3d_step(args, dev, rank, world):
             prefetch.submit(sets[state["k"] % n_sets])
 
     step.set_spatial_sort = set_spatial_sort
+    step.close = (lambda: prefetch.close()) if prefetch is not None else (lambda: None)
     step.scenes_per_rank = B
     step.skew_info = skew_info
     step.state = state
@@ -697,6 +699,8 @@ def main():
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),
         }
         print(json.dumps(line))
+    if hasattr(step, "close"):
+        step.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -98,3 +98,43 @@ def test_fused_criterion_matches_the_reference_golden(device):
     for b in range(2):
         assert np.array_equal(crit.last_indices[0][b][0].cpu().numpy(), z[f"match_q_{b}"])
         assert np.array_equal(crit.last_indices[0][b][1].cpu().numpy(), z[f"match_t_{b}"])
+
+
+@pytest.mark.parametrize("fault", ["nan_logit", "inf_mask", "label_out_of_range", "label_negative"])
+def test_infeasible_assignment_raises_like_scipy(device, fault):
+    """The reference stops a diverged run: scipy.optimize.linear_sum_assignment raises ValueError on NaN / inf costs
+    (models/matcher.py:163).  The device solver reports status != 0 and the call itself carries on (identity
+    assignment, no host wait); the status travels through pinned memory and the ValueError surfaces at the next
+    criterion call or at check_lsap_status(wait=True).  An out-of-range target label takes the same route (it turns its
+    cost column into NaN) instead of reading past the class logits."""
+    crit, logits, tables, targets, wd = _case(device, 2, [300, 500], [5, 7], seed=9)
+    with torch.no_grad():
+        if fault == "nan_logit":
+            logits[4][1, 17, 0] = float("nan")
+        elif fault == "inf_mask":
+            tables[2][0][0, 3] = float("inf")          # row 0 is in every target: inf - inf = NaN, as in the reference
+        elif fault == "label_out_of_range":
+            targets[1]["labels"][2] = 7
+        else:
+            targets[0]["labels"][0] = -1
+    crit.check_lsap_status(wait=True)                                   # nothing pending
+    losses = crit(_outputs(logits, tables, 100, attach=True), targets, mask_type="segment_mask")   # does not raise itself
+    assert getattr(losses, "flat", None) is not None
+    with pytest.raises(ValueError, match="invalid numeric entries"):
+        crit.check_lsap_status(wait=True)
+    crit.check_lsap_status(wait=True)                                   # reported once
+    # a healthy call afterwards is clean, and a pending fault surfaces at the NEXT call without an explicit check
+    good = _case(device, 2, [300, 500], [5, 7], seed=10)
+    crit(_outputs(good[1], good[2], 100, attach=True), good[3], mask_type="segment_mask")
+    crit.check_lsap_status(wait=True)
+    crit(_outputs(logits, tables, 100, attach=True), targets, mask_type="segment_mask")
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError):
+        crit(_outputs(good[1], good[2], 100, attach=True), good[3], mask_type="segment_mask")
+
+
+def test_host_labels_take_the_operator_path(device):
+    """`labels` on the host (or of the wrong length) are not dereferenced by the kernels: the operator path runs."""
+    crit, logits, tables, targets, wd = _case(device, 1, [200], [4], seed=3)
+    targets[0]["labels"] = targets[0]["labels"].cpu()
+    assert crit._fused_tables([{"pred_logits": logits[0], "pred_masks": [tables[0][0]]}], targets, "segment_mask") is None

@@ -147,7 +147,7 @@ def test_config3_full_mask3d_step_loss_and_gradient_parity(device, spatial_sort)
     indices: collate bit-exact up to the stated permutation, losses < 1e-3, gradients of every parameter.
 
     Two things make a naive "every gradient within 1e-3 of the oracle" check meaningless for this network, both
-    measured on this very case (tools/scratch/r03/grad_diag2.py, grad_bisect.py):
+    measured on this very case (round-3 diagnosis scripts, git history: tools/scratch/r03/grad_diag2.py, grad_bisect.py):
     * DISCRETE decisions — the attention masks `sigmoid(mean logit) < 0.5` of the 12 decoder passes (reference
       models/mask3d.py:432-436) and the 13 x B assignments.  The test checks them against the oracle's own (masks:
       < 1e-4 of the bits differ; assignments: at most a few tied problems) and then imposes the device's on the oracle,

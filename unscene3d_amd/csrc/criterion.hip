@@ -119,12 +119,17 @@ __global__ __launch_bounds__(64) void lsap_reg_kernel(const float* __restrict__ 
 #pragma unroll
   for (int c = 0; c < NCL; ++c) { v[c] = 0.0; spc[c] = INFINITY; r4c[c] = -1; path[c] = -1; pos[c] = -1; sc[c] = false; }
   for (int e = lane; e < nr; e += 64) { u[e] = 0.0; col4row[e] = -1; }
+  // scipy rejects a matrix with a NaN or -inf entry up front ("matrix contains invalid numeric entries"), wherever it
+  // sits; the search below would simply never pick such an entry
+  bool invalid = false;
   for (int e = lane; e < nr * nc; e += 64) {
     const int i = e / nc, j = e - i * nc;
-    cm[e] = tr ? cost[(int64_t)j * nc0 + i] : cost[(int64_t)i * nc0 + j];
+    const float x = tr ? cost[(int64_t)j * nc0 + i] : cost[(int64_t)i * nc0 + j];
+    invalid |= (x != x) || x == -INFINITY;
+    cm[e] = x;
   }
   __syncthreads();
-  bool infeasible = false;
+  bool infeasible = __ballot(invalid) != 0ull;
   for (int cur = 0; cur < nr && !infeasible; ++cur) {
     double minVal = 0.0;
     int num = nc;
@@ -253,6 +258,8 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
 
   for (int e = lane; e < nr; e += 64) { u[e] = 0.0; col4row[e] = -1; }
   for (int e = lane; e < nc; e += 64) { v[e] = 0.0; row4col[e] = -1; path[e] = -1; }
+  bool invalid = false;                                    // NaN / -inf anywhere: scipy's "invalid numeric entries"
+  for (int e = lane; e < nr0 * nc0; e += 64) { const float x = cost[e]; invalid |= (x != x) || x == -INFINITY; }
   if (stage) {
     for (int e = lane; e < nr * nc; e += 64) {
       const int i = e / nc, j = e - i * nc;
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(64) void lsap_kernel(const float* __restrict__ cost
     }
   }
   __syncthreads();
-  bool infeasible = false;
+  bool infeasible = __ballot(invalid) != 0ull;
   for (int cur = 0; cur < nr && !infeasible; ++cur) {
     double minVal = 0.0;
     int num = nc;

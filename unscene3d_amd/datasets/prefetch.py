@@ -13,7 +13,11 @@ then keeps a freed block away from the side stream until the compute stream is p
 is kept referenced until the batch after it has been consumed."""
 from __future__ import annotations
 
+import atexit
 import collections
+import queue
+import threading
+import weakref
 
 import torch
 
@@ -54,17 +58,58 @@ class ScenePrefetcher:
     `data.raw_coordinates` attached, ready for `InstanceSegmentation.training_step`."""
 
     def __init__(self, collate, add_raw_coordinates: bool = True, n_down: int = 4, ksize: int = 3, device="cuda",
-                 precompute=None):
+                 precompute=None, threaded: bool = False):
         """precompute: optional `Mask3D.precompute_geometry` (bound method): the parameter-free, geometry-only part
-        of the model's forward pass is then issued here as well."""
+        of the model's forward pass is then issued here as well.
+        threaded: issue the batch from a worker thread (the reference's DataLoader workers, conf/data/indoor.yaml:24).
+        The ~6 ms of host time a 150 k-voxel batch takes to issue — about a third of it blocked in the count read-backs
+        of the voxel unique / coordinate maps, which release the interpreter lock — then overlap with the main thread
+        issuing the step instead of extending it; submit() returns at once, take() joins."""
         self.collate, self.add_raw, self.n_down, self.ksize = collate, add_raw_coordinates, n_down, ksize
         self.precompute = precompute
         self.device = torch.device(device)
         self.side = torch.cuda.Stream(device=self.device)
         self._pending = None
         self._keep = collections.deque(maxlen=2)
+        self._jobs = self._worker = None
+        if threaded:
+            self._jobs = queue.Queue()
+            self._worker = threading.Thread(target=self._serve, name="usc3d-scene-prefetch", daemon=True)
+            self._worker.start()
+            # a daemon thread still inside the runtime when the interpreter tears down aborts the process
+            # ("terminate called without an active exception"): stop it first
+            ref = weakref.ref(self)
+            atexit.register(lambda: ref() is not None and ref().close())
+
+    def _serve(self):
+        torch.cuda.set_device(self.device)
+        while True:
+            job = self._jobs.get()
+            if job is None:
+                return
+            samples, box = job
+            try:
+                box["result"] = self._issue(samples)
+            except BaseException as err:                     # handed to the thread that calls take()
+                box["error"] = err
+            box["done"].set()
+
+    def close(self):
+        """Stop the worker thread (pending work is finished first); submit() falls back to the calling thread."""
+        worker, self._worker = self._worker, None
+        if worker is not None:
+            self._jobs.put(None)
+            worker.join(timeout=30)
 
     def submit(self, samples):
+        if self._worker is not None:
+            box = {"done": threading.Event()}
+            self._jobs.put((samples, box))
+            self._pending = box
+            return
+        self._pending = self._issue(samples)
+
+    def _issue(self, samples):
         with torch.cuda.stream(self.side):
             data, target, names = self.collate(samples)
             feats, raw = data.features, None
@@ -80,13 +125,18 @@ class ScenePrefetcher:
             data.sparse_tensor, data.raw_coordinates = x, raw
             done = torch.cuda.Event()
             done.record(self.side)
-        self._pending = ((data, target, names), done)
+        return (data, target, names), done
 
     def take(self):
         if self._pending is None:
             raise RuntimeError("ScenePrefetcher.take() without a submit()")
-        batch, done = self._pending
-        self._pending = None
+        pending, self._pending = self._pending, None
+        if isinstance(pending, dict):                        # issued by the worker thread
+            pending["done"].wait()
+            if "error" in pending:
+                raise pending["error"]
+            pending = pending["result"]
+        batch, done = pending
         main = torch.cuda.current_stream(self.device)
         main.wait_event(done)
         _record_streams(batch, main, set())

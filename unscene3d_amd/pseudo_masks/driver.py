@@ -101,7 +101,9 @@ class PseudoMaskDriver:
                         i = todo.pop(0)
                         gen = self.scene_steps(scenes[i], **kw)
 
-        for slot in range(min(self.concurrent, len(todo))):
+        for slot in range(self.concurrent):
+            if not todo:                                       # (advance() itself takes further scenes off the list)
+                break
             j = todo.pop(0)
             advance(slot, j, self.scene_steps(scenes[j], **kw))
         while slots:
