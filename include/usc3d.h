@@ -229,6 +229,19 @@ int64_t usc_spconv_wgrad_table_ws_bytes(int32_t K, int32_t cin, int32_t cout);
 int usc_spconv_wgrad_table(const float* in, int32_t cin, const float* dy, int32_t cout, const int32_t* nbr, int32_t K,
                            int64_t n_out, float* dW, int32_t accumulate, void* ws, int64_t ws_bytes, usc_stream_t s);
 
+/* GROUPED weight gradient: R problems of one shape on one kernel map — the conv1 / conv2 weight gradients of a level's
+ * residual blocks (reference models/modules/resnet_block.py:48-64 builds them, autograd differentiates them one by
+ * one; models/res16unet.py LAYERS = 2..6 same-shape blocks per level) — in ONE grid: dW[r][k] (+)= sum_p a[r][a_idx[p]]^T
+ * b[r][b_idx[p]].  a / b / dW: HOST arrays of R device pointers (copied into the launch; R <= usc_spconv_wgrad_group_max()).
+ * No pair split and no reduction launch: every (problem, offset, channel tile) workgroup walks its whole pair list and
+ * writes (accumulate = 1: adds into) dW[r][k] itself, in a fixed order.  usc_spconv_wgrad_group_ok: whether the grouped
+ * form applies (channel pair covered, >= 256 workgroups, <= 2 048 pairs per offset: the coarse levels). */
+int32_t usc_spconv_wgrad_group_max(void);
+int usc_spconv_wgrad_group_ok(int32_t R, int32_t cin, int32_t cout, int32_t K, int64_t n_rows);
+int usc_spconv_wgrad_group(int32_t R, const float* const* a, const float* const* b, float* const* dW, int32_t cin,
+                           int32_t cout, int32_t K, const int32_t* a_idx, const int32_t* b_idx, const int64_t* koff,
+                           int64_t n_rows, int32_t accumulate, usc_stream_t s);
+
 /* ------------------------------------------------------------------------
  * Native issue path: whole convolutions and "conv -> batch norm (+ residual)
  * (+ ReLU)" units behind ONE call each way — the operator granularity of
@@ -336,6 +349,55 @@ int usc_conv_bn_act_backward(const usc_kmap* m, int32_t kind, const float* x,
                              int32_t dW_accumulate, float* dgamma,
                              float* dbeta, int32_t dbn_accumulate, void* ws,
                              int64_t ws_bytes, usc_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Step programs: the issue loop of a whole network stage behind ONE call.
+ * The reference walks Res16UNetBase.forward (models/res16unet.py:224-297) module by module from the interpreter, and
+ * autograd walks it back; here the caller describes the same walk once as an array of steps — conv+BN units, the
+ * channel concatenation of a skip connection (`me.cat`, :259-289), and for the way back the units' backward calls, the
+ * column split of a concatenation's gradient and the fan-in adds of tensors with several consumers — and
+ * usc_program_run launches steps [begin, end) in order on the stream.  Every pointer is a device pointer owned by the
+ * caller (activations, gradients and scratch live in the caller's arenas for as long as the steps need them); the
+ * library allocates nothing and keeps nothing: deferred weight gradients (defer_wgrad != 0, see
+ * usc_spconv_wgrad_group) are queued inside one call only and flushed before it returns.
+ *   USC_STEP_UNIT_FWD : usc_conv_bn_act_forward(map, kind, x, cin, W, cout, bn, residual, relu, y, stats, out)
+ *   USC_STEP_UNIT_BWD : usc_conv_bn_act_backward(map, kind, x, cin, W, cout, bn, y, stats, out (NULL: no ReLU),
+ *                       dout, dy, dres, dx, dx_accumulate, dW, dW_accumulate, dgamma, dbeta, dbn_accumulate)
+ *   USC_STEP_CAT      : dst[n, ca + cb] = [a[n, ca] | b[n, cb]]
+ *   USC_STEP_SPLIT    : dst[n, ca] = a[:, :ca];  dst2[n, cb] (+= when accumulate) a[:, ca:ca + cb]   (a is [n, ca + cb])
+ *   USC_STEP_ADD      : dst[0 .. n) += a[0 .. n)   (n counts floats)
+ * ---------------------------------------------------------------------- */
+enum usc_step_op { USC_STEP_UNIT_FWD = 0, USC_STEP_UNIT_BWD = 1, USC_STEP_CAT = 2, USC_STEP_SPLIT = 3, USC_STEP_ADD = 4 };
+typedef struct usc_step {
+  int32_t op, kind, cin, cout, relu;
+  int32_t dx_accumulate, dW_accumulate, dbn_accumulate, defer_wgrad, accumulate;
+  const usc_kmap* map;
+  const usc_bn* bn;
+  const float* x;
+  const float* W;
+  const float* residual;
+  float* y;
+  float* stats;
+  float* out;
+  const float* dout;
+  float* dy;
+  float* dres;
+  float* dx;
+  float* dW;
+  float* dgamma;
+  float* dbeta;
+  const float* a;
+  const float* b;
+  float* dst;
+  float* dst2;
+  int64_t n;
+  int32_t ca, cb;
+} usc_step;
+/* sizeof(usc_step) as the library was compiled: a binding checks its own mirror of the structure against it. */
+int32_t usc_step_size(void);
+/* Scratch bytes that cover every step of the program (the steps run one after the other on one stream). */
+int64_t usc_program_ws_bytes(const usc_step* steps, int32_t n_steps);
+int usc_program_run(const usc_step* steps, int32_t begin, int32_t end, void* ws, int64_t ws_bytes, usc_stream_t s);
 
 /* ------------------------------------------------------------------------
  * B  row-wise batch norm / ReLU / residual — replaces [ME] MinkowskiBatchNorm

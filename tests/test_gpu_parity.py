@@ -1544,3 +1544,82 @@ def test_gather_rows_backward_unique_and_atomic_paths_agree(device, c):
     s = src.to(device).requires_grad_(True)
     ops.gather_rows(s, dup.to(device)).backward(torch.ones(200, c, device=device))
     assert float(s.grad[idx[:100].to(device)].min()) == 2.0 and float(s.grad.sum()) == 200.0 * c
+
+
+@pytest.mark.parametrize("n,extent,cin,cout,R_", [(500, 5, 256, 256, 11), (2200, 9, 128, 128, 7), (2200, 9, 256, 256, 3),
+                                                  (700, 6, 64, 64, 5), (37, 3, 32, 32, 16), (2200, 9, 96, 96, 4)])
+def test_grouped_weight_gradient(device, n, extent, cin, cout, R_):
+    """usc_spconv_wgrad_group — R same-shape weight gradients on one kernel map in one grid — against the oracle's
+    autograd (dW of R.conv_gather, f64) and against R single launches of usc_spconv_wgrad; accumulation into existing
+    gradient buffers; the result is bit-reproducible (fixed order, no atomics)."""
+    from unscene3d_amd import ops
+
+    c, cmap = _maps(device, seed=n + cin + R_, n=n, extent=extent)
+    N = len(c)
+    nbr = ops.kernel_map_cube(cmap, 3)
+    rb = ops.rulebook_compact(nbr)
+    enbr = R.kernel_map_cube(c, 1)
+    g = torch.Generator().manual_seed(n + cout)
+    xs = [torch.randn(N, cin, generator=g) for _ in range(R_)]
+    dys = [torch.randn(N, cout, generator=g) for _ in range(R_)]
+    base = [torch.randn(27, cin, cout, generator=g) for _ in range(R_)]
+    into = [_dev(b, device) for b in base]
+    ops.wgrad_group([_dev(x, device) for x in xs], [_dev(d, device) for d in dys], into, 27, rb.in_idx, rb.out_idx, rb.koff)
+    again = [_dev(b, device) for b in base]
+    ops.wgrad_group([_dev(x, device) for x in xs], [_dev(d, device) for d in dys], again, 27, rb.in_idx, rb.out_idx, rb.koff)
+    for r in range(R_):
+        assert torch.equal(into[r], again[r])                                     # deterministic
+        single = ops.wgrad(_dev(xs[r], device), _dev(dys[r], device), 27, rb.in_idx, rb.out_idx, rb.koff)
+        assert rel_err(into[r] - _dev(base[r], device), single) < 1e-5
+        if r in (0, R_ - 1):                                                      # the oracle (f64) on the first and last
+            W = torch.zeros(27, cin, cout, dtype=torch.float64, requires_grad=True)
+            R.conv_gather(xs[r].double(), W, enbr, N).backward(dys[r].double())
+            assert rel_err((into[r] - _dev(base[r], device)).cpu(), W.grad) < 1e-5
+    with pytest.raises(RuntimeError):
+        ops.wgrad_group([], [], [], 27, rb.in_idx, rb.out_idx, rb.koff)
+
+
+def test_deferred_weight_gradients_equal_the_immediate_ones(device, monkeypatch):
+    """Res16UNet34C on a 20 k-voxel scene, gradient buffers allocated (the trainer's configuration): with the
+    weight gradients of the coarse levels queued and issued as grouped launches (units.GROUP_WGRAD) every parameter
+    gradient equals the immediate path's to rounding, nothing is left in the queue after backward, and a second
+    backward pass gives the same bits (no stale queue state)."""
+    from types import SimpleNamespace
+
+    from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd import units
+    from unscene3d_amd.models.res16unet import Res16UNet34C
+    from unscene3d_amd.synthetic import make_scene
+
+    sc = make_scene(2101, target_voxels=20_000, tol=0.05)
+    ec = R.voxel_floor(sc["xyz"], 0.02)
+    eu, _ = R.sparse_quantize(ec)
+    coords4, feats = R.sparse_collate([ec[eu]], [sc["colors"][eu]])
+    torch.manual_seed(12)
+    cfg = SimpleNamespace(bn_momentum=0.02, conv1_kernel_size=3, dilations=[1, 1, 1, 1])
+    model = Res16UNet34C(3, 20, cfg, out_fpn=True).to(device).train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    calls = []
+    real = units.lib.usc_spconv_wgrad_group
+
+    def counting(R_, *a):
+        calls.append(int(R_))
+        return real(R_, *a)
+
+    res = {}
+    for mode in (False, True, "again"):
+        monkeypatch.setattr(units, "GROUP_WGRAD", bool(mode))
+        monkeypatch.setattr(units.lib, "usc_spconv_wgrad_group", counting)
+        model.load_state_dict(state)
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        x = ME.SparseTensor(features=_dev(feats, device), coordinates=_dev(coords4, device), device=device)
+        out, fmaps = model(x)
+        (out.F.square().mean() + sum(f.F.square().mean() for f in fmaps[:-1])).backward()
+        assert all(not q.items for q in units._WGQ.values())
+        res[mode] = {n: p.grad.clone() for n, p in model.named_parameters() if not n.startswith("final.")}
+    assert len(calls) >= 4 and max(calls) >= 5, calls                 # grouped launches really happened
+    worst = max((rel_err(res[True][n], res[False][n]), n) for n in res[False])
+    assert worst[0] < 1e-5, worst
+    for n in res[True]:
+        assert torch.equal(res[True][n], res["again"][n]), n

@@ -40,6 +40,20 @@ class BNDesc(C.Structure):
 _kp = C.POINTER(KMap)
 _bp = C.POINTER(BNDesc)
 
+
+class Step(C.Structure):
+    """usc_step (include/usc3d.h): one step of a step program (usc_program_run)."""
+    _fields_ = [("op", _i32), ("kind", _i32), ("cin", _i32), ("cout", _i32), ("relu", _i32),
+                ("dx_accumulate", _i32), ("dW_accumulate", _i32), ("dbn_accumulate", _i32), ("defer_wgrad", _i32),
+                ("accumulate", _i32),
+                ("map", _kp), ("bn", _bp), ("x", _p), ("W", _p), ("residual", _p), ("y", _p), ("stats", _p), ("out", _p),
+                ("dout", _p), ("dy", _p), ("dres", _p), ("dx", _p), ("dW", _p), ("dgamma", _p), ("dbeta", _p),
+                ("a", _p), ("b", _p), ("dst", _p), ("dst2", _p), ("n", _i64), ("ca", _i32), ("cb", _i32)]
+
+
+_sp = C.POINTER(Step)
+STEP_UNIT_FWD, STEP_UNIT_BWD, STEP_CAT, STEP_SPLIT, STEP_ADD = 0, 1, 2, 3, 4
+
 # name -> (restype, [argtypes])   — mirrors include/usc3d.h one to one
 SIGNATURES = {
     "usc_last_error": (C.c_char_p, []),
@@ -66,6 +80,12 @@ SIGNATURES = {
     "usc_spconv_wgrad_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p, _i64, _p]),
     "usc_spconv_wgrad_ws_bytes_rows": (_i64, [_i32, _i32, _i32, _i64]),
+    "usc_step_size": (_i32, []),
+    "usc_program_ws_bytes": (_i64, [_sp, _i32]),
+    "usc_program_run": (C.c_int, [_sp, _i32, _i32, _p, _i64, _p]),
+    "usc_spconv_wgrad_group_max": (_i32, []),
+    "usc_spconv_wgrad_group_ok": (C.c_int, [_i32, _i32, _i32, _i32, _i64]),
+    "usc_spconv_wgrad_group": (C.c_int, [_i32, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _i64, _i32, _p]),
     "usc_spconv_wgrad_table_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_spconv_wgrad_table": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _i64, _p, _i32, _p, _i64, _p]),
     "usc_set_side_stream": (C.c_int, [_p]),
@@ -177,6 +197,9 @@ def _load():
 
 
 lib = _load()
+if lib.usc_step_size() != C.sizeof(Step):
+    raise ImportError(f"unscene3d_amd._lib.Step ({C.sizeof(Step)} bytes) does not mirror usc_step "
+                      f"({lib.usc_step_size()} bytes): rebuild the library or fix the binding")
 
 
 def last_error() -> str:

@@ -824,13 +824,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 // vector loads (A: a[in][ci0 + CT*i ..+CT), B: b[out][co0 + NB*i ..+NB)) for CT*NB MFMAs.  The older kernel gave every
 // 32-channel input tile its own workgroup: each pair's 384-byte b row was gathered Cin/32 times, with 12-byte
 // stride-12 loads.  Cross-wave reduction through one LDS tile in three ordered rounds (deterministic).
+// GROUPED form (g.R > 0): R problems of ONE shape on ONE kernel map — the weight gradients of a level's residual
+// blocks — share the grid: blockIdx.x = (r, k, s).  On the coarse levels a single problem fills a fraction of the chip
+// (216 workgroups for 256 -> 256 on 507 rows) and needs a pair split with its reduction launch to reach that; R of
+// them in one grid need neither.  Same per-element arithmetic as the single form at the same S.
+constexpr int kMaxWgradGroup = 16;
+struct WgradGroup { const float* a[kMaxWgradGroup]; const float* b[kMaxWgradGroup]; float* dW[kMaxWgradGroup]; int R; };
+
 template <int CT, int NB>
-__global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p) {
+__global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p, WgradGroup g) {
   extern __shared__ float red[];  // [4 waves][NB*16 regs][64 lanes]
   constexpr int NA = CT * NB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int k = blockIdx.x / p.S, s = blockIdx.x % p.S;
+  int bx = blockIdx.x;
+  if (g.R > 0) {
+    const int per = p.K * p.S, r = bx / per;
+    bx -= r * per;
+    p.a = g.a[r]; p.b = g.b[r]; p.direct = g.dW[r];
+  }
+  const int k = bx / p.S, s = bx % p.S;
   const int ci0 = blockIdx.y * (32 * CT), co0 = blockIdx.z * (NB * 32);
   const int cin = p.cin, cout = p.cout;
   int64_t pb, pe;
@@ -1403,7 +1416,7 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
 #define USC_WF(C, N) if (CT == C && NBf == N) { \
       static bool attr_set = false; auto kfn = wgrad_full_kernel<C, N>; \
       if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; } \
-      hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p); }
+      hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p, WgradGroup{}); }
     USC_WF(3, 3) USC_WF(2, 3) USC_WF(1, 3) USC_WF(2, 4) USC_WF(1, 4) USC_WF(4, 2) USC_WF(3, 2) USC_WF(2, 2) USC_WF(1, 2) USC_WF(4, 1) USC_WF(3, 1) USC_WF(2, 1) USC_WF(1, 1)
 #undef USC_WF
     if (S > 1)
@@ -1433,6 +1446,55 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, S, numel,
                      (int)accumulate, dW);
   USC_CHECK_LAUNCH("usc_spconv_wgrad");
+  return USC_OK;
+}
+
+int32_t usc_spconv_wgrad_group_max(void) { return kMaxWgradGroup; }
+
+int usc_spconv_wgrad_group_ok(int32_t R, int32_t cin, int32_t cout, int32_t K, int64_t n_rows) {
+  // the grouped form covers what wgrad_full_kernel covers, and only where ONE slice per problem fills the chip
+  if (R < 2 || R > kMaxWgradGroup || cin % 32 || cout % 32 || K < 1 || n_rows <= 0) return 0;
+  const int ctiles = cin / 32, cb = cout / 32;
+  const int NBf = wgrad_full_nb(cb);
+  if (NBf == 3 && ctiles % 3 != 0) return 0;
+  const int CT = wgrad_full_ct(ctiles, NBf);
+  const int64_t blocks = (int64_t)R * K * (ctiles / CT) * (cb / NBf);
+  // per workgroup the whole pair list of one offset: bounded so that the longest chain stays short next to the launch
+  return blocks >= 256 && n_rows / K <= 2048 ? 1 : 0;
+}
+
+int usc_spconv_wgrad_group(int32_t R, const float* const* a, const float* const* b, float* const* dW, int32_t cin,
+                           int32_t cout, int32_t K, const int32_t* a_idx, const int32_t* b_idx, const int64_t* koff,
+                           int64_t n_rows, int32_t accumulate, usc_stream_t s) {
+  USC_REQUIRE(R >= 1 && R <= kMaxWgradGroup, "usc_spconv_wgrad_group: 1 <= R <= %d problems per launch", kMaxWgradGroup);
+  USC_REQUIRE(a && b && dW, "usc_spconv_wgrad_group: null pointer table");
+  USC_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 32 && cout % 32 == 0 && K >= 1 && n_rows >= 0,
+              "usc_spconv_wgrad_group: channels must be multiples of 32");
+  USC_REQUIRE((a_idx && b_idx && koff) || (!a_idx && K == 1), "usc_spconv_wgrad_group: pair lists required for K>1");
+  const int ctiles = cin / 32, cb = cout / 32;
+  const int NBf = wgrad_full_nb(cb);
+  USC_REQUIRE(!(NBf == 3 && ctiles % 3 != 0), "usc_spconv_wgrad_group: unsupported channel pair %d -> %d", cin, cout);
+  if (n_rows == 0) return USC_OK;
+  WgradGroup g{};
+  g.R = R;
+  for (int r = 0; r < R; ++r) {
+    USC_REQUIRE(a[r] && b[r] && dW[r], "usc_spconv_wgrad_group: null pointer in problem %d", r);
+    g.a[r] = a[r]; g.b[r] = b[r]; g.dW[r] = dW[r];
+  }
+  WgradParams p{};
+  p.a_idx = a_idx; p.b_idx = b_idx; p.koff = koff; p.n_rows = n_rows; p.cin = cin; p.cout = cout; p.K = K;
+  p.S = 1; p.accumulate = accumulate; p.direct = g.dW[0]; p.a = g.a[0]; p.b = g.b[0];
+  const int CT = wgrad_full_ct(ctiles, NBf);
+  hipStream_t st = as_stream(s);
+  dim3 grid((unsigned)(R * K), (unsigned)(ctiles / CT), (unsigned)(cb / NBf));
+  const size_t lds = (size_t)4 * NBf * 16 * 64 * sizeof(float);
+#define USC_WF(C, N) if (CT == C && NBf == N) { \
+    static bool attr_set = false; auto kfn = wgrad_full_kernel<C, N>; \
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; } \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p, g); }
+  USC_WF(3, 3) USC_WF(2, 3) USC_WF(1, 3) USC_WF(2, 4) USC_WF(1, 4) USC_WF(4, 2) USC_WF(3, 2) USC_WF(2, 2) USC_WF(1, 2) USC_WF(4, 1) USC_WF(3, 1) USC_WF(2, 1) USC_WF(1, 1)
+#undef USC_WF
+  USC_CHECK_LAUNCH("usc_spconv_wgrad_group");
   return USC_OK;
 }
 

@@ -123,6 +123,73 @@ int check_map(const usc_kmap* m, int kind, int cin, int cout, const char* who) {
   return USC_OK;
 }
 
+
+// ---- element-wise steps of a step program ---------------------------------------------------------------------------
+// dst[r][0:ca] = a[r][:], dst[r][ca:ca+cb] = b[r][:]   (float4 lanes; ca, cb multiples of 4)
+__global__ __launch_bounds__(256) void cat_cols_kernel(const float4* __restrict__ a, int ca4, const float4* __restrict__ b,
+                                                      int cb4, float4* __restrict__ dst, int64_t total4) {
+  const int c4 = ca4 + cb4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / c4;
+    const int j = (int)(e - r * c4);
+    dst[e] = j < ca4 ? a[r * ca4 + j] : b[r * cb4 + (j - ca4)];
+  }
+}
+// da[r][:] = src[r][0:ca], db[r][:] (+)= src[r][ca:ca+cb]
+__global__ __launch_bounds__(256) void split_cols_kernel(const float4* __restrict__ src, int ca4, int cb4, float4* __restrict__ da,
+                                                        float4* __restrict__ db, int accumulate, int64_t total4) {
+  const int c4 = ca4 + cb4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / c4;
+    const int j = (int)(e - r * c4);
+    const float4 v = src[e];
+    if (j < ca4) {
+      da[r * ca4 + j] = v;
+    } else {
+      float4* o = db + r * cb4 + (j - ca4);
+      if (accumulate) { const float4 t = *o; *o = make_float4(t.x + v.x, t.y + v.y, t.z + v.z, t.w + v.w); }
+      else *o = v;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) {
+    float4 d = reinterpret_cast<float4*>(dst)[e];
+    const float4 v = reinterpret_cast<const float4*>(src)[e];
+    d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
+    reinterpret_cast<float4*>(dst)[e] = d;
+  }
+  for (int64_t e = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) dst[e] += src[e];
+}
+inline unsigned ew_grid(int64_t work) {
+  int64_t g = ceil_div(work, (int64_t)256 * 4);
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (unsigned)g;
+}
+
+// weight gradients queued during ONE usc_program_run call (same kernel map and shape -> one grouped launch)
+struct DeferredWgrads {
+  const usc_kmap* map = nullptr; int cin = 0, cout = 0, n = 0;
+  const float* a[16]; const float* b[16]; float* dW[16];
+};
+int flush_deferred(DeferredWgrads& q, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  if (q.n == 0) return USC_OK;
+  const usc_kmap* m = q.map;
+  int rc = USC_OK;
+  if (q.n >= 2 && usc_spconv_wgrad_group_ok(q.n, q.cin, q.cout, m->K, m->pair_capacity)) {
+    rc = usc_spconv_wgrad_group(q.n, q.a, q.b, q.dW, q.cin, q.cout, m->K, m->pair_in, m->pair_out, m->koff, m->pair_capacity, 1, s);
+  } else {
+    const int64_t b = usc_spconv_wgrad_ws_bytes_rows(m->K, q.cin, q.cout, m->pair_capacity);
+    if (b > ws_bytes) { set_error("usc_program_run: workspace too small (weight gradient)"); rc = USC_ERR_ARG; }
+    for (int r = 0; r < q.n && !rc; ++r)
+      rc = usc_spconv_wgrad(q.a[r], q.cin, q.b[r], q.cout, m->K, m->pair_in, m->pair_out, m->koff, m->pair_capacity, q.dW[r], 1, ws, b, s);
+  }
+  q.n = 0;
+  q.map = nullptr;
+  return rc;
+}
 }  // namespace
 
 extern "C" {
@@ -381,6 +448,82 @@ int usc_conv_bn_act_backward(const usc_kmap* m, int32_t kind, const float* x, in
   rc = usc_bn_backward_dx(y, dout, out_relu, mean, invstd, bn->gamma, red, red + cout, dy, dres, sh.n_out, cout, s);
   if (rc) return rc;
   return usc_conv_backward(m, kind, x, cin, W, cout, dy, dx, dx_accumulate, dW, dW_accumulate, cur.rest(), cur.left(), s);
+}
+
+int32_t usc_step_size(void) { return (int32_t)sizeof(usc_step); }
+
+int64_t usc_program_ws_bytes(const usc_step* steps, int32_t n_steps) {
+  int64_t need = 256;
+  if (!steps) return need;
+  for (int i = 0; i < n_steps; ++i) {
+    const usc_step& t = steps[i];
+    if ((t.op == USC_STEP_UNIT_FWD || t.op == USC_STEP_UNIT_BWD) && t.map) {
+      const int64_t b = usc_unit_ws_bytes(t.map, t.kind, t.cin, t.cout);
+      if (b > need) need = b;
+    }
+  }
+  return need;
+}
+
+int usc_program_run(const usc_step* steps, int32_t begin, int32_t end, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(steps && begin >= 0 && end >= begin, "usc_program_run: bad step range");
+  hipStream_t st = as_stream(s);
+  DeferredWgrads q;
+  int rc = USC_OK;
+  for (int i = begin; i < end && !rc; ++i) {
+    const usc_step& t = steps[i];
+    switch (t.op) {
+      case USC_STEP_UNIT_FWD:
+        rc = usc_conv_bn_act_forward(t.map, t.kind, t.x, t.cin, t.W, t.cout, t.bn, t.residual, t.relu, t.y, t.stats, t.out,
+                                     ws, ws_bytes, s);
+        break;
+      case USC_STEP_UNIT_BWD: {
+        USC_REQUIRE(t.map, "usc_program_run: step %d has no kernel map", i);
+        const bool defer = t.defer_wgrad && t.dW && t.dW_accumulate && t.kind == USC_CONV_SAME && t.map->K > 1 && t.map->pair_in;
+        if (defer && q.n > 0 && (q.map != t.map || q.cin != t.cin || q.cout != t.cout || q.n == 16)) {
+          rc = flush_deferred(q, ws, ws_bytes, s);
+          if (rc) break;
+        }
+        rc = usc_conv_bn_act_backward(t.map, t.kind, t.x, t.cin, t.W, t.cout, t.bn, t.y, t.stats, t.out, t.dout, t.dy, t.dres,
+                                      t.dx, t.dx_accumulate, defer ? nullptr : t.dW, t.dW_accumulate, t.dgamma, t.dbeta,
+                                      t.dbn_accumulate, ws, ws_bytes, s);
+        if (!rc && defer) {          // x and this step's own dy stay valid until the end of the call (caller's arenas)
+          q.map = t.map; q.cin = t.cin; q.cout = t.cout;
+          q.a[q.n] = t.x; q.b[q.n] = t.dy; q.dW[q.n] = t.dW;
+          ++q.n;
+        }
+        break;
+      }
+      case USC_STEP_CAT: {
+        USC_REQUIRE(t.a && t.b && t.dst && t.ca % 4 == 0 && t.cb % 4 == 0 && t.n >= 0, "usc_program_run: bad cat step %d", i);
+        const int64_t total4 = t.n * ((t.ca + t.cb) / 4);
+        if (total4 > 0)
+          hipLaunchKernelGGL(cat_cols_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, (const float4*)t.a, t.ca / 4,
+                             (const float4*)t.b, t.cb / 4, (float4*)t.dst, total4);
+        break;
+      }
+      case USC_STEP_SPLIT: {
+        USC_REQUIRE(t.a && t.dst && t.dst2 && t.ca % 4 == 0 && t.cb % 4 == 0 && t.n >= 0, "usc_program_run: bad split step %d", i);
+        const int64_t total4 = t.n * ((t.ca + t.cb) / 4);
+        if (total4 > 0)
+          hipLaunchKernelGGL(split_cols_kernel, dim3(ew_grid(total4)), dim3(256), 0, st, (const float4*)t.a, t.ca / 4, t.cb / 4,
+                             (float4*)t.dst, (float4*)t.dst2, (int)t.accumulate, total4);
+        break;
+      }
+      case USC_STEP_ADD:
+        USC_REQUIRE(t.a && t.dst && t.n >= 0, "usc_program_run: bad add step %d", i);
+        if (t.n > 0) hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_grid(t.n / 4 + 1)), dim3(256), 0, st, t.dst, t.a, t.n);
+        break;
+      default:
+        set_error("usc_program_run: unknown step op");
+        rc = USC_ERR_ARG;
+    }
+  }
+  const int rc2 = flush_deferred(q, ws, ws_bytes, s);
+  if (rc) return rc;
+  if (rc2) return rc2;
+  USC_CHECK_LAUNCH("usc_program_run");
+  return USC_OK;
 }
 
 }  // extern "C"

@@ -74,6 +74,15 @@ class Res16UNetBase(ResNetBase):
         # all coordinate / kernel maps of the pyramid first (their host read-backs would otherwise stall the
         # convolution pipeline four times; see CoordinateManager.prepare)
         x.coordinate_manager.prepare(x.tensor_stride[0], n_down=len(self._DOWN), ksize=3)
+        # the whole trunk as one step program each way (one autograd node, two C calls forward + one per stage
+        # backward: unscene3d_amd/program.py) when every piece is the plain form; else module by module below
+        from .. import program
+        lv = program.trunk(self, x)
+        if lv is not None:
+            cm, ts, top = x.coordinate_manager, x._ts(), len(self._DOWN)
+            levels = [ME.SparseTensor(features=f, coordinate_manager=cm,
+                                      coordinate_map_key=ME.CoordinateMapKey(ts << (top - k))) for k, f in enumerate(lv)]
+            return levels[-1], levels
         skip = [ME.conv_bn_act(self.conv0p1s1, self.bn0, x, relu=True)]          # out_p1
         out = skip[0]
         for cname, nname, bname in self._DOWN:

@@ -365,6 +365,29 @@ def wgrad(a, b, K, a_idx=None, b_idx=None, koff=None, into=None, out=None, nbr=N
     return dW
 
 
+def wgrad_group(a_list, b_list, into_list, K, a_idx, b_idx, koff):
+    """R same-shape weight gradients on one kernel map in ONE launch (usc_spconv_wgrad_group):
+    into_list[r][k] += sum_p a_list[r][a_idx[p]]^T b_list[r][b_idx[p]].  The buffers of `into_list` are added into."""
+    import ctypes as C
+    R = len(a_list)
+    if not (R == len(b_list) == len(into_list) and 1 <= R <= lib.usc_spconv_wgrad_group_max()):
+        raise RuntimeError("wgrad_group: between 1 and usc_spconv_wgrad_group_max() problems, three lists of equal length")
+    cin, cout = a_list[0].shape[1], b_list[0].shape[1]
+    for a, b, w in zip(a_list, b_list, into_list):
+        _chk(a, torch.float32, "a")
+        _chk(b, torch.float32, "b")
+        _chk(w, torch.float32, "dW")
+        if a.shape[1] != cin or b.shape[1] != cout or w.numel() != K * cin * cout:
+            raise RuntimeError("wgrad_group: the problems of a group have one shape")
+    n_rows = a_list[0].shape[0] if a_idx is None else int(a_idx.shape[0])
+    pa = (C.c_void_p * R)(*[t.data_ptr() for t in a_list])
+    pb = (C.c_void_p * R)(*[t.data_ptr() for t in b_list])
+    pw = (C.c_void_p * R)(*[t.data_ptr() for t in into_list])
+    check(lib.usc_spconv_wgrad_group(R, pa, pb, pw, cin, cout, K, _ptr(a_idx), _ptr(b_idx), _ptr(koff), n_rows, 1,
+                                     _stream()), "usc_spconv_wgrad_group")
+    return into_list
+
+
 class _ConvSame(torch.autograd.Function):
     """k^3 stride-1 conv on one map (in map == out map) or 1x1 conv (nbr None)."""
 

@@ -37,6 +37,14 @@ FORK_WGRAD = os.environ.get("USC3D_FORK_WGRAD", "0") == "1"
 LANE_MAX_ROWS = int(os.environ.get("USC3D_WGRAD_LANE_MAX_ROWS", "0"))
 LANE_WS_BYTES = 192 << 20
 SAME, DOWN, UP = 0, 1, 2
+# Grouped weight gradients (usc_spconv_wgrad_group): the stride-1 convolutions of one level's residual blocks have the
+# same shape on the same kernel map; their weight gradients are off the backward pass's critical chain (nothing reads
+# dW before the optimizer / the gradient exchange), so a unit only QUEUES (x, dy, dW) and the queue is flushed as ONE
+# grid when the shape changes, when it is full, or when the backward pass ends.  On the 507- and 2 222-row levels of a
+# 150 k-voxel scene a single weight gradient fills a quarter of the chip and needs a pair split plus a reduction
+# launch; eleven of them in one grid need neither (round-3 probe: 378 -> 197 us for the eleven 256 -> 256 problems of the
+# stride-16 level).  USC3D_GROUP_WGRAD=0 switches it off (A/B, and the bit-equality tests against the per-operator path).
+GROUP_WGRAD = os.environ.get("USC3D_GROUP_WGRAD", "1") == "1"
 _SIDE = {}     # device index -> torch.cuda.Stream handed to usc_set_side_stream
 _LANE = {}     # device index -> (stream, scratch tensor) handed to usc_set_wgrad_lane, or None
 _LANE_JOIN_QUEUED = set()
@@ -127,6 +135,89 @@ def kmap_identity(n):
     return KMapRef(None, None, None, None, n, n, 1)
 
 
+class _WgradQueue:
+    """Deferred same-shape weight gradients of the running backward pass (one queue per device)."""
+
+    def __init__(self):
+        self.key, self.items, self.callback_queued = None, [], False
+
+    def push(self, key, kmap, x, dy, W_param, dW):
+        if self.key is not None and key != self.key:
+            self.flush()
+        self.key = key
+        self.items.append((kmap, x, dy, W_param, dW))
+        if len(self.items) >= _group_max():
+            self.flush()
+        elif not self.callback_queued:
+            self.callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+
+    def _end_of_backward(self):
+        self.callback_queued = False
+        self.flush()
+
+    def flush(self):
+        items, key = self.items, self.key
+        self.items, self.key = [], None
+        if not items:
+            return
+        kmap = items[0][0]
+        cin, cout, K = key[1], key[2], kmap.K
+        s = kmap.struct
+        R = len(items)
+        with torch.cuda.device(items[0][1].device):
+            st = ops._stream()
+            if R >= 2 and lib.usc_spconv_wgrad_group_ok(R, cin, cout, K, s.pair_capacity):
+                pa = (C.c_void_p * R)(*[it[1].data_ptr() for it in items])
+                pb = (C.c_void_p * R)(*[it[2].data_ptr() for it in items])
+                pw = (C.c_void_p * R)(*[it[4].data_ptr() for it in items])
+                check(lib.usc_spconv_wgrad_group(R, pa, pb, pw, cin, cout, K, s.pair_in, s.pair_out, s.koff,
+                                                 s.pair_capacity, 1, st), "usc_spconv_wgrad_group")
+            else:                                   # a lone problem (or too few for the grouped grid): the usual launch
+                for _, x, dy, _, dW in items:
+                    wsb = lib.usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, s.pair_capacity)
+                    ws = workspace(wsb, x.device)
+                    check(lib.usc_spconv_wgrad(x.data_ptr(), cin, dy.data_ptr(), cout, K, s.pair_in, s.pair_out, s.koff,
+                                               s.pair_capacity, dW.data_ptr(), 1, ws.data_ptr(), ws.numel(), st),
+                          "usc_spconv_wgrad")
+        ops._grad_written(*[it[3] for it in items])
+
+
+_WGQ = {}
+_GROUP_MAX = []
+
+
+def _group_max():
+    if not _GROUP_MAX:
+        _GROUP_MAX.append(int(lib.usc_spconv_wgrad_group_max()))
+    return _GROUP_MAX[0]
+
+
+def _wgrad_queue(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    q = _WGQ.get(key)
+    if q is None:
+        q = _WGQ[key] = _WgradQueue()
+    return q
+
+
+def flush_deferred_wgrads(device=None):
+    """Issue every weight gradient still queued (called by the engine at the end of a backward pass; call it yourself
+    before reading .grad from inside a backward hook)."""
+    for q in (_WGQ.values() if device is None else [_wgrad_queue(device)]):
+        q.flush()
+
+
+def _defer_wgrad(kmap, kind, cin, cout, in_place):
+    """May this unit's weight gradient go to the queue?  Stride-1 table convolutions on the coarse levels whose
+    gradient is added into p.grad in place, outside graph capture, lane and fork modes off."""
+    if not (GROUP_WGRAD and in_place and kind == SAME and kmap.K > 1 and kmap.struct.pair_in and not FORK_WGRAD
+            and LANE_MAX_ROWS == 0):
+        return False
+    return bool(lib.usc_spconv_wgrad_group_ok(2, cin, cout, kmap.K, kmap.struct.pair_capacity) or
+                lib.usc_spconv_wgrad_group_ok(_group_max(), cin, cout, kmap.K, kmap.struct.pair_capacity))
+
+
 # one grow-only scratch buffer per device for the native calls (all on the compute stream: stream order makes the
 # reuse safe; the caching allocator hands a replaced buffer only to later work of the same stream)
 _WS = {}
@@ -205,8 +296,9 @@ def unit_forward(x, W3, bn, kmap: KMapRef, kind, residual, relu):
 
 
 def unit_backward(x, W3, bn, kmap, kind, y, stats, out_relu, dout, dy_buf, want_dres, dx, dx_accumulate, need_dx,
-                  W_param, g_param, b_param):
-    """Backward of one unit.  dy_buf: scratch [n_out, cout] (may be shared between the units of a block).
+                  W_param, g_param, b_param, defer_ok=False):
+    """Backward of one unit.  dy_buf: scratch [n_out, cout] (may be shared between the units of a block — unless
+    defer_ok: the weight gradient may then be queued for a grouped launch that reads dy_buf later).
     -> (dx or None, dres or None, dW, dgamma, dbeta) — the last three None when written into .grad in place."""
     dev = x.device
     K, cin, cout = W3.shape
@@ -226,13 +318,19 @@ def unit_backward(x, W3, bn, kmap, kind, y, stats, out_relu, dout, dy_buf, want_
     _, bref = _bn_desc(bn, _training(bn))
     wsb = lib.usc_unit_ws_bytes(kmap.ref, kind, cin, cout)
     ws = workspace(wsb, dev)
+    defer = defer_ok and _defer_wgrad(kmap, kind, cin, cout, tW is not None)
     check(lib.usc_conv_bn_act_backward(kmap.ref, kind, x.data_ptr(), cin, W3.data_ptr(), cout, bref, y.data_ptr(),
                                        stats.data_ptr(), None if out_relu is None else out_relu.data_ptr(),
                                        dout.data_ptr(), dy_buf.data_ptr(), None if dres is None else dres.data_ptr(),
-                                       dx.data_ptr() if need_dx else None, int(bool(dx_accumulate)), dW.data_ptr(),
+                                       dx.data_ptr() if need_dx else None, int(bool(dx_accumulate)),
+                                       None if defer else dW.data_ptr(),
                                        int(tW is not None), dg.data_ptr(), db.data_ptr(), int(bn_in_place),
                                        ws.data_ptr(), ws.numel(), ops._stream()), "usc_conv_bn_act_backward")
-    if tW is not None:
+    if defer:
+        # queued: x and this unit's OWN dy stay referenced until the grouped launch; the write is reported then
+        _wgrad_queue(dev).push((id(kmap), cin, cout), kmap, x, dy_buf, W_param, tW)
+        dW = None
+    elif tW is not None:
         ops._grad_written(W_param)
         dW = None
     if bn_in_place:
@@ -266,7 +364,8 @@ class _Unit(torch.autograd.Function):
         W, gamma, beta = ctx.params
         dy = torch.empty_like(y)
         dx, dres, dW, dg, db = unit_backward(x, W3, ctx.bn, ctx.kmap, ctx.kind, y, stats, out_relu, dout, dy,
-                                             ctx.has_res, None, False, ctx.needs_input_grad[0], W, gamma, beta)
+                                             ctx.has_res, None, False, ctx.needs_input_grad[0], W, gamma, beta,
+                                             defer_ok=True)
         if dW is not None and W.dim() == 2:
             dW = dW.view(W.shape)
         return dx, dW, dg, db, dres, None, None, None, None
@@ -309,19 +408,22 @@ class _BasicBlock(torch.autograd.Function):
         dy = torch.empty_like(y2)                 # d(conv output) scratch, shared by the units (same shape) ...
         # ... unless their weight gradients go to the lane: each then reads its own dy after this function has moved on
         lane_on = _lane(x.device) is not None and x.shape[0] <= LANE_MAX_ROWS
-        dy1 = torch.empty_like(y2) if lane_on else dy
-        dyd = torch.empty_like(y2) if (lane_on and Wdc is not None) else dy
+        # ... or to the grouped launch (queued weight gradients read their dy when the queue is flushed)
+        own_dy = lane_on or (GROUP_WGRAD and _defer_wgrad(ctx.kmap, SAME, W2c.shape[1], W2c.shape[2],
+                                                          ops._grad_target(W2) is not None))
+        dy1 = torch.empty_like(y2) if own_dy else dy
+        dyd = torch.empty_like(y2) if (own_dy and Wdc is not None) else dy     # (never a queued unit's buffer)
         # unit 2: dout -> (d a1, d residual)
         da1, dres, dW2, dg2, db2 = unit_backward(a1, W2c, bn2, ctx.kmap, SAME, y2, st2, out, dout, dy, True, None,
-                                                 False, True, W2, g2, b2)
+                                                 False, True, W2, g2, b2, defer_ok=own_dy)
         dWd = dgd = dbd = None
         if Wdc is None:
             # identity residual: conv1's input gradient is accumulated straight onto the residual gradient
             dx, _, dW1, dg1, db1 = unit_backward(x, W1c, bn1, ctx.kmap, SAME, y1, st1, a1, da1, dy1, False, dres, True,
-                                                 need_dx, W1, g1, b1)
+                                                 need_dx, W1, g1, b1, defer_ok=own_dy)
         else:
             dx, _, dW1, dg1, db1 = unit_backward(x, W1c, bn1, ctx.kmap, SAME, y1, st1, a1, da1, dy1, False, None, False,
-                                                 need_dx, W1, g1, b1)
+                                                 need_dx, W1, g1, b1, defer_ok=own_dy)
             dx, _, dWd, dgd, dbd = unit_backward(x, Wdc, bnd, ctx.kmap_id, SAME, yd, std, None, dres, dyd, False, dx,
                                                  True, need_dx, Wd, gd, bd)
             if dWd is not None and Wd.dim() == 2:
