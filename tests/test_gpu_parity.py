@@ -1587,10 +1587,11 @@ def test_deferred_weight_gradients_equal_the_immediate_ones(device, monkeypatch)
     from types import SimpleNamespace
 
     from unscene3d_amd import MinkowskiEngine as ME
-    from unscene3d_amd import units
+    from unscene3d_amd import program, units
     from unscene3d_amd.models.res16unet import Res16UNet34C
     from unscene3d_amd.synthetic import make_scene
 
+    monkeypatch.setattr(program, "ENABLED", False)      # the per-block path and its Python-side queue (units.py)
     sc = make_scene(2101, target_voxels=20_000, tol=0.05)
     ec = R.voxel_floor(sc["xyz"], 0.02)
     eu, _ = R.sparse_quantize(ec)

@@ -46,7 +46,8 @@ class Step(C.Structure):
     _fields_ = [("op", _i32), ("kind", _i32), ("cin", _i32), ("cout", _i32), ("relu", _i32),
                 ("dx_accumulate", _i32), ("dW_accumulate", _i32), ("dbn_accumulate", _i32), ("defer_wgrad", _i32),
                 ("accumulate", _i32),
-                ("map", _kp), ("bn", _bp), ("x", _p), ("W", _p), ("residual", _p), ("y", _p), ("stats", _p), ("out", _p),
+                ("map", _p), ("bn", _p),          # (addresses of a KMap / BNDesc: C.addressof)
+                ("x", _p), ("W", _p), ("residual", _p), ("y", _p), ("stats", _p), ("out", _p),
                 ("dout", _p), ("dy", _p), ("dres", _p), ("dx", _p), ("dW", _p), ("dgamma", _p), ("dbeta", _p),
                 ("a", _p), ("b", _p), ("dst", _p), ("dst2", _p), ("n", _i64), ("ca", _i32), ("cb", _i32)]
 

@@ -216,15 +216,16 @@ class _Trunk(torch.autograd.Function):
                 ps, _ = car.take(4 * cout)
                 ptr[op["y"]], ptr[op["out"]] = py, po
                 km = kmap(op)
-                _, bref = units._bn_desc(op["bn"], units._training(op["bn"]))
+                bdesc, _ = units._bn_desc(op["bn"], units._training(op["bn"]))
+                bref = C.addressof(bdesc)                  # (the descriptor is kept alive by units._BN_DESC and `bnrefs`)
                 st.op, st.kind, st.cin, st.cout, st.relu = STEP_UNIT_FWD, op["kind"], op["cin"], cout, int(op["relu"])
-                st.map, st.bn = km.ref, bref
+                st.map, st.bn = C.addressof(km.struct), bref
                 st.x, st.W = ptr[op["x"]], op["conv"].kernel.data_ptr()
                 st.residual = ptr[op["res"]] if op["res"] is not None else None
                 st.y, st.stats, st.out = py, ps, po
                 stats_ptr.append(ps)
                 kmaps.append(km)
-                bnrefs.append(bref)
+                bnrefs.append((bref, bdesc))
             else:
                 n = rows[op["level"]]
                 pc, offs[op["out"]] = car.take(n * (op["ca"] + op["cb"]))
@@ -328,7 +329,7 @@ class _Trunk(torch.autograd.Function):
             st = steps[ns]
             ns += 1
             st.op, st.kind, st.cin, st.cout = STEP_UNIT_BWD, op["kind"], cin, cout
-            st.map, st.bn = kmaps[i].ref, bnrefs[i]
+            st.map, st.bn = C.addressof(kmaps[i].struct), bnrefs[i][0]
             st.x, st.W = ptr[op["x"]], conv.kernel.data_ptr()
             st.y, st.stats = ptr[op["y"]], stats_ptr[i]
             st.out = ptr[op["out"]] if op["relu"] else None
