@@ -370,7 +370,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline_mask3d(sample_voxels, runs=10, warmup=3, leg_budget_s=25.0):
+def cpu_baseline_mask3d(sample_voxels, runs=10, warmup=3, leg_budget_s=25.0, full_size_voxels=VOXELS):
     """oracle/mask3d_ref.py forward + criterion + backward (through every parameter, backbone included) on one small
     scene (SURVEY.md §8d "Timing the reference CPU path": ME cannot run, so the baseline is the CPU restatement):
     `warmup` untimed + up to `runs` timed passes per leg — 3 threads (the reference's scripts export
@@ -393,6 +393,7 @@ def cpu_baseline_mask3d(sample_voxels, runs=10, warmup=3, leg_budget_s=25.0):
     wd.update({f"{k}_{i}": v for i in range(12) for k, v in list(wd.items())})
 
     def one_pass():
+        nonlocal sample
         sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in sd0.items()}
         t0 = time.perf_counter()
         ec = R.voxel_floor(sample[0], 0.02)
@@ -434,23 +435,42 @@ def cpu_baseline_mask3d(sample_voxels, runs=10, warmup=3, leg_budget_s=25.0):
         q = lambda f: ts[min(len(ts) - 1, int(round(f * (len(ts) - 1))))]
         legs[name] = {"threads": nthr, "timed_passes": len(ts), "median_s": q(0.5), "p10_s": q(0.1), "p90_s": q(0.9),
                       "min_s": ts[0], "max_s": ts[-1], "scenes_per_s_150k_equiv": (nv / VOXELS) / q(0.5)}
+    # one UNSCALED pass at the metric's own size (round-3 verdict, weak #15: the legs above time a 10 k-voxel scene and
+    # scale by the voxel ratio): a full 150 k-voxel scene with 16 threads — the thread count at which the restatement's
+    # index kernels stop scaling on the hosts seen so far
+    full = None
+    if full_size_voxels:
+        nthr = min(16, all_threads)
+        torch.set_num_threads(nthr)
+        small = sample
+        sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=full_size_voxels, seed=2000)[0]
+        dt, nv_full = one_pass()
+        sample = small
+        full = {"threads": nthr, "voxels": int(nv_full), "seconds": dt, "scenes_per_s": 1.0 / dt,
+                "scenes_per_s_150k_equiv": (nv_full / VOXELS) / dt}
     torch.set_num_threads(all_threads)
     best = max(legs.values(), key=lambda l: l["scenes_per_s_150k_equiv"])
     a, o = legs["all_threads"], legs["omp3"]
+    value, cores, unit = best["scenes_per_s_150k_equiv"], best["threads"], \
+        "scenes/s in 150k-voxel-scene equivalents (measured on a smaller scene, scaled by voxels/150000)"
+    if full is not None and full["scenes_per_s_150k_equiv"] >= value:
+        value, cores, unit = full["scenes_per_s_150k_equiv"], full["threads"], \
+            "scenes/s (one unscaled pass over a full-size scene; scaled by voxels/150000 only for the +-2 % size tolerance)"
     return {
-        # the faster of the two legs is the baseline (oversubscribed hosts run the restatement's many small torch ops
-        # far slower with all hardware threads than with three); both legs are reported
-        "value": best["scenes_per_s_150k_equiv"],
-        "unit": "scenes/s in 150k-voxel-scene equivalents (measured on a smaller scene, scaled by voxels/150000)",
-        "cores": best["threads"], "kind": "port", "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
-        "runs": best["timed_passes"], "legs": legs,
+        # the fastest leg is the baseline (oversubscribed hosts run the restatement's many small torch ops far slower
+        # with all hardware threads than with a few); every leg is reported
+        "value": value, "unit": unit,
+        "cores": cores, "kind": "port", "cpu_model": _cpu_model(), "host_cpus": os.cpu_count(),
+        "runs": best["timed_passes"], "legs": legs, "full_size_pass": full,
         "sample": f"oracle Mask3D self-train step (voxelise + maps + Res16UNet34C + decoder + Hungarian + losses, forward "
                   f"+ backward through all parameters, no optimizer; CPU restatement, not the reference binary: "
                   f"MinkowskiEngine cannot run here) on one {nv}-voxel synthetic scene; {warmup} warm-up + up to {runs} "
                   f"timed passes per leg (a leg stops after {leg_budget_s:.0f} s, >= 3 passes); "
                   f"3 threads (the reference's OMP_NUM_THREADS=3): {o['timed_passes']} passes, median {o['median_s']:.2f} s "
                   f"(p10 {o['p10_s']:.2f}, p90 {o['p90_s']:.2f}); {a['threads']} threads: {a['timed_passes']} passes, "
-                  f"median {a['median_s']:.2f} s (p10 {a['p10_s']:.2f}, p90 {a['p90_s']:.2f})",
+                  f"median {a['median_s']:.2f} s (p10 {a['p10_s']:.2f}, p90 {a['p90_s']:.2f})"
+                  + ("" if full is None else f"; plus ONE unscaled pass over a {full['voxels']}-voxel scene with "
+                                             f"{full['threads']} threads: {full['seconds']:.1f} s"),
     }
 
 
