@@ -629,6 +629,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    own_marks = None
+    if own is not None:                    # freeze the timed loop's marks (later steps must not append to them)
+        own_marks, own["marks"] = own["marks"], None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -690,11 +693,10 @@ def main():
         rot = {"rotated_scene_sets": args.rotate, "step_ms_p10": q(0.1), "step_ms_p50": q(0.5), "step_ms_p90": q(0.9),
                "step_ms_min": per[0], "step_ms_max": per[-1]}
     skew = None
-    if own is not None and len(own["marks"]) == args.steps:
+    if own_marks is not None and len(own_marks) == args.steps:
         # per-rank step-time skew: how long each rank's OWN work of a step took (step start -> backward queued, device
         # time), all-gathered; max / mean over the ranks of a step = what the gradient exchange makes the others wait
-        mine_ms = torch.tensor([marks[k].elapsed_time(own["marks"][k]) for k in range(args.steps)], device=dev)
-        own["marks"] = None
+        mine_ms = torch.tensor([marks[k].elapsed_time(own_marks[k]) for k in range(args.steps)], device=dev)
         allr = [torch.empty_like(mine_ms) for _ in range(world)]
         dist.all_gather(allr, mine_ms)
         tab = torch.stack(allr).cpu().numpy()                                  # [world, steps]

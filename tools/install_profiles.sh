@@ -1,17 +1,13 @@
-# copy one measurement set (tools/measure_r03.sh <tag>) from gpurun_out/<tag> into profiles/ as the round-3 files
+# copy one measurement set (tools/measure_r04.sh <tag>) from gpurun_out/<tag> into profiles/ as the round-4 files
 # usage: bash tools/install_profiles.sh <tag> "<comment for pmc_traffic.json>"
-T=${1:?tag}; C=${2:-"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over python bench.py (round 3)"}
+T=${1:?tag}; C=${2:-"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over python bench.py (round 4)"}
 O=gpurun_out/$T
-cp $O/bench.json profiles/r03_bench.json
-cp $O/bench_B8.json profiles/r03_bench_B8.json
-cp $O/bench_rotate8.json profiles/r03_bench_rotate8.json
-cp $O/bench_ncut.json profiles/r03_bench_ncut.json
-cp $O/kernel_stats.csv profiles/r03_bench_kernel_stats.csv
-cp $O/kernel_stats_summary.txt profiles/r03_bench_kernel_stats_summary.txt
-cp $O/conv_per_shape.txt profiles/r03_conv_per_shape.txt
-cp $O/hbm_bound_kernels.txt profiles/r03_hbm_bound_kernels.txt
-cp $O/ncut_scenes_in_flight.txt profiles/r03_ncut_scenes_in_flight.txt
-cp $O/scenes_per_gpu.txt profiles/r03_scenes_per_gpu.txt
-cp $O/step_vs_scene_size.txt profiles/r03_step_vs_scene_size.txt
-cp $O/pmc_traffic_raw.txt profiles/r03_pmc_bench_traffic.txt
-python tools/pmc_to_json.py $O/pmc_traffic_raw.txt profiles/pmc_traffic.json "$C"
+R=r04
+for f in bench.json bench_B8.json bench_rotate8.json bench_ncut.json bench_2rank_gloo_rotate.json bench_2rank_gloo_rotate_plain.json; do [ -s $O/$f ] && cp $O/$f profiles/${R}_$f; done
+[ -s $O/kernel_stats.csv ] && cp $O/kernel_stats.csv profiles/${R}_bench_kernel_stats.csv
+[ -s $O/kernel_stats_summary.txt ] && cp $O/kernel_stats_summary.txt profiles/${R}_bench_kernel_stats_summary.txt
+for f in conv_per_shape.txt hbm_bound_kernels.txt ncut_scenes_in_flight.txt scenes_per_gpu.txt step_vs_scene_size.txt host_vs_device.txt; do [ -s $O/$f ] && cp $O/$f profiles/${R}_$f; done
+if [ -s $O/pmc_traffic_raw.txt ]; then
+  cp $O/pmc_traffic_raw.txt profiles/${R}_pmc_bench_traffic.txt
+  python tools/pmc_to_json.py $O/pmc_traffic_raw.txt profiles/pmc_traffic.json "$C"
+fi

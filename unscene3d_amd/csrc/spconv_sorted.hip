@@ -269,6 +269,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void gather_gemm_so
     stage_store(0);
   }
   __syncthreads();
+#ifdef USC_ABLATE_SORTED_LOOP   /* developer switch (tools/build_ablate.sh): prologue + epilogue only */
+  if (p.cin < 0)
+#endif
   while (k < 32) {
     // next step's coordinates
     int k2 = k, ch2 = ch + 1;
@@ -330,6 +333,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 4 : 3) void gather_gemm_so
 
   // ---- write the tile (rows scattered back through perm)
   if (tile >= ntiles) return;
+#ifdef USC_ABLATE_SORTED_STORE  /* developer switch: no tile write-back (one word, so that the accumulators stay live) */
+  if (p.cin > 0) { if (lane == 0 && acc[0][0] == 123.456f) p.out[0] = acc[NB - 1][15]; return; }
+#endif
   float* outp = p.out;
   if (p.G > 1) outp += (int64_t)blockIdx.z * p.n_out * cout;
   const bool direct = p.G == 1;

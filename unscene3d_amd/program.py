@@ -167,6 +167,37 @@ class _Carver:
         return self.arena[off:off + n * c].view(n, c)
 
 
+class _Pool:
+    """Gradient buffers of one backward pass: chunks allocated on demand, exact-size reuse of released ranges.  The
+    steps run in order on ONE stream, so a range released after the step that last reads it may be handed to any later
+    step (the weight gradients queued inside a usc_program_run call read their dy until that call returns: those are
+    released when the stage's call is closed).  Peak ~1.5 GB for a 150 k-voxel scene instead of the 8 GB the sum of
+    all gradient buffers would take."""
+
+    def __init__(self, device, chunk_floats):
+        self.device, self.chunk_floats = device, int(chunk_floats)
+        self.chunks, self.base, self.off, self.cap = [], 0, 0, 0
+        self.free = {}
+
+    def take(self, n):
+        n = (int(n) + _ALIGN - 1) // _ALIGN * _ALIGN
+        lst = self.free.get(n)
+        if lst:
+            return lst.pop()
+        if self.off + n > self.cap:
+            self.cap = max(self.chunk_floats, n)
+            t = torch.empty(self.cap, dtype=torch.float32, device=self.device)
+            self.chunks.append(t)
+            self.base, self.off = t.data_ptr(), 0
+        p = self.base + 4 * self.off
+        self.off += n
+        return p
+
+    def release(self, p, n):
+        n = (int(n) + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.free.setdefault(n, []).append(p)
+
+
 def usable(model, x):
     """May this forward pass run as a step program?"""
     if not (ENABLED and units.usable(x.F, None) and x.F.shape[0] > 0):
@@ -245,13 +276,13 @@ class _Trunk(torch.autograd.Function):
     def backward(ctx, *gouts):
         model, pl, cm, ts, feats, car, ptr, stats_ptr, kmaps, bnrefs, rows = ctx.state
         dev = feats.device
-        floats = sum(r * f for r, f in zip(rows, pl.grad_floats)) + (pl.n_grad + 8) * _ALIGN
-        gar = _Carver(floats, dev)
+        gar = _Pool(dev, max(rows[0] * 256, 1 << 20))
         keep = [g.contiguous() if g is not None else None for g in gouts]
-        G = {}                                   # buffer id -> [pointer, read-only (an incoming gradient tensor)]
+        G = {}                                   # buffer id -> [pointer, read-only (an incoming gradient tensor), floats]
+        held_dy = []                             # dy buffers the current stage's queued weight gradients still read
         for b, g in zip(pl.levels, keep):
             if g is not None:
-                G[b] = [g.data_ptr(), True]
+                G[b] = [g.data_ptr(), True, g.numel()]
         steps = (Step * (3 * len(pl.ops) + 8))()
         ns = 0
         segments, cur_params, stage = [], [], None       # one C call per U-Net stage: (end step, parameters it finished)
@@ -268,20 +299,27 @@ class _Trunk(torch.autograd.Function):
             accumulated into: an incoming gradient tensor is never written, and the pair-list forms only write)."""
             cur = G.get(bid)
             if cur is None:
-                p, _ = gar.take(numel)
-                G[bid] = [p, False]
+                p = gar.take(numel)
+                G[bid] = [p, False, numel]
                 return p, 0, None
             if can_accumulate and not cur[1]:
                 return cur[0], 1, None
-            p, _ = gar.take(numel)
+            p = gar.take(numel)
             if cur[1]:                           # new buffer = this contribution + the incoming gradient; ours from now on
                 def fin(p=p, old=cur[0]):
                     add_step(p, old, numel)
-                    G[bid] = [p, False]
+                    G[bid] = [p, False, numel]
             else:
                 def fin(p=p, old=cur[0]):
                     add_step(old, p, numel)
+                    gar.release(p, numel)
             return p, 0, fin
+
+        def consumed(bid):
+            """The gradient of buffer `bid` has been read by its producer's backward step: give the range back."""
+            cur = G.pop(bid, None)
+            if cur is not None and not cur[1]:
+                gar.release(cur[0], cur[2])
 
         for i in range(len(pl.ops) - 1, -1, -1):
             op = pl.ops[i]
@@ -289,6 +327,9 @@ class _Trunk(torch.autograd.Function):
                 if stage is not None:
                     segments.append((ns, cur_params))
                     cur_params = []
+                    for p_, n_ in held_dy:       # the stage's C call flushes its queued weight gradients before it returns
+                        gar.release(p_, n_)
+                    held_dy = []
                 stage = op["stage"]
             if op["t"] == "cat":
                 g = G.get(op["out"])
@@ -308,12 +349,13 @@ class _Trunk(torch.autograd.Function):
                 for f in (fa, fb):
                     if f is not None:
                         f()
+                consumed(op["out"])
                 continue
             g = G.get(op["out"])
             if g is None:
                 continue                          # nothing downstream asked for this unit's gradient
             n_out, n_in, cin, cout = rows[op["lout"]], rows[op["lin"]], op["cin"], op["cout"]
-            pdy, _ = gar.take(n_out * cout)
+            pdy = gar.take(n_out * cout)
             pres, fres = None, None
             if op["res"] is not None:
                 pres, _, fres = contribute(op["res"], n_out * cout, False)
@@ -341,6 +383,11 @@ class _Trunk(torch.autograd.Function):
             for f in (fres, fdx):
                 if f is not None:
                     f()
+            consumed(op["out"])
+            if st.defer_wgrad and op["kind"] == SAME and op["kvol"] > 1:
+                held_dy.append((pdy, n_out * cout))
+            else:
+                gar.release(pdy, n_out * cout)
         segments.append((ns, cur_params))
         wsb = lib.usc_program_ws_bytes(steps, ns)
         ws = units.workspace(wsb, dev)
