@@ -263,3 +263,65 @@ def test_masked_cross_attention_at_eval_key_counts(device, S, B):
     scores = qd @ kd.transpose(1, 2) / 4.0 + add.repeat_interleave(H, dim=0)
     ref = (torch.softmax(scores, -1) @ vd).transpose(0, 1).reshape(L, B, E)
     assert rel_err(out, ref) < 1e-5
+
+
+def test_one_self_training_round_end_to_end(device, tmp_path):
+    """The loop the hot path serves: scene files -> reader -> collate -> training step ->
+    eval_step over the scene with `general.save_for_freemask` (trainer.py:743-760 writes `{scene}_cloud.npy` /
+    `{scene}_masks.npy`) -> the NEXT round's reader merges those masks into the scene's pseudo masks
+    (freemask_semseg.py:224-265) -> collate -> training step.  Every hand-over is the reference's file / tuple format;
+    everything between the files runs on the device."""
+    import os
+
+    from unscene3d_amd.config import apply_overrides, default_config
+    from unscene3d_amd.datasets.freemask import FreeMaskSceneReader
+    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+    from unscene3d_amd.ddp import flatten_grads
+    from unscene3d_amd.optim import FlatAdamW
+    from unscene3d_amd.trainer.trainer import InstanceSegmentation
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset.npz"))
+    d = tmp_path / "scans" / "scene0001_00"
+    d.mkdir(parents=True)
+    np.save(d / "0001_00.npy", z["points"])
+    np.save(d / "0001_00_freemasks.npy", z["freemasks"])
+    entry = {"filepath": str(d / "0001_00.npy"), "raw_filepath": "raw/scene0001_00/scene0001_00_vh_clean_2.ply"}
+    save_dir = str(tmp_path / "round1")
+    cfg = apply_overrides(default_config(), ["general.num_targets=3", "model.sample_sizes=[50,100,200,400,800]",
+                                             "general.save_for_freemask=true", f"general.save_dir={save_dir}",
+                                             "general.topk_per_image=20", "general.scores_threshold=0.0"])
+    torch.manual_seed(3)
+    module = InstanceSegmentation(cfg).to(device).train()
+    params = [p for n, p in module.named_parameters() if ".backbone.final." not in n]
+    opt = FlatAdamW(params, lr=1e-4, flat_grad=flatten_grads(params))
+    train_collate = FreeMaskVoxelizeCollate(voxel_size=0.02, mode="train", device=str(device))
+    val_collate = FreeMaskVoxelizeCollate(voxel_size=0.02, mode="validation", device=str(device))
+
+    def one_training_step(reader):
+        total, parts = module.training_step(train_collate([reader[0]]))
+        opt.zero_grad(set_to_none=False)
+        total.backward()
+        opt.step()
+        assert bool(torch.isfinite(total)) and len(parts) == 52
+        return float(total)
+
+    # round k: train on the scene's own pseudo masks, then export
+    reader0 = FreeMaskSceneReader([entry], add_normals=False, add_raw_coordinates=True, device=str(device))
+    n_masks0 = reader0[0][2].shape[1]
+    one_training_step(reader0)
+    module.eval()
+    res = module.eval_step(val_collate([reader0[0]]))
+    module.train()
+    inst = res["instances"][0]
+    cloud = np.load(os.path.join(save_dir, "freemasks", "scene0001_00_cloud.npy"))
+    masks = np.load(os.path.join(save_dir, "freemasks", "scene0001_00_masks.npy"))
+    assert cloud.shape == (z["points"].shape[0], 3) and masks.dtype == bool
+    assert masks.shape == (cloud.shape[0], inst["pred_masks"].shape[1]) and masks.shape[1] >= 1
+    assert np.array_equal(masks, inst["pred_masks"].cpu().numpy())
+    # round k+1: the reader merges the exported masks (1-NN to the scene's points, greedy merge) and training goes on
+    reader1 = FreeMaskSceneReader([entry], add_normals=False, add_raw_coordinates=True, load_self_train_data=True,
+                                  self_train_data_dir=save_dir, num_self_train_data=5, device=str(device))
+    item = reader1[0]
+    assert item[2].shape[0] == z["points"].shape[0] and item[2].shape[1] >= n_masks0       # masks | ... | segment id
+    one_training_step(reader1)
+    module.criterion.check_lsap_status(wait=True)
