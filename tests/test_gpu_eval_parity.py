@@ -122,7 +122,7 @@ def _compare_outputs(res, out_ref, ex, n_scenes, level_sizes):
     return worst
 
 
-def _compare_export(cfg, res, out_ref, data, target, n_scenes):
+def _compare_export(cfg, res, out_ref, data, target, n_scenes, unfiltered=False):
     """The masks the next self-training round would read: the device's export of the DEVICE's eval outputs against
     oracle/export_ref.py applied to the ORACLE's outputs.  Exported masks are thresholded segment means of thresholded
     logits: a logit within 1e-3 of zero may flip a segment, so scenes are compared by matched IoU."""
@@ -131,13 +131,20 @@ def _compare_export(cfg, res, out_ref, data, target, n_scenes):
     general = NS(use_dbscan=g.use_dbscan, dbscan_eps=g.dbscan_eps, topk_per_image=g.topk_per_image,
                  filter_out_instances=g.filter_out_instances, scores_threshold=g.scores_threshold,
                  iou_threshold=g.iou_threshold)
+    instances = res["instances"]
+    if unfiltered:      # every one of the top-100 (query, class) candidates, no overlap filter: 100 masks per scene
+        from unscene3d_amd.trainer.postprocess import export_instances
+        general = NS(use_dbscan=False, dbscan_eps=0.95, topk_per_image=100, filter_out_instances=False,
+                     scores_threshold=0.0, iou_threshold=1.0)
+        instances = export_instances(res["output"], target, data.target_full, data.inverse_maps, None, general,
+                                     num_classes=3, label_offset=2, full_res_coords=data.full_res_coords)
     ref = export_instances_ref(out_ref["pred_logits"], out_ref["pred_masks"],
                                [t["point2segment"].cpu() for t in target], [m.cpu() for m in data.inverse_maps],
                                [t["point2segment"].cpu() for t in data.target_full], None, general, num_classes=3,
                                label_offset=2)
-    assert len(res["instances"]) == len(ref) == n_scenes
+    assert len(instances) == len(ref) == n_scenes
     total = 0
-    for got, want in zip(res["instances"], ref):
+    for got, want in zip(instances, ref):
         gm, wm = got["pred_masks"].cpu().numpy(), want["pred_masks"]
         assert gm.shape[0] == wm.shape[0]
         # same instances, in the same (score) order, up to ties between equal scores
@@ -169,8 +176,10 @@ def test_eval_forward_and_export_match_the_oracle(device):
     sizes = [max(_level_rows(cm, ts)) for ts in (16, 8, 4, 2)]
     worst = _compare_outputs(res, out_ref, ex, 2, sizes)
     n = _compare_export(cfg, res, out_ref, data, target, 2)
+    n_all = _compare_export(cfg, res, out_ref, data, target, 2, unfiltered=True)
+    assert n_all == 200
     print(f"eval parity (2 x 12 k voxels): worst rel err {worst:.2e}, mask bits differing {ex.diff}/{ex.bits}, "
-          f"{n} exported instances compared")
+          f"{n} filtered + {n_all} unfiltered exported instances compared")
     # eval mode left the running statistics alone
     rm = module.model.backbone.bn0.bn.running_mean.clone()
     module.eval_step((data, target, ["a", "b"]))
@@ -195,8 +204,10 @@ def test_eval_forward_at_full_size(device):
     assert sizes[3] > 35_000                                  # far beyond the 12 800 sampled keys of training
     worst = _compare_outputs(res, out_ref, ex, 1, sizes)
     n = _compare_export(cfg, res, out_ref, data, target, 1)
+    n_all = _compare_export(cfg, res, out_ref, data, target, 1, unfiltered=True)
+    assert n_all == 100
     print(f"eval parity (150 k voxels, {sizes[3]} keys at stride 2): worst rel err {worst:.2e}, "
-          f"mask bits differing {ex.diff}/{ex.bits}, {n} exported instances")
+          f"mask bits differing {ex.diff}/{ex.bits}, {n} filtered + {n_all} unfiltered exported instances")
     # and training continues afterwards with the captured passes
     module.train()
     from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
