@@ -316,7 +316,10 @@ int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t c
     Lane* lane = lane_for_current_device();
     const int64_t rows = m->nbr ? m->pair_capacity : sh.n_in;
     const int64_t b = usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows);
-    if (lane && sh.n_in > 0 && sh.n_in <= lane->max_rows && sh.n_out <= lane->max_rows && b <= lane->ws_bytes &&
+    // USC3D_WGRAD_LANE_MIN_ROWS (experiment knob): only maps with at least that many rows go to the lane — the
+    // throughput-bound weight gradients of the fine levels, queued to run beside the latency-bound coarse-level chain
+    static const int64_t lane_min_rows = getenv("USC3D_WGRAD_LANE_MIN_ROWS") ? atoll(getenv("USC3D_WGRAD_LANE_MIN_ROWS")) : 0;
+    if (lane && sh.n_in > 0 && sh.n_in >= lane_min_rows && sh.n_in <= lane->max_rows && sh.n_out <= lane->max_rows && b <= lane->ws_bytes &&
         (!m->nbr || (m->pair_in && m->pair_out && m->koff)) &&
         hipEventRecord(lane->fork, as_stream(s)) == hipSuccess && hipStreamWaitEvent(lane->st, lane->fork, 0) == hipSuccess) {
       usc_stream_t ls = (usc_stream_t)lane->st;

@@ -277,6 +277,10 @@ class _Trunk(torch.autograd.Function):
         model, pl, cm, ts, feats, car, ptr, stats_ptr, kmaps, bnrefs, rows = ctx.state
         dev = feats.device
         gar = _Pool(dev, max(rows[0] * 256, 1 << 20))
+        lane = units._lane(dev)                  # weight-gradient lane (experiment, off by default): its launches read x
+        if lane is not None:                     # and dy after this function has moved on -> nothing they read is re-used
+            gar.release = lambda p_, n_: None
+            car.arena.record_stream(lane[0])
         keep = [g.contiguous() if g is not None else None for g in gouts]
         G = {}                                   # buffer id -> [pointer, read-only (an incoming gradient tensor), floats]
         held_dy = []                             # dy buffers the current stage's queued weight gradients still read
@@ -399,6 +403,13 @@ class _Trunk(torch.autograd.Function):
             if plist:
                 ops._grad_written(*plist)         # finished stages are reported while the earlier ones are still issued
             begin = end
+        if lane is not None:
+            for t in gar.chunks:
+                t.record_stream(lane[0])
+            key = dev.index if dev.index is not None else torch.cuda.current_device()
+            if key not in units._LANE_JOIN_QUEUED:
+                units._LANE_JOIN_QUEUED.add(key)
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: units._join_lane_after_backward(key))
         ctx.state = None
         return (None, None, None, None, None) + (None,) * len(pl.params)
 

@@ -50,12 +50,29 @@ _LANE = {}     # device index -> (stream, scratch tensor) handed to usc_set_wgra
 _LANE_JOIN_QUEUED = set()
 
 
+def _lane_stream(device):
+    """The lane's stream: plain, with a priority (USC3D_LANE_PRIORITY: torch's convention, lower = more urgent), or
+    restricted to a subset of the CUs (USC3D_LANE_CU_PATTERN=<hex word repeated over the 256-CU mask>, e.g. 55555555 =
+    every second CU) so that the main stream's latency-bound launches always find free CUs — experiment knobs."""
+    pat = os.environ.get("USC3D_LANE_CU_PATTERN")
+    if pat:
+        hip = C.CDLL("libamdhip64.so")
+        words = (C.c_uint32 * 8)(*([int(pat, 16) & 0xffffffff] * 8))
+        raw = C.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(raw), 8, words)
+        if rc != 0 or not raw.value:
+            raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+        return torch.cuda.ExternalStream(raw.value, device=device)
+    pr = os.environ.get("USC3D_LANE_PRIORITY")
+    return torch.cuda.Stream(device=device, priority=int(pr)) if pr is not None else torch.cuda.Stream(device=device)
+
+
 def _lane(device):
     """(stream, scratch) of the device's weight-gradient lane, or None when it is switched off."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _LANE:
         if LANE_MAX_ROWS > 0 and not FORK_WGRAD:
-            st = torch.cuda.Stream(device=device)
+            st = _lane_stream(device)
             ws = torch.empty(LANE_WS_BYTES, dtype=torch.uint8, device=device)
             check(lib.usc_set_wgrad_lane(st.cuda_stream, ws.data_ptr(), ws.numel(), LANE_MAX_ROWS), "usc_set_wgrad_lane")
             _LANE[key] = (st, ws)
