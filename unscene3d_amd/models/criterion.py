@@ -89,6 +89,10 @@ class _FusedCriterion(torch.autograd.Function):
         den_tot = torch.empty(L, dtype=torch.float32, device=dev)
         check(lib.usc_criterion_table(parts.data_ptr(), B, L, table.data_ptr(), den_tot.data_ptr(), st),
               "usc_criterion_table")
+        # the differentiable inputs go through save_for_backward (version check: a table modified in place between
+        # forward and backward raises instead of differentiating stale numbers); the per-scene intermediates are this
+        # Function's own tensors
+        ctx.save_for_backward(*[t for sc in scenes for t in sc.pop("tabs")])
         ctx.scenes, ctx.den_tot, ctx.shape, ctx.class_w = scenes, den_tot, (L, B, Q, NC), crit.empty_weight
         crit.last_indices = [[(sc["src"][l], sc["tid"][l]) for sc in scenes] for l in range(L)]   # device tensors
         crit.last_lsap_status = [sc["status"] for sc in scenes]
@@ -106,9 +110,10 @@ class _FusedCriterion(torch.autograd.Function):
         st = ops._stream()
         dlogits = torch.empty((L, B, Q, NC), dtype=torch.float32, device=dev)
         grads = []
+        saved = ctx.saved_tensors
         for b, sc in enumerate(ctx.scenes):
             dtab = torch.empty((L, sc["S"], sc["ld"]), dtype=torch.float32, device=dev)
-            ptrs = (C.c_void_p * L)(*[t.data_ptr() for t in sc["tabs"]])
+            ptrs = (C.c_void_p * L)(*[t.data_ptr() for t in saved[b * L:(b + 1) * L]])
             dptrs = (C.c_void_p * L)(*[dtab[l].data_ptr() for l in range(L)])
             check(lib.usc_criterion_backward(ptrs, dptrs, L, sc["ld"], sc["S"], Q, sc["T"], sc["bits"].data_ptr(),
                                              sc["cnt"].data_ptr(), sc["src"].data_ptr(), sc["tid"].data_ptr(),
@@ -397,6 +402,13 @@ class SetCriterion(nn.Module):
         levels = [final] + list(outputs.get("aux_outputs", []))
         self.check_lsap_status()                             # an earlier call's infeasible assignment -> ValueError
         tables = self._fused_tables(levels, targets, mask_type)
+        if tables is None and FUSED and levels[0]["pred_logits"].is_cuda and not self.__dict__.get("_warned_operator_path"):
+            # e.g. a prediction table that lost its `_usc_padded` companion by being cloned / re-wrapped, host-side
+            # targets, > 32 targets: correct, but ~150 stock launches and a device->host copy per step slower
+            self.__dict__["_warned_operator_path"] = True
+            import warnings
+            warnings.warn("SetCriterion: the device criterion (csrc/criterion.hip) does not apply to these inputs; "
+                          "using the torch-operator path (see SetCriterion._fused_tables for the conditions)")
         if tables is not None:
             if is_dist_avail_and_initialized():     # the reference's collective (criterion.py:258-260); its result is
                 # never used by the losses (loss_masks overwrites num_masks, :189), so nobody waits for it here

@@ -6,6 +6,7 @@ PyTorch-Lightning / hydra (neither is part of the accelerated path).  Difference
 on the device and synchronised once per step (the reference does 52 `.cpu().item()` calls, :149)."""
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -130,6 +131,9 @@ class InstanceSegmentation(nn.Module):
         if getattr(g, "save_for_freemask", False):
             for name, coords, inst in zip(file_names, data.full_res_coords, instances):
                 save_for_freemask(g.save_dir, name, coords, inst["pred_masks"])
+        sc = output.get("sampled_coords")
+        if sc is not None and not isinstance(sc, np.ndarray):       # the reference hands back a numpy array (mask3d.py:467)
+            output["sampled_coords"] = np.asarray(sc)
         return {"losses": val, "instances": instances, "output": output}
 
     def configure_optimizers(self, steps_per_epoch: int, epochs: int = None):
