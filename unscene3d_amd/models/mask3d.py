@@ -207,6 +207,19 @@ class Mask3D(nn.Module):
         # seeded run consumes the global generator in the reference's order.
         rng_queries = (not self.non_parametric_queries) and (self.random_queries or self.random_query_both)
         geo["key_samples"] = None if rng_queries else self._draw_key_samples(coords, is_eval)
+        if self.train_on_segments and point2segment is not None and _FUSED_ATTN_MASK and len(point2segment) >= 1:
+            # the mask module's child -> segment-row table (used by all 12 attention-mask chains of the step)
+            if len(point2segment) == 1:
+                rows = point2segment[0].to(torch.int64).contiguous()
+            else:
+                off, parts = 0, []
+                for p2s, csr in zip(point2segment, geo["seg_csr"]):
+                    parts.append(p2s.to(torch.int64) + off)
+                    off += csr.S
+                rows = torch.cat(parts).contiguous()
+                cm._usc_p2s_batched = rows
+            geo["p2s_rows"] = rows
+            _child_segment_table(cm, x._ts(), rows)
         cm.geometry = geo
         return geo
 
@@ -457,8 +470,14 @@ class Mask3D(nn.Module):
                     rows = torch.cat(parts).contiguous()
                     cm._usc_p2s_batched = rows          # geometry only: built once per batch
             for step in range(num_pooling_steps):
-                pooled = ops.avgpool_down2(pooled, cm.stride_map(ts)["nbr2"], row_of=rows if step == 0 else None,
-                                           threshold=step == num_pooling_steps - 1)
+                if step == 0:
+                    # child table -> segment rows, folded once per batch (geometry only): the kernel then reads
+                    # child -> logits row in two dependent loads instead of three, in all 12 calls of the step
+                    pooled = ops.avgpool_down2(pooled, _child_segment_table(cm, ts, rows),
+                                               threshold=num_pooling_steps == 1)
+                else:
+                    pooled = ops.avgpool_down2(pooled, cm.stride_map(ts)["nbr2"],
+                                               threshold=step == num_pooling_steps - 1)
                 ts *= 2
             attn_mask = me.SparseTensor(features=pooled, coordinate_manager=cm,
                                         coordinate_map_key=ME.CoordinateMapKey(ts))
@@ -676,6 +695,19 @@ def _padded_index(n, size, device):
         midx[:n] = False
         hit = _PAD_CACHE[key] = (idx, midx)
     return hit
+
+
+def _child_segment_table(cm, ts, rows):
+    """i32[8, n_coarse]: for every coarse voxel the SEGMENT-TABLE rows of its (present) children, -1 where a child is
+    absent — `point2segment` folded into the k2/s2 child table of the map at tensor stride ts.  Cached on the coordinate
+    manager (one per batch; `rows` is the batch-wide row index into the stacked segment tables)."""
+    cache = cm.__dict__.setdefault("_usc_child_segments", {})
+    hit = cache.get(ts)
+    if hit is None or hit[0] != rows.data_ptr():
+        nbr2 = cm.stride_map(ts)["nbr2"]
+        tab = torch.where(nbr2 >= 0, rows.to(torch.int32)[nbr2.clamp(min=0).long()], nbr2).contiguous()
+        hit = cache[ts] = (rows.data_ptr(), tab, rows)
+    return hit[1]
 
 
 def _stack(tensors):

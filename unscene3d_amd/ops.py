@@ -617,12 +617,12 @@ def relu(x):
 # ------------------------------------------------------------------ pooling / gather / segments
 def avgpool_down2(feats, nbr2, row_of=None, threshold=False):
     """MinkowskiAvgPooling(kernel_size=2, stride=2) forward: mean over present children.
-    row_of (i64[n_fine]): the fine rows are feats[row_of[i]] (feats may be a column slice of a wider table);
+    row_of (i64[n_fine]): the fine rows are feats[row_of[i]] (feats may be a column slice of a wider table); a child
+    table that already holds the ROWS OF `feats` to read (row_of folded into nbr2 once per batch) needs no row_of;
     threshold: return sigmoid(mean) < 0.5 as bool instead of the means."""
     if feats.dtype != torch.float32 or not feats.is_cuda or feats.dim() != 2 or feats.stride(1) != 1:
         raise RuntimeError("avgpool_down2: feats must be an f32 HIP matrix with unit column stride")
-    if row_of is None and not feats.is_contiguous():
-        raise RuntimeError("avgpool_down2: feats must be contiguous")
+    # (a column slice of a wider table is fine either way: rows are addressed through the leading dimension)
     if row_of is not None:
         _chk(row_of, torch.int64, "row_of")
     nc, c = nbr2.shape[1], feats.shape[1]
