@@ -59,8 +59,14 @@ class _GraphedFn(torch.autograd.Function):
     def forward(ctx, runner, *inputs):
         runner.check_param_data()
         for s, a in zip(runner.static_in, inputs):
-            if s.data_ptr() != a.data_ptr():
-                s.copy_(a)
+            if s.data_ptr() == a.data_ptr():
+                continue                       # the producer wrote straight into the buffer (or it is the previous pass's output)
+            hold = getattr(s, "_usc_holds", None)
+            if hold is not None and hold[0] is a and hold[1] == a._version:
+                continue                       # a buffer SHARED by several passes already holds this very tensor
+            s.copy_(a)
+            if hold is not None:
+                s._usc_holds = (a, a._version)  # (keeps `a` alive: its storage cannot be handed to another tensor)
         runner.fwd_graph.replay()
         ctx.runner = runner
         return runner.static_out.detach()
@@ -94,10 +100,14 @@ class GraphedPass:
         return _GraphedFn.apply(self._runner, *inputs)
 
 
-def capture_passes(modules, sample_inputs, warmup_iters: int = 3):
+def capture_passes(modules, sample_inputs, warmup_iters: int = 3, shared_inputs=(), chain_input=None):
     """modules: callables (nn.Modules sharing parameters or not); sample_inputs: one tuple of tensors per module
     (requires_grad marks the inputs whose gradient is needed).  -> list of GraphedPass, replayed in the order
-    given for the forward direction and in reverse for the backward one (like the captured order)."""
+    given for the forward direction and in reverse for the backward one (like the captured order).
+    shared_inputs: input positions that receive the SAME tensor in every pass of a step (the decoder's `query_pos`):
+    the passes share one static buffer there and only the first replay of a step copies into it.
+    chain_input: input position that receives the PREVIOUS pass's output (the decoder's `queries`): pass k+1 reads
+    pass k's output buffer in place — no copy between consecutive replays."""
     assert len(modules) == len(sample_inputs)
     runners = []
     for m, smp in zip(modules, sample_inputs):
@@ -106,6 +116,13 @@ def capture_passes(modules, sample_inputs, warmup_iters: int = 3):
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         runners.append(_Runner(m, smp, params))
+    for j in shared_inputs:
+        first = runners[0].static_in[j]
+        first._usc_holds = (None, -1)
+        for r in runners[1:]:
+            if r.static_in[j].shape != first.shape or r.static_in[j].dtype != first.dtype:
+                raise RuntimeError("capture_passes: a shared input must have one shape in every pass")
+            r.static_in[j] = first
 
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
@@ -123,9 +140,16 @@ def capture_passes(modules, sample_inputs, warmup_iters: int = 3):
     pool = torch.cuda.graph_pool_handle()
     # all forward graphs first, then the backward graphs in reverse order: the pool's liveness during capture
     # then mirrors the liveness during a training step (fwd 0..n-1, bwd n-1..0)
+    prev = None
     for r in runners:
+        if chain_input is not None and prev is not None and prev.static_out.shape == r.static_in[chain_input].shape \
+                and prev.static_out.dtype == r.static_in[chain_input].dtype:
+            # a fresh leaf over the previous pass's output storage (same strides): replaying pass k then pass k+1 hands
+            # the queries over without a copy; any other tensor given at replay is copied into it as before
+            r.static_in[chain_input] = prev.static_out.detach().requires_grad_(r.static_in[chain_input].requires_grad)
         with torch.cuda.graph(r.fwd_graph, pool=pool, capture_error_mode=_CAPTURE_MODE):
             r.static_out = r.module(*r.static_in)
+        prev = r
     for r in reversed(runners):
         r.static_grad_out = torch.zeros_like(r.static_out)
         targets = [r.static_in[j] for j in r.grad_in_idx] + r.params

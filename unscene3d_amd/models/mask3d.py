@@ -141,7 +141,8 @@ class Mask3D(nn.Module):
                                 torch.zeros(B, K, Q, device=device, dtype=torch.bool),
                                 torch.zeros(B, K, d, device=device)))
         from ..graphs import capture_passes
-        graphed = capture_passes(passes, samples)
+        # query_pos (input 1) is one tensor for all passes of a step; the queries (input 0) are the previous pass's output
+        graphed = capture_passes(passes, samples, shared_inputs=(1,), chain_input=0)
         self._graph_shapes = [tuple(a.shape for a in smp) for smp in samples]
         object.__setattr__(self, "_graphed_passes", list(graphed))
 
