@@ -485,6 +485,11 @@ int usc_scatter_add_rows(const float* src, int32_t c, const int64_t* idx,
  * with a zeroed dst this is the backward of usc_gather_rows at gather bandwidth.  Duplicates would race. */
 int usc_scatter_rows_unique(const float* src, int32_t c, const int64_t* idx,
                             int64_t n, float* dst, usc_stream_t s);
+/* dst[idx[i],:] += src[i,:] for a duplicate-free index set: plain read-modify-write.  Several sampled subsets of one
+ * table (the three decoders' key samples of a level, models/mask3d.py:306-349: autograd sums their three scattered
+ * gradients) are accumulated launch after launch into ONE buffer instead of three zero-filled tensors and two adds. */
+int usc_scatter_rows_unique_add(const float* src, int32_t c, const int64_t* idx,
+                                int64_t n, float* dst, usc_stream_t s);
 
 /* The decoder's key sampling of one pass (reference models/mask3d.py:306-346: three row gathers by the sampled
  * indices, `attn[attn.sum(1) == K] = False`, `attn |= padding`), two launches:

@@ -1624,3 +1624,38 @@ def test_deferred_weight_gradients_equal_the_immediate_ones(device, monkeypatch)
     assert worst[0] < 1e-5, worst
     for n in res[True]:
         assert torch.equal(res[True][n], res["again"][n]), n
+
+
+@pytest.mark.parametrize("unique", [True, False])
+def test_sampled_key_gradients_through_one_sink(device, unique):
+    """Three key samples of one feature table (the three decoders' passes over a backbone level, reference
+    models/mask3d.py:306-349): with a shared ops.GradSink the table's gradient is accumulated in ONE buffer — bit-equal to
+    autograd's sum of the three scattered gradients; a consumer whose backward never runs is reported."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    n, c, q, K = 5000, 96, 100, 800
+    feats = torch.randn(n, c, generator=g).to(device)
+    mask = (torch.rand(n, q, generator=g) < 0.5).to(device)
+    idxs = [(torch.randperm(n, generator=g)[:K] if unique else torch.randint(0, n, (K,), generator=g)).to(device)
+            for _ in range(3)]
+    ws = [torch.randn(1, K, c, generator=g).to(device) for _ in range(3)]
+
+    def run(sink):
+        f = feats.clone().requires_grad_()
+        outs = [ops.sample_keys(f, mask, None, i, 1, K, [K], unique=unique, sink=sink)[0] for i in idxs]
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        return f.grad
+
+    ref = run(None)
+    got = run(ops.GradSink())
+    if unique:
+        assert torch.equal(got, ref)
+    else:                                   # float atomics: order-free only up to rounding when rows repeat
+        assert rel_err(got, ref) < 1e-6
+    sink = ops.GradSink()
+    f = feats.clone().requires_grad_()
+    a = ops.sample_keys(f, mask, None, idxs[0], 1, K, [K], unique=unique, sink=sink)[0]
+    ops.sample_keys(f, mask, None, idxs[1], 1, K, [K], unique=unique, sink=sink)          # never differentiated
+    with pytest.raises(RuntimeError, match="GradSink"):
+        a.sum().backward()

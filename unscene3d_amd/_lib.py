@@ -113,6 +113,7 @@ SIGNATURES = {
     "usc_gather_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_scatter_add_rows": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_scatter_rows_unique": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
+    "usc_scatter_rows_unique_add": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_sample_keys_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_sample_keys": (C.c_int, [_p, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p]),
     "usc_segment_csr_ws_bytes": (_i64, [_i64, _i64]),

@@ -722,6 +722,29 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
   }
 }
 
+// dst[idx[i], :] += src[i, :], duplicate-free index set: plain read-modify-write (launches on one stream are ordered, so
+// several sampled subsets of the same table may be accumulated one launch after the other without atomics)
+template <int VEC>
+__global__ __launch_bounds__(256) void scatter_rows_rmw_kernel(const float* __restrict__ src, int c,
+                                                              const int64_t* __restrict__ idx, int64_t n,
+                                                              float* __restrict__ dst) {
+  const int CT = c / VEC;
+  const int64_t total = n * CT;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = j / CT;
+    const int cg = (int)(j - r * CT);
+    const int64_t d = idx[r];
+    if (VEC == 4) {
+      float4* o = reinterpret_cast<float4*>(dst + d * c + cg * 4);
+      const float4 v = *reinterpret_cast<const float4*>(src + r * c + cg * 4);
+      const float4 t = *o;
+      *o = make_float4(t.x + v.x, t.y + v.y, t.z + v.z, t.w + v.w);
+    } else {
+      dst[d * c + cg] += src[r * c + cg];
+    }
+  }
+}
+
 // mode bit 0: use only rows with a non-zero entry; bit 1: per-channel MAX instead of the mean (N1 'max' mode)
 __global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* __restrict__ src, int c,
                                                               const int64_t* __restrict__ order,
@@ -1061,6 +1084,20 @@ int usc_scatter_rows_unique(const float* src, int32_t c, const int64_t* idx, int
     hipLaunchKernelGGL((usc::scatter_rows_kernel<1>), dim3(stream_grid(n * c, 256)), dim3(256), 0, as_stream(s), src, (int)c,
                        idx, n, dst);
   USC_CHECK_LAUNCH("usc_scatter_rows_unique");
+  return USC_OK;
+}
+
+int usc_scatter_rows_unique_add(const float* src, int32_t c, const int64_t* idx, int64_t n, float* dst, usc_stream_t s) {
+  USC_REQUIRE(c >= 1 && n >= 0, "usc_scatter_rows_unique_add: bad sizes");
+  if (n == 0) return USC_OK;
+  USC_REQUIRE(src && idx && dst, "usc_scatter_rows_unique_add: null pointer");
+  if (c % 4 == 0)
+    hipLaunchKernelGGL((usc::scatter_rows_rmw_kernel<4>), dim3(stream_grid(n * (c / 4), 256)), dim3(256), 0, as_stream(s),
+                       src, (int)c, idx, n, dst);
+  else
+    hipLaunchKernelGGL((usc::scatter_rows_rmw_kernel<1>), dim3(stream_grid(n * c, 256)), dim3(256), 0, as_stream(s), src,
+                       (int)c, idx, n, dst);
+  USC_CHECK_LAUNCH("usc_scatter_rows_unique_add");
   return USC_OK;
 }
 

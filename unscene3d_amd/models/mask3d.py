@@ -32,6 +32,7 @@ _PADDED_MASK_EMBED = os.environ.get("USC3D_PADDED_MASK_EMBED", "1") == "1"
 _LAZY_HOST_COPIES = os.environ.get("USC3D_LAZY_HOST_COPIES", "1") == "1"
 _FUSED_KEY_SAMPLING = os.environ.get("USC3D_FUSED_KEY_SAMPLING", "1") == "1"
 _GATHER_INTO_GRAPH_INPUTS = os.environ.get("USC3D_GATHER_INTO_GRAPH_INPUTS", "1") == "1"
+_GRAD_SINKS = os.environ.get("USC3D_GRAD_SINKS", "1") == "1"
 
 
 class Mask3D(nn.Module):
@@ -319,6 +320,7 @@ class Mask3D(nn.Module):
 
         predictions_class, predictions_mask = [], []
         p2s_arg = point2segment if self.train_on_segments else None
+        sinks = {}      # one gradient buffer per backbone level for the num_decoders key samples taken from it
         for decoder_counter in range(self.num_decoders):
             dec = 0 if self.shared_decoder else decoder_counter
             for i, hlevel in enumerate(self.hlevels):
@@ -369,7 +371,8 @@ class Mask3D(nn.Module):
                     batched_aux, batched_attn, batched_pos_enc = ops.sample_keys(
                         feats_l.contiguous(), attn_mask.F.contiguous(), pos_l.contiguous(), plan["gidx"], n_scenes,
                         curr_sample_size, [min(n, curr_sample_size) for n in sizes], outs=outs,
-                        unique=plan["all_sampled"])
+                        unique=plan["all_sampled"],
+                        sink=sinks.setdefault((hlevel, bool(plan["all_sampled"])), ops.GradSink()) if _GRAD_SINKS else None)
                 elif bufs is not None:
                     # ONE gather for the whole batch: rows of the level's feature / mask tables addressed by
                     # scene offset + sampled index, written into the [B, K, .] input buffers of the captured pass

@@ -669,9 +669,27 @@ def gather_rows(src, idx, out=None, unique=False):
     return _GatherRows.apply(src, idx, out, unique)
 
 
+class GradSink:
+    """One gradient buffer for SEVERAL consumers of the same table (the three decoders' key samples of a backbone
+    level): every consumer's backward accumulates its rows into `buf` (zero-filled by the first one to arrive) and hands
+    autograd None; the last one hands over the buffer.  Replaces one zero fill + scatter per consumer and autograd's
+    adds of the dense results (same per-row summation order: arrival order).  A consumer whose backward never runs would
+    leave the others' gradients stranded: checked when the backward pass ends."""
+
+    def __init__(self):
+        self.buf, self.pending, self.check_queued = None, 0, False
+
+    def _check(self):
+        self.check_queued = False
+        if self.pending != 0 and self.buf is not None:
+            self.buf = None
+            raise RuntimeError("GradSink: a consumer's backward did not run; the gradients accumulated for its table were "
+                               "not delivered (call the consumers without a shared sink)")
+
+
 class _SampleKeys(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, mask, pos, idx, n_scenes, K, n_valid, outs, unique):
+    def forward(ctx, feats, mask, pos, idx, n_scenes, K, n_valid, outs, unique, sink=None):
         c, q = feats.shape[1], mask.shape[1]
         p = 0 if pos is None else pos.shape[1]
         dev = feats.device
@@ -697,6 +715,9 @@ class _SampleKeys(torch.autograd.Function):
                                   _ptr(om), _ptr(op), _ptr(ws), ws.numel(), _stream()), "usc_sample_keys")
         ctx.save_for_backward(idx)
         ctx.n_src, ctx.unique = feats.shape[0], bool(unique)
+        ctx.sink = sink if (sink is not None and feats.requires_grad and torch.is_grad_enabled()) else None
+        if ctx.sink is not None:
+            ctx.sink.pending += 1
         ctx.mark_non_differentiable(om)
         if op is not None:
             ctx.mark_non_differentiable(op)
@@ -707,19 +728,36 @@ class _SampleKeys(torch.autograd.Function):
     def backward(ctx, dfeats, *_):
         (idx,) = ctx.saved_tensors
         dfeats = dfeats.contiguous().view(idx.shape[0], -1)
+        sink = ctx.sink
+        if sink is not None:
+            first = sink.buf is None
+            if first:
+                sink.buf = torch.zeros((ctx.n_src, dfeats.shape[1]), dtype=torch.float32, device=dfeats.device)
+                if not sink.check_queued:
+                    sink.check_queued = True
+                    torch.autograd.Variable._execution_engine.queue_callback(sink._check)
+            fn = (lib.usc_scatter_rows_unique if first else lib.usc_scatter_rows_unique_add) if ctx.unique \
+                else lib.usc_scatter_add_rows
+            check(fn(_ptr(dfeats), dfeats.shape[1], _ptr(idx), idx.shape[0], _ptr(sink.buf), _stream()), "usc_scatter_rows")
+            sink.pending -= 1
+            if sink.pending > 0:
+                return (None,) * 10
+            dsrc, sink.buf = sink.buf, None
+            return (dsrc,) + (None,) * 9
         dsrc = torch.zeros((ctx.n_src, dfeats.shape[1]), dtype=torch.float32, device=dfeats.device)
         fn = lib.usc_scatter_rows_unique if ctx.unique else lib.usc_scatter_add_rows
         check(fn(_ptr(dfeats), dfeats.shape[1], _ptr(idx), idx.shape[0], _ptr(dsrc), _stream()), "usc_scatter_add_rows")
-        return (dsrc,) + (None,) * 8
+        return (dsrc,) + (None,) * 9
 
 
-def sample_keys(feats, mask, pos, idx, n_scenes, K, n_valid, outs=None, unique=False):
+def sample_keys(feats, mask, pos, idx, n_scenes, K, n_valid, outs=None, unique=False, sink=None):
     """The cross-attention keys of one decoder pass (reference models/mask3d.py:306-346) in two launches:
     rows `idx` (i64[n_scenes*K], batch-wide row numbers) of the level's features f32[n,c], thresholded attention
     masks bool[n,Q] and positional encodings f32[n,p] (or None) -> ([B,K,c], bool[B,K,Q], [B,K,p]); a query column
     masked in all K rows of its scene is cleared; rows k >= n_valid[b] (padding) are fully masked.
     outs: the caller's three buffers (e.g. the inputs of a captured pass).  Gradient: features only (scatter;
-    `unique` as in gather_rows)."""
+    `unique` as in gather_rows).  sink: a GradSink shared by every call that samples the SAME `feats` in this forward
+    pass — their gradients are then accumulated into one buffer."""
     _chk(feats, torch.float32, "feats")
     _chk(mask, torch.bool, "mask")
     _chk(idx, torch.int64, "idx")
@@ -729,7 +767,7 @@ def sample_keys(feats, mask, pos, idx, n_scenes, K, n_valid, outs=None, unique=F
             raise RuntimeError("sample_keys: pos and feats must have the same rows")
     if mask.shape[0] != feats.shape[0] or idx.shape[0] != n_scenes * K or len(n_valid) != n_scenes:
         raise RuntimeError("sample_keys: inconsistent sizes")
-    return _SampleKeys.apply(feats, mask, pos, idx, int(n_scenes), int(K), list(n_valid), outs, unique)
+    return _SampleKeys.apply(feats, mask, pos, idx, int(n_scenes), int(K), list(n_valid), outs, unique, sink)
 
 
 def gather_rows_i32(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
