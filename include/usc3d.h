@@ -702,6 +702,14 @@ int usc_layernorm_bwd(const float* dy, const float* x, const float* mean,
                       int32_t d, float* dx, float* dgamma, float* dbeta,
                       int32_t accumulate, void* ws, int64_t ws_bytes,
                       usc_stream_t s);
+/* The same with dx = (LayerNorm's input gradient) + dx_add (f32[rows, d] or NULL): the gradient that reaches x AROUND
+ * the norm — `queries` feed `decoder_norm` inside mask_module AND the next decoder layer (models/mask3d.py:356-373,
+ * :410) — summed in this launch instead of by an autograd add. */
+int usc_layernorm_bwd_ex(const float* dy, const float* x, const float* mean,
+                         const float* rstd, const float* gamma, int64_t rows,
+                         int32_t d, const float* dx_add, float* dx, float* dgamma,
+                         float* dbeta, int32_t accumulate, void* ws,
+                         int64_t ws_bytes, usc_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Q1  furthest point sampling — replaces pointnet2._ext.furthest_point_sampling

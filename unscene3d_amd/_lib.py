@@ -169,6 +169,7 @@ SIGNATURES = {
     "usc_linear_bwd_ex2": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "usc_layernorm_bwd_ws_bytes": (_i64, [_i64, _i32]),
     "usc_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _i32, _p, _i64, _p]),
+    "usc_layernorm_bwd_ex": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _i32, _p, _i64, _p]),
     "usc_affine_rows": (C.c_int, [_p, _i32, _i64, _i32, _p, _p, _p]),
     "usc_colsum_sequential": (C.c_int, [_p, _i64, _i32, _i32, _p, _p]),
     "usc_col_sum_ws_bytes": (_i64, [_i64, _i32]),

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(const float* __rest
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ gamma, int64_t rows, int d,
                                                             int64_t rows_per_block, int accumulate,
-                                                            float* __restrict__ dx,
+                                                            const float* __restrict__ dx_add, float* __restrict__ dx,
                                                             float* __restrict__ part /* [G][2][d] or dgamma/dbeta */,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[16][2][64 * PER];
@@ -80,7 +80,11 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(const float* __rest
     s1 = wave_reduce_addf(s1) / (float)d;
     s2 = wave_reduce_addf(s2) / (float)d;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) dx[r * d + lane + 64 * j] = rs * (gy[j] - s1 - xh[j] * s2);
+    for (int j = 0; j < PER; ++j) {
+      const float v = rs * (gy[j] - s1 - xh[j] * s2);
+      // dx_add: the gradient that reaches x around the norm (a second consumer of x), summed here instead of by autograd
+      dx[r * d + lane + 64 * j] = dx_add ? v + dx_add[r * d + lane + 64 * j] : v;
+    }
   }
 #pragma unroll
   for (int j = 0; j < PER; ++j) { red[wave][0][lane + 64 * j] = dg[j]; red[wave][1][lane + 64 * j] = db[j]; }
@@ -151,12 +155,18 @@ int64_t usc_layernorm_bwd_ws_bytes(int64_t rows, int32_t d) {
 int usc_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       int64_t rows, int32_t d, float* dx, float* dgamma, float* dbeta, int32_t accumulate, void* ws,
                       int64_t ws_bytes, usc_stream_t s) {
+  return usc_layernorm_bwd_ex(dy, x, mean, rstd, gamma, rows, d, nullptr, dx, dgamma, dbeta, accumulate, ws, ws_bytes, s);
+}
+
+int usc_layernorm_bwd_ex(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                         int64_t rows, int32_t d, const float* dx_add, float* dx, float* dgamma, float* dbeta,
+                         int32_t accumulate, void* ws, int64_t ws_bytes, usc_stream_t s) {
   USC_REQUIRE(rows >= 1 && d >= 64 && d % 64 == 0 && d <= 64 * kLnMaxPerLane, "usc_layernorm_bwd: bad sizes");
   USC_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "usc_layernorm_bwd: null pointer");
   const int64_t G = ceil_div(rows, kLnRowsPerBlock);
   USC_REQUIRE(G == 1 || (ws && ws_bytes >= G * 2 * d * 4), "usc_layernorm_bwd: workspace too small");
   hipStream_t st = as_stream(s);
-#define USC_LN_B(P) hipLaunchKernelGGL((layernorm_bwd_kernel<P>), dim3((unsigned)G), dim3(1024), 0, st, dy, x, mean, rstd, gamma, rows, (int)d, kLnRowsPerBlock, (int)accumulate, dx, (float*)ws, dgamma, dbeta)
+#define USC_LN_B(P) hipLaunchKernelGGL((layernorm_bwd_kernel<P>), dim3((unsigned)G), dim3(1024), 0, st, dy, x, mean, rstd, gamma, rows, (int)d, kLnRowsPerBlock, (int)accumulate, dx_add, dx, (float*)ws, dgamma, dbeta)
   switch (d / 64) {
     case 1: USC_LN_B(1); break;  case 2: USC_LN_B(2); break;  case 3: USC_LN_B(3); break;  case 4: USC_LN_B(4); break;
     case 6: USC_LN_B(6); break;  case 8: USC_LN_B(8); break;

@@ -33,6 +33,7 @@ _LAZY_HOST_COPIES = os.environ.get("USC3D_LAZY_HOST_COPIES", "1") == "1"
 _FUSED_KEY_SAMPLING = os.environ.get("USC3D_FUSED_KEY_SAMPLING", "1") == "1"
 _GATHER_INTO_GRAPH_INPUTS = os.environ.get("USC3D_GATHER_INTO_GRAPH_INPUTS", "1") == "1"
 _GRAD_SINKS = os.environ.get("USC3D_GRAD_SINKS", "1") == "1"
+_LN_PASSTHROUGH = os.environ.get("USC3D_LN_PASSTHROUGH", "1") == "1"
 
 
 class Mask3D(nn.Module):
@@ -324,9 +325,10 @@ class Mask3D(nn.Module):
         for decoder_counter in range(self.num_decoders):
             dec = 0 if self.shared_decoder else decoder_counter
             for i, hlevel in enumerate(self.hlevels):
+                normed, queries = self._norm_queries(queries)
                 output_class, outputs_mask, attn_mask = self.mask_module(
                     queries, mask_features, mask_segments, len(aux) - hlevel - 1, ret_attn_mask=True,
-                    point2segment=p2s_arg, coords=coords, defer_class=True)
+                    point2segment=p2s_arg, coords=coords, defer_class=True, normed=normed)
 
                 decomposed_aux = aux[hlevel].decomposed_features
                 decomposed_attn = attn_mask.decomposed_features
@@ -427,9 +429,20 @@ class Mask3D(nn.Module):
             "backbone_features": pcd_features,
         }
 
+    def _norm_queries(self, queries):
+        """decoder_norm(queries) for mask_module AND the queries for the next decoder layer as outputs of ONE autograd
+        node: the gradient that comes back from the layer is then summed inside the norm's backward launch
+        (ops.layer_norm(passthrough=True)) instead of by an autograd add per pass -> (normed, queries)."""
+        norm = self.decoder_norm
+        if (_LN_PASSTHROUGH and queries.is_cuda and queries.dtype == torch.float32 and queries.requires_grad
+                and isinstance(norm, LayerNorm) and norm.elementwise_affine and norm.bias is not None
+                and len(norm.normalized_shape) == 1 and norm.normalized_shape[0] in ops._LN_DIMS):
+            return ops.layer_norm(queries, norm.weight, norm.bias, norm.eps, passthrough=True)
+        return norm(queries), queries
+
     def mask_module(self, query_feat, mask_features, mask_segments, num_pooling_steps, ret_attn_mask=True,
-                    point2segment=None, coords=None, defer_class=False):
-        query_feat = self.decoder_norm(query_feat)
+                    point2segment=None, coords=None, defer_class=False, normed=None):
+        query_feat = self.decoder_norm(query_feat) if normed is None else normed
         head = self.mask_embed_head
         Q = query_feat.shape[-2]
         q_pad = (-Q) % 32

@@ -715,7 +715,7 @@ class _SampleKeys(torch.autograd.Function):
                                   _ptr(om), _ptr(op), _ptr(ws), ws.numel(), _stream()), "usc_sample_keys")
         ctx.save_for_backward(idx)
         ctx.n_src, ctx.unique = feats.shape[0], bool(unique)
-        ctx.sink = sink if (sink is not None and feats.requires_grad and torch.is_grad_enabled()) else None
+        ctx.sink = sink if (sink is not None and ctx.needs_input_grad[0]) else None     # (forward runs under no_grad)
         if ctx.sink is not None:
             ctx.sink.pending += 1
         ctx.mark_non_differentiable(om)
@@ -897,7 +897,7 @@ _LN_DIMS = {64, 128, 192, 256, 384, 512}
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, passthrough=False):
         d = x.shape[-1]
         x2 = x.contiguous().view(-1, d)
         rows = x2.shape[0]
@@ -909,13 +909,18 @@ class _LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x2, weight, mean, rstd)
         ctx.shape = x.shape
         ctx.w_param, ctx.b_param = weight, bias
-        return y.view(x.shape)
+        # passthrough: x comes back as a second output; the gradient that arrives there (x's other consumer) is summed
+        # inside the backward launch (usc_layernorm_bwd_ex: dx_add) instead of by a separate autograd add
+        return (y.view(x.shape), x) if passthrough else y.view(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x2, weight, mean, rstd = ctx.saved_tensors
         rows, d = x2.shape
+        if dy is None:                                  # only the passthrough output was used
+            return (None if dpass is None else dpass), None, None, None, None
         dy2 = dy.contiguous().view(rows, d)
+        dadd = None if dpass is None else dpass.contiguous().view(rows, d)
         dx = torch.empty_like(x2)
         tg, tb = _grad_target(ctx.w_param), _grad_target(ctx.b_param)
         in_place = tg is not None and tb is not None
@@ -923,13 +928,13 @@ class _LayerNorm(torch.autograd.Function):
         dbeta = tb if in_place else torch.empty_like(weight)
         wsb = lib.usc_layernorm_bwd_ws_bytes(rows, d)
         ws = _ws(wsb, x2.device) if wsb > 0 else None
-        check(lib.usc_layernorm_bwd(_ptr(dy2), _ptr(x2), _ptr(mean), _ptr(rstd), _ptr(weight), rows, d, _ptr(dx),
-                                    _ptr(dgamma), _ptr(dbeta), int(in_place), _ptr(ws), wsb, _stream()),
+        check(lib.usc_layernorm_bwd_ex(_ptr(dy2), _ptr(x2), _ptr(mean), _ptr(rstd), _ptr(weight), rows, d, _ptr(dadd),
+                                       _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(in_place), _ptr(ws), wsb, _stream()),
               "usc_layernorm_bwd")
         if in_place:
             dgamma = dbeta = None
             _grad_written(ctx.w_param, ctx.b_param)
-        return dx.view(ctx.shape), dgamma, dbeta, None
+        return dx.view(ctx.shape), dgamma, dbeta, None, None
 
 
 class _AddLayerNorm(torch.autograd.Function):
@@ -953,7 +958,7 @@ class _AddLayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dx, dgamma, dbeta, _ = _LayerNorm.backward(ctx, dy)
+        dx, dgamma, dbeta, _, _ = _LayerNorm.backward(ctx, dy)
         return dx, dx, dgamma, dbeta, None
 
 
@@ -966,13 +971,15 @@ def add_layer_norm(x, res, weight, bias, eps=1e-5):
     return _AddLayerNorm.apply(x, res, weight, bias, eps)
 
 
-def layer_norm(x, weight, bias, eps=1e-5):
-    """F.layer_norm over the last dimension through the HIP kernels (f32, contiguous weight/bias, d in _LN_DIMS)."""
+def layer_norm(x, weight, bias, eps=1e-5, passthrough=False):
+    """F.layer_norm over the last dimension through the HIP kernels (f32, contiguous weight/bias, d in _LN_DIMS).
+    passthrough: -> (y, x'), x' = x as an output of the same autograd node: hand it to x's OTHER consumer and that
+    consumer's gradient is summed inside this norm's backward launch."""
     _chk(weight, torch.float32, "weight")
     _chk(bias, torch.float32, "bias")
     if x.dtype != torch.float32 or not x.is_cuda or x.shape[-1] not in _LN_DIMS:
         raise RuntimeError(f"layer_norm: needs an f32 HIP tensor with last dim in {sorted(_LN_DIMS)}")
-    return _LayerNorm.apply(x, weight, bias, eps)
+    return _LayerNorm.apply(x, weight, bias, eps, passthrough)
 
 
 # linear layers with at most this many rows go to the tile-per-workgroup kernels of decoder.hip (the 100 queries; the
