@@ -447,7 +447,12 @@ class Mask3D(nn.Module):
         Q = query_feat.shape[-2]
         q_pad = (-Q) % 32
         if query_feat.is_cuda and query_feat.dtype == torch.float32:      # Linear + ReLU in one launch
-            hidden = ops.linear(query_feat, head[0].weight, head[0].bias, relu=True)
+            if defer_class and _RESIDUAL_IN_PROJECTION and query_feat.requires_grad:
+                # the normalised queries feed the mask head AND the class head: routed through the first projection's
+                # node, the class head's gradient is summed inside that projection's input-gradient launch
+                hidden, query_feat = ops.linear(query_feat, head[0].weight, head[0].bias, relu=True, passthrough=True)
+            else:
+                hidden = ops.linear(query_feat, head[0].weight, head[0].bias, relu=True)
             if (q_pad and _PADDED_MASK_EMBED and query_feat.dim() == 3 and query_feat.shape[0] == 1
                     and isinstance(head[2], Linear) and head[2].out_features % 32 == 0):
                 # one scene: the embeddings come out zero-extended to a multiple of 32 rows (what the logits product
