@@ -815,6 +815,62 @@ __global__ __launch_bounds__(1024) void tri_backtransform_kernel(TriState t, con
   for (int64_t r = tid; r < n; r += 1024) x[r] = z[r] / sqrt(deg[r]);
 }
 
+// The same on ONE wave for n <= 64 * PER (round 4): z lives in registers (element lane + 64 j), the next reflector's
+// vector and tau are in flight while the current one is applied, the dot product is one wave reduction — no LDS, no
+// workgroup barrier (the 1 024-thread form above spends ~1 us per reflector in three barriers and a global round trip
+// of z: 0.66 ms of a 5.6 ms solve at n = 625; this form ~0.1 ms).  Same reflectors in the same order; the dot
+// products are summed in a different order (last-bit differences in the eigenvector).
+template <int PER>
+__global__ __launch_bounds__(64) void tri_backtransform_wave_kernel(TriState t, const double* __restrict__ deg,
+                                                                   const double* __restrict__ z, double* __restrict__ x) {
+  const int lane = threadIdx.x;
+  const int64_t n = t.n;
+  double zr[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int64_t r = lane + 64 * j;
+    zr[j] = r < n ? z[r] : 0.0;
+  }
+  // kBtDepth reflectors in flight (a reflector's 8 * n bytes come from L2 / HBM at ~1-2 us; applying one takes ~0.1 us)
+  constexpr int D = PER <= 8 ? 8 : 6;
+  double v[D][PER], tau[D];
+  auto load = [&](int64_t i, double (&vv)[PER], double& tt) __attribute__((always_inline)) {
+    if (i < 0) { tt = 0.0; return; }             // wave-uniform
+    const double* vp = t.Vt + i * n;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int64_t r = lane + 64 * j;
+      vv[j] = (r > i && r < n) ? vp[r] : 0.0;
+    }
+    tt = t.tau[i];
+  };
+  auto apply = [&](const double (&vv)[PER], double tt) __attribute__((always_inline)) {
+    if (tt == 0.0) return;                       // wave-uniform
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) dot += vv[j] * zr[j];
+    dot = wave_reduce_addd(dot);
+    const double f = tt * dot;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) zr[j] -= f * vv[j];
+  };
+  int64_t i = n - 2;
+#pragma unroll
+  for (int q = 0; q < D; ++q) load(i - q, v[q], tau[q]);
+  for (; i >= 0; i -= D) {
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+      apply(v[q], tau[q]);
+      load(i - D - q, v[q], tau[q]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int64_t r = lane + 64 * j;
+    if (r < n) x[r] = zr[j] / sqrt(deg[r]);
+  }
+}
+
 // One-launch tridiagonalisation when the co-resident grid and its LDS fit; false -> caller runs the stepwise path.
 // USC3D_TRI_STEPWISE=1 forces the stepwise path (A/B measurements).
 static bool launch_persistent(const TriState& t, double* tail, hipStream_t st) {
@@ -937,7 +993,17 @@ int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double e
                        (const double*)t.e, S, 1, eval, z, work);
   else
     hipLaunchKernelGGL(tri_eig_kernel<0>, dim3(1), dim3(128), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
-  hipLaunchKernelGGL(tri_backtransform_kernel, dim3(1), dim3(1024), 0, st, t, deg, z, evec);
+  static const bool bt_wave = !(getenv("USC3D_BACKTRANSFORM_WAVE") && getenv("USC3D_BACKTRANSFORM_WAVE")[0] == '0');
+  if (bt_wave && S <= 256)
+    hipLaunchKernelGGL(tri_backtransform_wave_kernel<4>, dim3(1), dim3(64), 0, st, t, deg, (const double*)z, evec);
+  else if (bt_wave && S <= 512)
+    hipLaunchKernelGGL(tri_backtransform_wave_kernel<8>, dim3(1), dim3(64), 0, st, t, deg, (const double*)z, evec);
+  else if (bt_wave && S <= 704)
+    hipLaunchKernelGGL(tri_backtransform_wave_kernel<11>, dim3(1), dim3(64), 0, st, t, deg, (const double*)z, evec);
+  else if (bt_wave && S <= 1024)
+    hipLaunchKernelGGL(tri_backtransform_wave_kernel<16>, dim3(1), dim3(64), 0, st, t, deg, (const double*)z, evec);
+  else
+    hipLaunchKernelGGL(tri_backtransform_kernel, dim3(1), dim3(1024), 0, st, t, deg, z, evec);
   USC_CHECK_LAUNCH("usc_ncut_fiedler");
   return USC_OK;
 }
