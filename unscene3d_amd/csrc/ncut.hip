@@ -849,7 +849,7 @@ __global__ __launch_bounds__(64) void tri_backtransform_wave_kernel(TriState t, 
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) dot += vv[j] * zr[j];
-    dot = wave_reduce_addd(dot);
+    dot = wave_sum_dpp(dot);                     // (ds_bpermute butterflies: 12 LDS-crossbar trips per reflector)
     const double f = tt * dot;
 #pragma unroll
     for (int j = 0; j < PER; ++j) zr[j] -= f * vv[j];
