@@ -666,12 +666,12 @@ __device__ inline int sturm_count(const double* d, const double* e, int64_t n, d
 // LDS = 1: the tridiagonal (d, e), the LU work arrays and the iterate live in LDS (n <= kEigLdsMax) — the bisection and
 // above all the single-lane inverse iteration are chains of dependent loads, ~10 k of them per call: 4.3 ms of a
 // 12 ms solve from global memory.
-constexpr int64_t kEigLdsMax = 1000;
+constexpr int64_t kEigLdsMax = 900;     // 9 n doubles of LDS (64 KB without an attribute)
 template <int LDS>
 __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__ d_g, const double* __restrict__ e_g, int64_t n,
                                                     int k, double* __restrict__ eval_out /*[2]*/,
                                                     double* __restrict__ z_g /*[n]*/, double* __restrict__ work_g /*[5n]*/) {
-  extern __shared__ double eig_sh[];   // LDS: d[n] e[n] z[n] work[5n]
+  extern __shared__ double eig_sh[];   // LDS: d[n] e[n] z[n] work[5n] zprev[n]
   // two waves: wave 0 bisects eigenvalue #k and goes straight on to its eigenvector, wave 1 bisects #k+1 (only
   // reported) at the same time — the two bisections are independent chains of 14 x n dependent divisions
   const int lane = threadIdx.x & 63, which = threadIdx.x >> 6;
@@ -679,12 +679,13 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
   const double* e = e_g;
   double* z = z_g;
   double* work = work_g;
+  double* zprev = work_g + 5 * n;      // (global form: the tridiagonalisation's exchange slots behind the work arrays, free by now)
   if (LDS) {
     double* dl_ = eig_sh;
     double* el_ = eig_sh + n;
     for (int64_t j = threadIdx.x; j < n; j += 128) { dl_[j] = d_g[j]; el_[j] = j < n - 1 ? e_g[j] : 0.0; }
     __syncthreads();
-    d = dl_; e = el_; z = eig_sh + 2 * n; work = eig_sh + 3 * n;
+    d = dl_; e = el_; z = eig_sh + 2 * n; work = eig_sh + 3 * n; zprev = eig_sh + 8 * n;
   }
   // Gershgorin interval
   double lo = 1e300, hi = -1e300;
@@ -706,6 +707,8 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
       const double na = first == 0 ? a : a + (b - a) * (double)first / 65.0;
       const double nb = first == 64 ? b : a + (b - a) * (double)(first + 1) / 65.0;
       a = na; b = nb;
+      // 65^9 > 2^53: the bracket reaches neighbouring doubles after nine rounds; further rounds cannot move it
+      if (b - a <= 4.5e-16 * fmax(fabs(a), fabs(b))) break;      // (a, b are wave-uniform)
     }
     lam = 0.5 * (a + b);
   }
@@ -773,8 +776,25 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
     }
     nrm = __shfl(nrm, 0, 64);
     USC_WAVE_SYNC();
-    for (int64_t j = lane; j < n; j += 64) z[j] /= nrm;
+    // normalise; the iteration has converged when the normalised iterate repeats (up to sign) to 1e-14 of its largest
+    // entry — with the shift at the eigenvalue that takes two or three sweeps; the remaining ones of the fixed six only
+    // reproduced the same vector (each sweep is ~3 n dependent LDS round trips on one lane: 0.15 ms at n = 625)
+    double dmax = 0.0, smax = 0.0, zmax = 0.0;
+    for (int64_t j = lane; j < n; j += 64) {
+      const double zn = z[j] / nrm, zp = zprev[j];
+      dmax = fmax(dmax, fabs(zn - zp));
+      smax = fmax(smax, fabs(zn + zp));
+      zmax = fmax(zmax, fabs(zn));
+      z[j] = zn;
+      zprev[j] = zn;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      dmax = fmax(dmax, __shfl_xor(dmax, o, 64));
+      smax = fmax(smax, __shfl_xor(smax, o, 64));
+      zmax = fmax(zmax, __shfl_xor(zmax, o, 64));
+    }
     USC_WAVE_SYNC();
+    if (it >= 1 && fmin(dmax, smax) <= 1e-14 * zmax) break;      // wave-uniform
   }
   int flip = 0;
   if (lane == 0) {
@@ -989,7 +1009,7 @@ int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double e
     hipLaunchKernelGGL(tri_last_diag_kernel, dim3(1), dim3(64), 0, st, t);
   }
   if (S <= kEigLdsMax)
-    hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(128), (size_t)S * 8 * sizeof(double), st, (const double*)t.d,
+    hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(128), (size_t)S * 9 * sizeof(double), st, (const double*)t.d,
                        (const double*)t.e, S, 1, eval, z, work);
   else
     hipLaunchKernelGGL(tri_eig_kernel<0>, dim3(1), dim3(128), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
