@@ -680,30 +680,86 @@ __device__ inline int sturm_count(const double* d, const double* e, int64_t n, d
   return cnt;
 }
 
+// The same count from the determinant recurrence  p_j = (d_j - x) p_{j-1} - e_{j-1}^2 p_{j-2}  (q_j = p_j / p_{j-1}): the
+// dependent chain of a step is ONE fma instead of an f64 division (~10 dependent instructions) — a bisection round over
+// n = 625 drops from ~55 us to ~10 us.  p is rescaled by a power of two every four steps (exact; growth per step is
+// bounded by |d - x| + e^2, shrinkage by cancellation).  An exact zero (the ratio form's q = 0 -> 1e-300 rule) or a
+// non-finite value sends the lane to the ratio form; neither happens on real Laplacians.
+__device__ inline int sturm_count_fast(const double* d, const double* e, const double* e2, int64_t n, double x) {
+  double p0 = 1.0, p1 = d[0] - x;
+  int cnt = p1 < 0.0;
+  bool bad = p1 == 0.0;
+  int64_t j = 1;
+  for (; j + 4 <= n; j += 4) {
+    double dj[4], ej[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { dj[u] = d[j + u]; ej[u] = e2[j + u - 1]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double p2 = (dj[u] - x) * p1 - ej[u] * p0;
+      cnt += (int)(((unsigned)__double2hiint(p2) ^ (unsigned)__double2hiint(p1)) >> 31);
+      bad |= p2 == 0.0;
+      p0 = p1; p1 = p2;
+    }
+    int ex0, ex1;
+    (void)frexp(p0, &ex0);
+    (void)frexp(p1, &ex1);
+    const int ex = ex0 > ex1 ? ex0 : ex1;
+    p0 = ldexp(p0, -ex);
+    p1 = ldexp(p1, -ex);
+  }
+  for (; j < n; ++j) {
+    const double p2 = (d[j] - x) * p1 - e2[j - 1] * p0;
+    cnt += (int)(((unsigned)__double2hiint(p2) ^ (unsigned)__double2hiint(p1)) >> 31);
+    bad |= p2 == 0.0;
+    p0 = p1; p1 = p2;
+  }
+  bad |= !(fabs(p1) < 1.7e308);
+  if (bad) cnt = sturm_count(d, e, n, x);
+  return cnt;
+}
+
 // LDS = 1: the tridiagonal (d, e), the LU work arrays and the iterate live in LDS (n <= kEigLdsMax) — the bisection and
-// above all the single-lane inverse iteration are chains of dependent loads, ~10 k of them per call: 4.3 ms of a
-// 12 ms solve from global memory.
-constexpr int64_t kEigLdsMax = 900;     // 9 n doubles of LDS (64 KB without an attribute)
+// above all the single-lane recurrences of the inverse iteration are chains of dependent loads from global memory
+// otherwise: 4.3 ms of a 12 ms solve.
+// Round 4: every recurrence carries its state in registers and reads its operands eight steps at a time (a step used to
+// be an LDS store -> load round trip, ~130 cycles; the chains are now an fma or two), the back substitution multiplies by
+// reciprocals computed by all lanes, norm / arg-max / start vector are spread over the wave: 1.41 -> see DESIGN §5.
+constexpr int64_t kEigLdsMax = 800;     // 10 n doubles of LDS (64 KB without an attribute)
 template <int LDS>
 __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__ d_g, const double* __restrict__ e_g, int64_t n,
                                                     int k, double* __restrict__ eval_out /*[2]*/,
-                                                    double* __restrict__ z_g /*[n]*/, double* __restrict__ work_g /*[5n]*/) {
-  extern __shared__ double eig_sh[];   // LDS: d[n] e[n] z[n] work[5n] zprev[n]
+                                                    double* __restrict__ z_g /*[n]*/, double* __restrict__ work_g /*[7n]*/) {
+  extern __shared__ double eig_sh[];   // LDS: d[n] e[n] z[n] work[5n] zprev[n] e2[n]
   // two waves: wave 0 bisects eigenvalue #k and goes straight on to its eigenvector, wave 1 bisects #k+1 (only
-  // reported) at the same time — the two bisections are independent chains of 14 x n dependent divisions
+  // reported) at the same time
   const int lane = threadIdx.x & 63, which = threadIdx.x >> 6;
   const double* d = d_g;
   const double* e = e_g;
   double* z = z_g;
   double* work = work_g;
   double* zprev = work_g + 5 * n;      // (global form: the tridiagonalisation's exchange slots behind the work arrays, free by now)
+  double* e2 = work_g + 6 * n;
   if (LDS) {
     double* dl_ = eig_sh;
     double* el_ = eig_sh + n;
-    for (int64_t j = threadIdx.x; j < n; j += 128) { dl_[j] = d_g[j]; el_[j] = j < n - 1 ? e_g[j] : 0.0; }
+    e2 = eig_sh + 9 * n;
+    for (int64_t j = threadIdx.x; j < n; j += 128) {
+      const double ej = j < n - 1 ? e_g[j] : 0.0;
+      dl_[j] = d_g[j]; el_[j] = ej; e2[j] = ej * ej;
+    }
     __syncthreads();
     d = dl_; e = el_; z = eig_sh + 2 * n; work = eig_sh + 3 * n; zprev = eig_sh + 8 * n;
+  } else {
+    for (int64_t j = threadIdx.x; j < n; j += 128) { const double ej = j < n - 1 ? e_g[j] : 0.0; e2[j] = ej * ej; }
+    __syncthreads();
   }
+#ifdef USC_EIG_TIMING   // developer build: cycles per phase of wave 0, printed at the end
+  long long tph[6] = {0, 0, 0, 0, 0, 0}, tq0 = clock64(), tq1;
+#define EIG_MARK(i) do { tq1 = clock64(); tph[i] += tq1 - tq0; tq0 = tq1; } while (0)
+#else
+#define EIG_MARK(i) do {} while (0)
+#endif
   // Gershgorin interval
   double lo = 1e300, hi = -1e300;
   for (int64_t j = lane; j < n; j += 64) {
@@ -718,7 +774,7 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
     const int target = k + which;   // eigenvalue index (0-based): smallest x with count(x) > target
     for (int round = 0; round < 14; ++round) {
       const double x = a + (b - a) * (double)(lane + 1) / 65.0;
-      const int cnt = sturm_count(d, e, n, x);
+      const int cnt = sturm_count_fast(d, e, e2, n, x);
       const unsigned long long m = __ballot(cnt > target);   // lanes whose shift is above the eigenvalue
       const int first = m ? (__ffsll((long long)m) - 1) : 64;
       const double na = first == 0 ? a : a + (b - a) * (double)first / 65.0;
@@ -731,10 +787,11 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
   }
   if (lane == 0) eval_out[which] = lam;
   if (which != 0) return;
-  // ---- inverse iteration on wave 0.  The LU sweep, the two substitutions and the norm are recurrences (lane 0);
-  // everything element-wise (set-up, the 1/norm scaling with its n divisions per iteration, sign, copy-out) is spread
-  // over the 64 lanes with the same per-element arithmetic.  Lane 0's LDS/global writes are ordered against the other
-  // lanes' later reads by program order within the wave plus the waits below.
+  EIG_MARK(0);
+  // ---- inverse iteration on wave 0.  The LU sweep and the two substitutions are recurrences (lane 0); everything
+  // element-wise (set-up, reciprocals, norm, the 1/norm scaling, arg-max, sign, copy-out) is spread over the 64 lanes.
+  // Lane 0's LDS/global writes are ordered against the other lanes' later reads by program order within the wave plus
+  // the waits below.
 #define USC_WAVE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
   double tnorm = 0.0;
   for (int64_t j = lane; j < n; j += 64)
@@ -742,60 +799,117 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
   for (int o = 32; o > 0; o >>= 1) tnorm = fmax(tnorm, __shfl_xor(tnorm, o, 64));
   const double shift = lam;
   double* dl = work;            // sub-diagonal multipliers
-  double* dd = work + n;        // U diagonal
+  double* dd = work + n;        // U diagonal, then its reciprocal
   double* du = work + 2 * n;    // U first super-diagonal
   double* du2 = work + 3 * n;   // U second super-diagonal (from pivoting)
   double* piv = work + 4 * n;   // 1.0 if rows were swapped
-  // LU with partial pivoting of T - shift*I
+  // LU with partial pivoting of T - shift*I (dgttrf's elimination order)
   const double tiny = 2.3e-16 * fmax(tnorm, 1e-300);
-  for (int64_t j = lane; j < n; j += 64) { dd[j] = d[j] - shift; du[j] = (j < n - 1) ? e[j] : 0.0; du2[j] = 0.0; }
-  USC_WAVE_SYNC();
-  if (lane == 0) {
-    for (int64_t j = 0; j < n - 1; ++j) {
-      const double sub = e[j];
-      if (fabs(dd[j]) >= fabs(sub)) {
-        if (fabs(dd[j]) < tiny) dd[j] = tiny;
-        const double mlt = sub / dd[j];
-        dl[j] = mlt; piv[j] = 0.0;
-        dd[j + 1] -= mlt * du[j];
-      } else {
-        const double mlt = dd[j] / sub;
-        dl[j] = mlt; piv[j] = 1.0;
-        const double t1 = dd[j + 1];
-        dd[j] = sub;
-        dd[j + 1] = du[j] - mlt * t1;
-        du[j] = t1;
-        if (j < n - 2) { du2[j] = du[j + 1]; du[j + 1] = -mlt * du2[j]; }
-      }
-    }
-    if (fabs(dd[n - 1]) < tiny) dd[n - 1] = tiny;
-    // start vector: fixed pseudo-random in (-1,1)
-    unsigned long long st = 0x9E3779B97F4A7C15ull;
-    for (int64_t j = 0; j < n; ++j) {
-      st = st * 6364136223846793005ull + 1442695040888963407ull;
+  for (int64_t j = lane; j < n; j += 64) du2[j] = 0.0;
+  // start vector: fixed pseudo-random in (-1,1): z[j] from state j+1 of  st <- a st + c;  lane L jumps L+1 steps, then 64
+  {
+    const unsigned long long la = 6364136223846793005ull, lc = 1442695040888963407ull;
+    unsigned long long A = 1ull, Cc = 0ull;
+    for (int t = 0; t < 64; ++t)
+      if (t <= lane) { A = A * la; Cc = Cc * la + lc; }
+    const unsigned long long A64 = __shfl(A, 63, 64), C64 = __shfl(Cc, 63, 64);
+    unsigned long long st = A * 0x9E3779B97F4A7C15ull + Cc;
+    for (int64_t j = lane; j < n; j += 64) {
       z[j] = ((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0;
+      st = A64 * st + C64;
     }
   }
-  for (int it = 0; it < 6; ++it) {
-    double nrm = 0.0;
-    if (lane == 0) {
-      // forward: apply L^-1 with the recorded row swaps
-      for (int64_t j = 0; j < n - 1; ++j) {
-        if (piv[j] != 0.0) { const double tmp = z[j]; z[j] = z[j + 1]; z[j + 1] = tmp - dl[j] * z[j]; }
-        else z[j + 1] -= dl[j] * z[j];
+  USC_WAVE_SYNC();
+  EIG_MARK(1);
+  if (lane == 0) {
+    double ddj = d[0] - shift;                 // U diagonal of the row being eliminated
+    double duj = n > 1 ? e[0] : 0.0;           // its first super-diagonal
+    double sub = n > 1 ? e[0] : 0.0;           // sub-diagonal entry below it
+    double d_next = n > 1 ? d[1] - shift : 0.0, e_next = n > 2 ? e[1] : 0.0;
+    for (int64_t j = 0; j < n - 1; ++j) {
+      // operands of the NEXT step: independent of the chain, in flight during this step's division
+      const double d_nn = j + 2 < n ? d[j + 2] - shift : 0.0;
+      const double e_nn = j + 2 < n - 1 ? e[j + 2] : 0.0;
+      double ddn, dun;
+      if (fabs(ddj) >= fabs(sub)) {
+        if (fabs(ddj) < tiny) ddj = tiny;
+        const double mlt = sub / ddj;
+        dl[j] = mlt; piv[j] = 0.0; dd[j] = ddj; du[j] = duj;
+        ddn = d_next - mlt * duj;
+        dun = e_next;
+      } else {
+        const double mlt = ddj / sub;
+        dl[j] = mlt; piv[j] = 1.0; dd[j] = sub; du[j] = d_next;
+        ddn = duj - mlt * d_next;
+        dun = e_next;
+        if (j < n - 2) { du2[j] = e_next; dun = -mlt * e_next; }
       }
-      // backward: U x = z
-      z[n - 1] /= dd[n - 1];
-      if (n > 1) z[n - 2] = (z[n - 2] - du[n - 2] * z[n - 1]) / dd[n - 2];
-      for (int64_t j = n - 3; j >= 0; --j) z[j] = (z[j] - du[j] * z[j + 1] - du2[j] * z[j + 2]) / dd[j];
-      for (int64_t j = 0; j < n; ++j) nrm += z[j] * z[j];
-      nrm = sqrt(nrm);
+      ddj = ddn; duj = dun;
+      sub = e_next; d_next = d_nn; e_next = e_nn;
     }
-    nrm = __shfl(nrm, 0, 64);
+    if (fabs(ddj) < tiny) ddj = tiny;
+    dd[n - 1] = ddj; du[n - 1] = 0.0;
+  }
+  USC_WAVE_SYNC();
+  for (int64_t j = lane; j < n; j += 64) dd[j] = 1.0 / dd[j];
+  USC_WAVE_SYNC();
+  EIG_MARK(2);
+  for (int it = 0; it < 6; ++it) {
+    if (lane == 0) {
+      // forward: apply L^-1 with the recorded row swaps; zc = the entry carried down
+      double zc = z[0];
+      int64_t j = 0;
+      for (; j + 8 <= n - 1; j += 8) {
+        double zn[8], dlj[8], pj[8], out[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { zn[u] = z[j + u + 1]; dlj[u] = dl[j + u]; pj[u] = piv[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool sw = pj[u] != 0.0;
+          out[u] = sw ? zn[u] : zc;
+          const double other = sw ? zc : zn[u];
+          zc = other - dlj[u] * out[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z[j + u] = out[u];
+      }
+      for (; j < n - 1; ++j) {
+        const double zn = z[j + 1], dlj = dl[j];
+        const bool sw = piv[j] != 0.0;
+        const double out = sw ? zn : zc, other = sw ? zc : zn;
+        z[j] = out;
+        zc = other - dlj * out;
+      }
+      z[n - 1] = zc;
+      // backward: U x = z (dd holds the reciprocals)
+      double z1 = z[n - 1] * dd[n - 1], z2 = 0.0;     // x[j+1], x[j+2]
+      z[n - 1] = z1;
+      j = n - 2;
+      for (; j - 7 >= 0; j -= 8) {
+        double zj[8], duj[8], du2j[8], rj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { zj[u] = z[j - u]; duj[u] = du[j - u]; du2j[u] = du2[j - u]; rj[u] = dd[j - u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const double xj = (zj[u] - duj[u] * z1 - du2j[u] * z2) * rj[u];
+          z2 = z1; z1 = xj; zj[u] = xj;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z[j - u] = zj[u];
+      }
+      for (; j >= 0; --j) {
+        const double xj = (z[j] - du[j] * z1 - du2[j] * z2) * dd[j];
+        z2 = z1; z1 = xj; z[j] = xj;
+      }
+    }
     USC_WAVE_SYNC();
+    EIG_MARK(3);
+    double nrm = 0.0;
+    for (int64_t j = lane; j < n; j += 64) nrm += z[j] * z[j];
+    for (int o = 32; o > 0; o >>= 1) nrm += __shfl_xor(nrm, o, 64);
+    nrm = sqrt(nrm);
     // normalise; the iteration has converged when the normalised iterate repeats (up to sign) to 1e-14 of its largest
-    // entry — with the shift at the eigenvalue that takes two or three sweeps; the remaining ones of the fixed six only
-    // reproduced the same vector (each sweep is ~3 n dependent LDS round trips on one lane: 0.15 ms at n = 625)
+    // entry — with the shift at the eigenvalue that takes two or three sweeps
     double dmax = 0.0, smax = 0.0, zmax = 0.0;
     for (int64_t j = lane; j < n; j += 64) {
       const double zn = z[j] / nrm, zp = zprev[j];
@@ -811,19 +925,33 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
       zmax = fmax(zmax, __shfl_xor(zmax, o, 64));
     }
     USC_WAVE_SYNC();
+    EIG_MARK(4);
     if (it >= 1 && fmin(dmax, smax) <= 1e-14 * zmax) break;      // wave-uniform
   }
-  int flip = 0;
-  if (lane == 0) {
-    int64_t jmax = 0;
-    for (int64_t j = 1; j < n; ++j) if (fabs(z[j]) > fabs(z[jmax])) jmax = j;
-    flip = z[jmax] < 0.0;
+  // sign: the largest-magnitude component (first one on ties) is positive
+  double best = -1.0;
+  long long bj = 0;
+  for (int64_t j = lane; j < n; j += 64) {
+    const double a = fabs(z[j]);
+    if (a > best) { best = a; bj = j; }
   }
-  flip = __shfl(flip, 0, 64);
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ob = __shfl_xor(best, o, 64);
+    const long long oj = __shfl_xor(bj, o, 64);
+    if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+  }
+  const int flip = z[bj] < 0.0;
   for (int64_t j = lane; j < n; j += 64) {
     const double zj = flip ? -z[j] : z[j];
     if (LDS) z_g[j] = zj; else z[j] = zj;
   }
+  EIG_MARK(5);
+#ifdef USC_EIG_TIMING
+  if (lane == 0)
+    printf("eig timing: bisection %lld  setup %lld  lu %lld  sweeps %lld  normalise %lld  sign+copy %lld cycles (n=%d)\n", tph[0],
+           tph[1], tph[2], tph[3], tph[4], tph[5], (int)n);
+#endif
+#undef EIG_MARK
 #undef USC_WAVE_SYNC
 }
 
@@ -1026,7 +1154,7 @@ int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double e
     hipLaunchKernelGGL(tri_last_diag_kernel, dim3(1), dim3(64), 0, st, t);
   }
   if (S <= kEigLdsMax)
-    hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(128), (size_t)S * 9 * sizeof(double), st, (const double*)t.d,
+    hipLaunchKernelGGL(tri_eig_kernel<1>, dim3(1), dim3(128), (size_t)S * 10 * sizeof(double), st, (const double*)t.d,
                        (const double*)t.e, S, 1, eval, z, work);
   else
     hipLaunchKernelGGL(tri_eig_kernel<0>, dim3(1), dim3(128), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
