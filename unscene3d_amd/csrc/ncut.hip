@@ -682,25 +682,34 @@ __device__ inline int sturm_count(const double* d, const double* e, int64_t n, d
 
 // The same count from the determinant recurrence  p_j = (d_j - x) p_{j-1} - e_{j-1}^2 p_{j-2}  (q_j = p_j / p_{j-1}): the
 // dependent chain of a step is ONE fma instead of an f64 division (~10 dependent instructions) — a bisection round over
-// n = 625 drops from ~55 us to ~10 us.  p is rescaled by a power of two every four steps (exact; growth per step is
-// bounded by |d - x| + e^2, shrinkage by cancellation).  An exact zero (the ratio form's q = 0 -> 1e-300 rule) or a
-// non-finite value sends the lane to the ratio form; neither happens on real Laplacians.
+// n = 625 drops from ~55 us to ~10 us.  p is rescaled by a power of two (exact; growth per step is
+// bounded by |d - x| + e^2, shrinkage by cancellation); p rescaled every eight steps; a collapsed or non-finite chain
+// sends the lane to the ratio form (neither happens on real Laplacians).
 __device__ inline int sturm_count_fast(const double* d, const double* e, const double* e2, int64_t n, double x) {
   double p0 = 1.0, p1 = d[0] - x;
-  int cnt = p1 < 0.0;
-  bool bad = p1 == 0.0;
+  unsigned sg = (unsigned)__double2hiint(p1) >> 31;   // sign bits of p, newest in bit 0
+  int cnt = (int)sg;
   int64_t j = 1;
-  for (; j + 4 <= n; j += 4) {
-    double dj[4], ej[4];
+  double dj[8], ej[8];
+  if (j + 8 <= n) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { dj[u] = d[j + u]; ej[u] = e2[j + u - 1]; }
+    for (int u = 0; u < 8; ++u) { dj[u] = d[j + u]; ej[u] = e2[j + u - 1]; }
+  }
+  for (; j + 8 <= n; j += 8) {
+    double dc[8], ec[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const double p2 = (dj[u] - x) * p1 - ej[u] * p0;
-      cnt += (int)(((unsigned)__double2hiint(p2) ^ (unsigned)__double2hiint(p1)) >> 31);
-      bad |= p2 == 0.0;
+    for (int u = 0; u < 8; ++u) { dc[u] = dj[u]; ec[u] = ej[u]; }
+    if (j + 16 <= n) {      // operands of the next block: in flight during this block's chain
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { dj[u] = d[j + 8 + u]; ej[u] = e2[j + 8 + u - 1]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double p2 = (dc[u] - x) * p1 - ec[u] * p0;
+      sg = __builtin_amdgcn_alignbit(sg, (unsigned)__double2hiint(p2), 31);   // (sg << 1) | sign(p2)
       p0 = p1; p1 = p2;
     }
+    cnt += __popc((sg ^ (sg >> 1)) & 0xffu);      // sign changes among the last nine values
     int ex0, ex1;
     (void)frexp(p0, &ex0);
     (void)frexp(p1, &ex1);
@@ -711,11 +720,12 @@ __device__ inline int sturm_count_fast(const double* d, const double* e, const d
   for (; j < n; ++j) {
     const double p2 = (d[j] - x) * p1 - e2[j - 1] * p0;
     cnt += (int)(((unsigned)__double2hiint(p2) ^ (unsigned)__double2hiint(p1)) >> 31);
-    bad |= p2 == 0.0;
     p0 = p1; p1 = p2;
   }
-  bad |= !(fabs(p1) < 1.7e308);
-  if (bad) cnt = sturm_count(d, e, n, x);
+  // An exact zero in the middle of the chain gives the ratio form's count by itself (p_{j+1} = -e^2 p_{j-1}: one sign
+  // change over the two steps either way); what the product form cannot survive is p_j = p_{j-1} = 0 (a split
+  // matrix with x on an eigenvalue of the leading block) or an overflow — both stay visible at the end of the chain.
+  if ((p1 == 0.0 && p0 == 0.0) || !(fabs(p1) < 1.7e308)) cnt = sturm_count(d, e, n, x);
   return cnt;
 }
 
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
   double* piv = work + 4 * n;   // 1.0 if rows were swapped
   // LU with partial pivoting of T - shift*I (dgttrf's elimination order)
   const double tiny = 2.3e-16 * fmax(tnorm, 1e-300);
-  for (int64_t j = lane; j < n; j += 64) du2[j] = 0.0;
+  for (int64_t j = lane; j < n; j += 64) { du2[j] = 0.0; dd[j] = d[j] - shift; }   // (du2[n-1] is read by the back substitution)
   // start vector: fixed pseudo-random in (-1,1): z[j] from state j+1 of  st <- a st + c;  lane L jumps L+1 steps, then 64
   {
     const unsigned long long la = 6364136223846793005ull, lc = 1442695040888963407ull;
@@ -822,31 +832,32 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
   USC_WAVE_SYNC();
   EIG_MARK(1);
   if (lane == 0) {
-    double ddj = d[0] - shift;                 // U diagonal of the row being eliminated
-    double duj = n > 1 ? e[0] : 0.0;           // its first super-diagonal
-    double sub = n > 1 ? e[0] : 0.0;           // sub-diagonal entry below it
-    double d_next = n > 1 ? d[1] - shift : 0.0, e_next = n > 2 ? e[1] : 0.0;
-    for (int64_t j = 0; j < n - 1; ++j) {
-      // operands of the NEXT step: independent of the chain, in flight during this step's division
-      const double d_nn = j + 2 < n ? d[j + 2] - shift : 0.0;
-      const double e_nn = j + 2 < n - 1 ? e[j + 2] : 0.0;
-      double ddn, dun;
-      if (fabs(ddj) >= fabs(sub)) {
-        if (fabs(ddj) < tiny) ddj = tiny;
-        const double mlt = sub / ddj;
-        dl[j] = mlt; piv[j] = 0.0; dd[j] = ddj; du[j] = duj;
-        ddn = d_next - mlt * duj;
-        dun = e_next;
-      } else {
-        const double mlt = ddj / sub;
-        dl[j] = mlt; piv[j] = 1.0; dd[j] = sub; du[j] = d_next;
-        ddn = duj - mlt * d_next;
-        dun = e_next;
-        if (j < n - 2) { du2[j] = e_next; dun = -mlt * e_next; }
-      }
-      ddj = ddn; duj = dun;
-      sub = e_next; d_next = d_nn; e_next = e_nn;
+    // state carried down the rows: U diagonal and first super-diagonal of the row being eliminated
+    double ddj = dd[0], duj = n > 1 ? e[0] : 0.0;
+    auto E = [&](int64_t j) { return (LDS || j < n - 1) ? e[j] : 0.0; };   // (the LDS copy stores e[n-1] = 0)
+    auto lu_step = [&](int64_t j, double sub, double d_next, double e_next) {
+      // sub = e[j];  d_next = d[j+1] - shift;  e_next = e[j+1] (0 past the end)
+      const bool swap = !(fabs(ddj) >= fabs(sub));
+      const double ddc = (!swap && fabs(ddj) < tiny) ? tiny : ddj;
+      const double num = swap ? ddc : sub, den = swap ? sub : ddc;
+      const double mlt = num / den;
+      const double A = swap ? duj : d_next, B = swap ? d_next : duj;
+      const bool fill = swap && j < n - 2;
+      dl[j] = mlt; piv[j] = swap ? 1.0 : 0.0; dd[j] = den; du[j] = B; du2[j] = fill ? e_next : 0.0;
+      ddj = A - mlt * B;
+      duj = fill ? -mlt * e_next : e_next;
+    };
+    int64_t j = 0;
+    for (; j + 8 <= n - 1; j += 8) {
+      double sb[9], dn[8];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) sb[u] = E(j + u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dn[u] = dd[j + u + 1];     // d - shift, written by all lanes above
+#pragma unroll
+      for (int u = 0; u < 8; ++u) lu_step(j + u, sb[u], dn[u], sb[u + 1]);
     }
+    for (; j < n - 1; ++j) lu_step(j, E(j), dd[j + 1], E(j + 1));
     if (fabs(ddj) < tiny) ddj = tiny;
     dd[n - 1] = ddj; du[n - 1] = 0.0;
   }
@@ -854,6 +865,7 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
   for (int64_t j = lane; j < n; j += 64) dd[j] = 1.0 / dd[j];
   USC_WAVE_SYNC();
   EIG_MARK(2);
+  double prev_change = 0.0;
   for (int it = 0; it < 6; ++it) {
     if (lane == 0) {
       // forward: apply L^-1 with the recorded row swaps; zc = the entry carried down
@@ -926,7 +938,13 @@ __global__ __launch_bounds__(128) void tri_eig_kernel(const double* __restrict__
     }
     USC_WAVE_SYNC();
     EIG_MARK(4);
-    if (it >= 1 && fmin(dmax, smax) <= 1e-14 * zmax) break;      // wave-uniform
+    // (wave-uniform)  The shift is an eigenvalue to an ulp, so one sweep suppresses every other component by
+    // ~1e-16 / gap: a change <= 1e-11 means the iterate BEFORE this sweep was already that close, and this sweep took it
+    // to the noise floor (measured: 2.5e-13 after sweep 1, 9.4e-14 from then on — the old 1e-14 bar was never met
+    // and all six sweeps ran).  Second exit: the change has stopped shrinking.
+    const double change = fmin(dmax, smax);
+    if (it >= 1 && (change <= 1e-11 * zmax || (it >= 2 && change >= 0.25 * prev_change))) break;
+    prev_change = change;
   }
   // sign: the largest-magnitude component (first one on ties) is positive
   double best = -1.0;
