@@ -201,6 +201,27 @@ struct TriState {
   int64_t n;
 };
 
+// The sixteen wave sums of a reflector's squared norm, added as a balanced tree (four dependent adds instead of
+// fifteen), and the Householder scalars from them.  ||(alpha, x)|| is one square root of alpha^2 + |x|^2 — the
+// entries of a normalised Laplacian are <= 2 in magnitude, so the squares cannot overflow; sqrt(tot) followed by hypot
+// cost ~60 dependent f64 instructions on the critical path of every step.  Shared by the stepwise and the one-launch
+// kernels: both give the same T and reflectors bit for bit.
+__device__ inline double sum16_tree(const double* red) {
+  const double a0 = red[0] + red[1], a1 = red[2] + red[3], a2 = red[4] + red[5], a3 = red[6] + red[7];
+  const double a4 = red[8] + red[9], a5 = red[10] + red[11], a6 = red[12] + red[13], a7 = red[14] + red[15];
+  return ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+__device__ inline void householder_scalars(double alpha, double tot, double& beta, double& tau, double& scale) {
+  if (tot == 0.0) {
+    beta = alpha; tau = 0.0; scale = 0.0;
+  } else {
+    const double nrm = sqrt(alpha * alpha + tot);
+    beta = alpha >= 0.0 ? -nrm : nrm;     // -sign(alpha) * ||(alpha, x)||
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+}
+
 // Steps (1) + (2) in one launch: every workgroup recomputes the reflector of column i — bit for bit the reduction of
 // tri_reflector_kernel's single 1024-thread workgroup (each of the 256 threads plays four of its threads, the sixteen
 // wave sums are added in the same order) — keeps v in LDS and then forms its rows of p = C22 v, one wave per row.
@@ -223,19 +244,10 @@ __global__ __launch_bounds__(256) void tri_reflect_symv_kernel(TriState t, int64
   }
   __syncthreads();
   if (tid == 0) {
-    double tot = 0.0;
-    for (int k = 0; k < 16; ++k) tot += red[k];
+    const double tot = sum16_tree(red);
     const double alpha = col[(i + 1) * n + i];
-    const double xnorm = sqrt(tot);
     double beta, tau, scale;
-    if (xnorm == 0.0) {
-      beta = alpha; tau = 0.0; scale = 0.0;
-    } else {
-      const double nrm = hypot(alpha, xnorm);
-      beta = alpha >= 0.0 ? -nrm : nrm;     // -sign(alpha) * ||(alpha, x)||
-      tau = (beta - alpha) / beta;
-      scale = 1.0 / (alpha - beta);
-    }
+    householder_scalars(alpha, tot, beta, tau, scale);
     s_scale = scale;
     if (blockIdx.x == 0) {
       t.d[i] = col[i * n + i];
@@ -436,20 +448,10 @@ __global__ __launch_bounds__(256) void tri_persistent_kernel(TriPersist a) {
     __syncthreads();
     double tau, scale;
     {
-      double tot = 0.0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) tot += red[k];
+      const double tot = sum16_tree(red);
       const double alpha = piv[i + 1];
-      const double xnorm = sqrt(tot);
       double beta;
-      if (xnorm == 0.0) {
-        beta = alpha; tau = 0.0; scale = 0.0;
-      } else {
-        const double nrm = hypot(alpha, xnorm);
-        beta = alpha >= 0.0 ? -nrm : nrm;
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-      }
+      householder_scalars(alpha, tot, beta, tau, scale);
       if (g == 0 && tid == 0) {
         t.d[i] = piv[i];
         t.e[i] = beta;
@@ -1054,6 +1056,110 @@ __global__ __launch_bounds__(64) void tri_backtransform_wave_kernel(TriState t, 
   }
 }
 
+// Four reflectors per step on four waves (round 4, second form).  The one-wave kernel above is bound by what ONE wave
+// can keep in flight (the vmcnt counter stops at 63 loads = 33 KB; 3.1 MB of reflectors at ~2 us per round trip is
+// 0.2-0.3 ms however short the arithmetic is).  Here wave w owns the elements r = lane + 64 (w + 4 j): four waves have
+// four times the loads in flight, and the reflectors a = i, b = i-1, c = i-2, d = i-3 of a step are applied together —
+//   f_a = tau_a (v_a.z)                      f_b = tau_b (v_b.z - f_a v_a.v_b)
+//   f_c = tau_c (v_c.z - f_a v_a.v_c - f_b v_b.v_c)      f_d = ...            z -= f_a v_a + f_b v_b + f_c v_c + f_d v_d
+// (what H(d) H(c) H(b) H(a) z is, with the intermediate z's eliminated) — so the ten dot products of a step share ONE
+// reduction and one workgroup barrier instead of four dependent wave reductions.  Every wave forms the four factors
+// from the same partial sums in the same order.  Differences to the sequential form: rounding only.
+template <int PER>
+__global__ __launch_bounds__(256) void tri_backtransform_quad_kernel(TriState t, const double* __restrict__ deg,
+                                                                    const double* __restrict__ z, double* __restrict__ x) {
+  constexpr int W = 4, B = 4, ND = 10;     // waves, reflectors per step, dot products per step
+  constexpr int P = PER <= 2 ? 6 : 4;      // steps whose reflectors are in flight (P * B * PER loads per lane <= 60)
+  __shared__ double part[2][ND][4 * W];   // [slot][dot product][wave * 4 + row of 16 lanes]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = t.n;
+  double zr[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int64_t r = lane + 64 * (wave + W * j);
+    zr[j] = r < n ? z[r] : 0.0;
+  }
+  double v[P][B][PER], tau[P][B];
+  // reflectors are fetched strictly in descending order, one row pointer walking down Vt (a pointer per ring slot cost
+  // more scalar registers than there are: the first build spilled ~600 readlane / writelane pairs per step)
+  int rr[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { rr[j] = lane + 64 * (wave + W * j); if (rr[j] >= (int)n) rr[j] = -1; }
+  int inext = (int)n - 2;
+  const double* pnext = t.Vt + (int64_t)inext * n;
+  const double* tnext = t.tau + inext;
+  auto load = [&](double (&vv)[B][PER], double (&tt)[B]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < B; ++q) {
+      if (inext < 0) {                            // workgroup-uniform: past the first reflector
+        tt[q] = 0.0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) vv[q][j] = 0.0;
+      } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) vv[q][j] = rr[j] > inext ? pnext[rr[j]] : 0.0;
+        tt[q] = *tnext;
+      }
+      --inext; pnext -= n; --tnext;
+    }
+  };
+  int step = 0;
+  auto apply = [&](const double (&vv)[B][PER], const double (&tt)[B]) __attribute__((always_inline)) {
+    // dots 0-3: v_q.z;  4-9: v_a.v_b, v_a.v_c, v_a.v_d, v_b.v_c, v_b.v_d, v_c.v_d
+    double dsum[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k) dsum[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+#pragma unroll
+      for (int q = 0; q < B; ++q) dsum[q] += vv[q][j] * zr[j];
+      dsum[4] += vv[0][j] * vv[1][j]; dsum[5] += vv[0][j] * vv[2][j]; dsum[6] += vv[0][j] * vv[3][j];
+      dsum[7] += vv[1][j] * vv[2][j]; dsum[8] += vv[1][j] * vv[3][j]; dsum[9] += vv[2][j] * vv[3][j];
+    }
+    // sums over the rows of 16 lanes (four DPP levels, no scalar round trip); the 4 x 4 row sums of a dot product meet in LDS
+#pragma unroll
+    for (int k = 0; k < ND; ++k) dsum[k] = row16_sum(dsum[k]);
+    const int slot = step & 1;
+    if ((lane & 15) == 15) {
+#pragma unroll
+      for (int k = 0; k < ND; ++k) part[slot][k][wave * 4 + (lane >> 4)] = dsum[k];
+    }
+    __syncthreads();
+    // lane k < 10 adds the sixteen row sums of dot product k (balanced tree); the totals go round by readlane
+    double mine = 0.0;
+    if (lane < ND) {
+      const double* pk = part[slot][lane];
+      mine = (((pk[0] + pk[1]) + (pk[2] + pk[3])) + ((pk[4] + pk[5]) + (pk[6] + pk[7]))) +
+             (((pk[8] + pk[9]) + (pk[10] + pk[11])) + ((pk[12] + pk[13]) + (pk[14] + pk[15])));
+    }
+    double dt[ND];
+#pragma unroll
+    for (int k = 0; k < ND; ++k)
+      dt[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), k), __builtin_amdgcn_readlane(__double2loint(mine), k));
+    const double fa = tt[0] * dt[0];
+    const double fb = tt[1] * (dt[1] - fa * dt[4]);
+    const double fc = tt[2] * (dt[2] - fa * dt[5] - fb * dt[7]);
+    const double fd = tt[3] * (dt[3] - fa * dt[6] - fb * dt[8] - fc * dt[9]);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) zr[j] -= fa * vv[0][j] + fb * vv[1][j] + fc * vv[2][j] + fd * vv[3][j];
+    ++step;
+  };
+#pragma unroll
+  for (int q = 0; q < P; ++q) load(v[q], tau[q]);
+  for (int i = (int)n - 2; i >= 0; i -= B * P) {
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+      if (i - B * q >= 0) apply(v[q], tau[q]);     // workgroup-uniform
+      load(v[q], tau[q]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int64_t r = lane + 64 * (wave + W * j);
+    if (r < n) x[r] = zr[j] / sqrt(deg[r]);
+  }
+}
+
 // One-launch tridiagonalisation when the co-resident grid and its LDS fit; false -> caller runs the stepwise path.
 // USC3D_TRI_STEPWISE=1 forces the stepwise path (A/B measurements).
 static bool launch_persistent(const TriState& t, double* tail, hipStream_t st) {
@@ -1177,7 +1283,14 @@ int usc_ncut_fiedler(const uint8_t* Abin, const double* deg, int64_t S, double e
   else
     hipLaunchKernelGGL(tri_eig_kernel<0>, dim3(1), dim3(128), 0, st, (const double*)t.d, (const double*)t.e, S, 1, eval, z, work);
   static const bool bt_wave = !(getenv("USC3D_BACKTRANSFORM_WAVE") && getenv("USC3D_BACKTRANSFORM_WAVE")[0] == '0');
-  if (bt_wave && S <= 256)
+  static const bool bt_quad = !(getenv("USC3D_BACKTRANSFORM_QUAD") && getenv("USC3D_BACKTRANSFORM_QUAD")[0] == '0');
+  if (bt_quad && S <= 512)
+    hipLaunchKernelGGL(tri_backtransform_quad_kernel<2>, dim3(1), dim3(256), 0, st, t, deg, (const double*)z, evec);
+  else if (bt_quad && S <= 768)
+    hipLaunchKernelGGL(tri_backtransform_quad_kernel<3>, dim3(1), dim3(256), 0, st, t, deg, (const double*)z, evec);
+  else if (bt_quad && S <= 1024)
+    hipLaunchKernelGGL(tri_backtransform_quad_kernel<4>, dim3(1), dim3(256), 0, st, t, deg, (const double*)z, evec);
+  else if (bt_wave && S <= 256)
     hipLaunchKernelGGL(tri_backtransform_wave_kernel<4>, dim3(1), dim3(64), 0, st, t, deg, (const double*)z, evec);
   else if (bt_wave && S <= 512)
     hipLaunchKernelGGL(tri_backtransform_wave_kernel<8>, dim3(1), dim3(64), 0, st, t, deg, (const double*)z, evec);
