@@ -748,6 +748,13 @@ int usc_fourier_posenc(const float* xyz, int64_t n, const float* lo,
 int usc_ncut_similarity(const float* F, int64_t S, int32_t d,
                         int32_t cosine_mode, float* normed, float* sim,
                         usc_stream_t s);
+/* The same over F with the rows flagged in zero_rows (u8[S] or NULL) multiplied by 0 first: the features
+ * get_masked_affinity_matrix (unscene3d_pseudo_main.py:122-135) hands to the next iteration are
+ * `(1 - painting) * feats`, painting only grows, so iteration i sees the ORIGINAL features with the rows painted so
+ * far zeroed — formed inside the row normalisation instead of by four element-wise passes per iteration. */
+int usc_ncut_similarity_masked(const float* F, const uint8_t* zero_rows, int64_t S,
+                               int32_t d, int32_t cosine_mode, float* normed,
+                               float* sim, usc_stream_t s);
 /* In-place normalize_mat: A -= min(A[A != 0]) if any(A > 0); A[A < 0] = 0;
  * A /= max(A) + 1e-5.  ws >= 12288 bytes. */
 int usc_ncut_normalize_mat(float* A, int64_t S, void* ws, int64_t ws_bytes,

@@ -123,6 +123,7 @@ SIGNATURES = {
     "usc_segment_mean_nonzero": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _p, _p]),
     "usc_segment_max_nonzero": (C.c_int, [_p, _i32, _p, _p, _i64, _p, _p, _p]),
     "usc_ncut_similarity": (C.c_int, [_p, _i64, _i32, _i32, _p, _p, _p]),
+    "usc_ncut_similarity_masked": (C.c_int, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
     "usc_ncut_normalize_mat": (C.c_int, [_p, _i64, _p, _i64, _p]),
     "usc_ncut_binarize": (C.c_int, [_p, _p, _i64, _f32, _f64, _p, _p, _p, _p]),
     "usc_ncut_fiedler_ws_bytes": (_i64, [_i64]),

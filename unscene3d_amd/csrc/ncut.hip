@@ -19,22 +19,25 @@ namespace usc {
 
 // ---------------------------------------------------------------------------
 // similarity
-__global__ __launch_bounds__(256) void ncut_rownorm_kernel(const float* __restrict__ F, int64_t S, int d, int cosine_again,
-                                                          float* __restrict__ out) {
-  // F.normalize(p=2, eps=1e-12) [+ cosine_sim's own x / (||x|| + 1e-9)]; one wave per row
+__global__ __launch_bounds__(256) void ncut_rownorm_kernel(const float* __restrict__ F, const uint8_t* __restrict__ zero_rows,
+                                                          int64_t S, int d, int cosine_again, float* __restrict__ out) {
+  // F.normalize(p=2, eps=1e-12) [+ cosine_sim's own x / (||x|| + 1e-9)]; one wave per row.
+  // zero_rows: the rows get_masked_affinity_matrix has multiplied by (1 - painting) = 0 (reference :122-135) — the
+  // product is formed here (0 * f, sign and NaN behaviour included) instead of by a pass over the features per iteration
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= S) return;
+  const float keep = (zero_rows && zero_rows[r]) ? 0.f : 1.f;
   float ss = 0.f;
-  for (int c = lane; c < d; c += 64) { const float v = F[r * d + c]; ss += v * v; }
+  for (int c = lane; c < d; c += 64) { const float v = keep * F[r * d + c]; ss += v * v; }
   ss = wave_reduce_addf(ss);
   const float n1 = fmaxf(sqrtf(ss), 1e-12f);
   float ss2 = 0.f;
-  for (int c = lane; c < d; c += 64) { const float v = F[r * d + c] / n1; ss2 += v * v; }
+  for (int c = lane; c < d; c += 64) { const float v = keep * F[r * d + c] / n1; ss2 += v * v; }
   ss2 = wave_reduce_addf(ss2);
   const float n2 = sqrtf(ss2) + 1e-9f;
   for (int c = lane; c < d; c += 64) {
-    float v = F[r * d + c] / n1;
+    float v = keep * F[r * d + c] / n1;
     if (cosine_again) v = v / n2;
     out[r * d + c] = v;
   }
@@ -1214,9 +1217,14 @@ extern "C" {
 
 int usc_ncut_similarity(const float* F, int64_t S, int32_t d, int32_t cosine_mode, float* normed, float* sim,
                         usc_stream_t s) {
+  return usc_ncut_similarity_masked(F, nullptr, S, d, cosine_mode, normed, sim, s);
+}
+
+int usc_ncut_similarity_masked(const float* F, const uint8_t* zero_rows, int64_t S, int32_t d, int32_t cosine_mode,
+                               float* normed, float* sim, usc_stream_t s) {
   USC_REQUIRE(S >= 1 && d >= 1 && F && normed && sim, "usc_ncut_similarity: bad argument");
   hipStream_t st = as_stream(s);
-  hipLaunchKernelGGL(ncut_rownorm_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, st, F, S, (int)d,
+  hipLaunchKernelGGL(ncut_rownorm_kernel, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, st, F, zero_rows, S, (int)d,
                      (int)cosine_mode, normed);
   hipLaunchKernelGGL(ncut_gram_kernel, dim3((unsigned)ceil_div(S, 16), (unsigned)ceil_div(S, 16)), dim3(256), 0, st,
                      (const float*)normed, S, (int)d, sim);

@@ -20,13 +20,14 @@ from .._lib import check, lib
 max_number_of_instances = 20
 
 
-def _similarity(feats: torch.Tensor, cosine_mode: bool) -> torch.Tensor:
+def _similarity(feats: torch.Tensor, cosine_mode: bool, zero_rows=None) -> torch.Tensor:
     feats = feats.float().contiguous()
     S, d = feats.shape
     normed = torch.empty_like(feats)
     sim = torch.empty((S, S), dtype=torch.float32, device=feats.device)
-    check(lib.usc_ncut_similarity(feats.data_ptr(), S, d, int(cosine_mode), normed.data_ptr(), sim.data_ptr(),
-                                  ops._stream()), "usc_ncut_similarity")
+    check(lib.usc_ncut_similarity_masked(feats.data_ptr(), None if zero_rows is None else zero_rows.data_ptr(), S, d,
+                                         int(cosine_mode), normed.data_ptr(), sim.data_ptr(), ops._stream()),
+          "usc_ncut_similarity_masked")
     return sim
 
 
@@ -38,18 +39,21 @@ def normalize_mat(A: torch.Tensor, eps=1e-5) -> torch.Tensor:
     return A
 
 
-def get_affinity_matrix(feats, tau=0.15, eps=1e-5, normalize_sim=True, similarity_metric="cos", painting=None):
+def get_affinity_matrix(feats, tau=0.15, eps=1e-5, normalize_sim=True, similarity_metric="cos", painting=None,
+                        zero_rows=None):
     """-> (A u8[S,S] on the device with A_ij = 1 meaning affinity 1 and 0 meaning `eps`, deg f64[S]).
 
     Single modality: row-min-max normalised cosine similarity; tuple of two modalities: plain normalised
     Gram matrices, each passed through normalize_mat, averaged.  `painting` (bool[S]) applies the
-    reference's `A[painting] = eps; A[:, painting] = eps` (unscene3d :426-427) in the same launch."""
+    reference's `A[painting] = eps; A[:, painting] = eps` (unscene3d :426-427) in the same launch.
+    `zero_rows` (device u8[S]): rows of `feats` to read as `0 * row` — get_masked_affinity_matrix's product formed
+    inside the row normalisation (the cut loop passes the ORIGINAL features and the painting so far)."""
     if similarity_metric != "cos":
         raise NotImplementedError("only the cosine metric is used by the published pipeline")
     if isinstance(feats, tuple):
-        sims = [_similarity(f, cosine_mode=False) for f in feats]
+        sims = [_similarity(f, cosine_mode=False, zero_rows=zero_rows) for f in feats]
     else:
-        sims = [_similarity(feats, cosine_mode=True)]
+        sims = [_similarity(feats, cosine_mode=True, zero_rows=zero_rows)]
     if normalize_sim:
         for sm in sims:
             normalize_mat(sm)
@@ -57,7 +61,12 @@ def get_affinity_matrix(feats, tau=0.15, eps=1e-5, normalize_sim=True, similarit
     dev = sims[0].device
     A = torch.empty((S, S), dtype=torch.uint8, device=dev)
     deg = torch.empty(S, dtype=torch.float64, device=dev)
-    pb = None if painting is None else painting.to(device=dev, dtype=torch.uint8).contiguous()
+    if painting is None:
+        pb = None
+    elif painting.dtype == torch.uint8 and painting.device == dev and painting.is_contiguous():
+        pb = painting
+    else:
+        pb = painting.to(device=dev, dtype=torch.uint8).contiguous()
     check(lib.usc_ncut_binarize(sims[0].data_ptr(), sims[1].data_ptr() if len(sims) > 1 else None, S, float(tau),
                                 float(eps), None if pb is None else pb.data_ptr(), A.data_ptr(), deg.data_ptr(),
                                 ops._stream()), "usc_ncut_binarize")
@@ -230,13 +239,23 @@ def unscene3d_steps(aggregated_features, unique_segments, seg_connectivity, segm
     dev = (feats[0] if isinstance(feats, tuple) else feats).device
     neighbours = neighbour_sets(unique_segments, seg_connectivity)
     bipartitions, foreground = [], set()
-    painting = torch.zeros(num_segments, device=dev)
-    current_mask, host = None, None
+    # The painting (segments of every part cut so far, reference :122-135, :426-427) is host state: S flags, uploaded
+    # once per iteration through a pinned buffer.  The reference's `feats = (1 - painting) * feats` per iteration is the
+    # ORIGINAL features with the painted rows zeroed (painting only grows): usc_ncut_similarity_masked forms the product
+    # while it normalises the rows.  (Round 3 kept painting / mask on the device: five element-wise launches and a
+    # blocking pageable upload of the part mask per iteration — 0.9 ms of the 1.8 ms of host time an iteration took.)
+    painting_np = np.zeros(num_segments, dtype=bool)
+    paint_pin = torch.zeros(num_segments, dtype=torch.uint8).pin_memory()
+    paint_dev = torch.zeros(num_segments, dtype=torch.uint8, device=dev)
+    host = None
     for it in range(max_number_of_instances):
         if it > 0:
-            feats, painting = get_masked_affinity_matrix(painting, feats, current_mask)
+            # safe to rewrite: the upload of the previous iteration ran before the event waited for below fired
+            paint_pin.numpy()[:] = painting_np
+            paint_dev.copy_(paint_pin, non_blocking=True)
         A, D = get_affinity_matrix(feats, tau=affinity_tau, eps=eps, normalize_sim=True,
-                                   similarity_metric=similarity_metric, painting=painting.bool())
+                                   similarity_metric=similarity_metric, painting=paint_dev,
+                                   zero_rows=paint_dev if it > 0 else None)
         host, event, keep = second_smallest_eigenvector_async(A, D, eps, host=host)
         yield event
         event.synchronize()
@@ -250,8 +269,7 @@ def unscene3d_steps(aggregated_features, unique_segments, seg_connectivity, segm
             vec = vec * -1
         part = separate_segments(bipartition, vec, unique_segments, seg_connectivity, mode=separation_mode,
                                  neighbours=neighbours)
-        part_mask = torch.as_tensor(segment_ids_to_mask(part, unique_segments), device=dev)
-        current_mask = part_mask
+        painting_np |= np.asarray(segment_ids_to_mask(part, unique_segments), dtype=bool)
         if len(part & foreground) / len(part) > 0.5:
             continue
         if len(part) < min_segment_size:
