@@ -598,6 +598,31 @@ def test_config5_ncut_irregular_scene_product_path(device):
         assert (m & r).sum() / max((m | r).sum(), 1) >= 0.99
 
 
+@pytest.mark.gpu
+def test_masked_similarity_equals_the_reference_product(device):
+    """usc_ncut_similarity_masked (the cut loop's form: original features + the painting so far) gives bit for bit what
+    get_masked_affinity_matrix's `(1 - painting) * feats` followed by the plain similarity gives (reference :122-135),
+    in both modes, negative entries (-0 products) included; affinity and degree built from it likewise."""
+    from unscene3d_amd.pseudo_masks import ncut
+
+    g = torch.Generator().manual_seed(11)
+    S = 333
+    fa = torch.randn(S, 96, generator=g).to(device)
+    fb = torch.randn(S, 384, generator=g).to(device)
+    paint = (torch.rand(S, generator=g) < 0.3)
+    pu8 = paint.to(device=device, dtype=torch.uint8)
+    for cosine_mode, f in ((True, fa), (False, fb)):
+        feats_ref, painting = ncut.get_masked_affinity_matrix(torch.zeros(S, device=device), f, paint.to(device).float())
+        assert torch.equal(painting.bool().cpu(), paint)
+        ref = ncut._similarity(feats_ref, cosine_mode)
+        got = ncut._similarity(f, cosine_mode, zero_rows=pu8)
+        assert torch.equal(ref.view(torch.int32), got.view(torch.int32)), cosine_mode
+    (ra, rb), painting = ncut.get_masked_affinity_matrix(torch.zeros(S, device=device), (fa, fb), paint.to(device).float())
+    A0, D0 = ncut.get_affinity_matrix((ra, rb), tau=0.6, painting=painting.bool())
+    A1, D1 = ncut.get_affinity_matrix((fa, fb), tau=0.6, painting=pu8, zero_rows=pu8)
+    assert torch.equal(A0, A1) and torch.equal(D0, D1)
+
+
 @pytest.mark.parametrize("side", [9, 26, 46])
 def test_tridiagonalisation_one_launch_equals_stepwise(device, side, tmp_path):
     """S = 81 (workgroup count capped by n), 676 (rows in LDS) and 2116 (rows in global memory): the persistent
