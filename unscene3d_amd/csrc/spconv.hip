@@ -221,7 +221,10 @@ constexpr int kZeroRowFloats = 4096;
 // (a select on a loaded register makes the compiler wait for the load — and everything older — first)
 __device__ float g_zero_row[kZeroRowFloats + 8];
 
-constexpr int kCompactWaves = 8;   // one 512-thread workgroup per CU, two waves per SIMD
+#ifndef USC_COMPACT_WAVES
+#define USC_COMPACT_WAVES 8          /* developer builds: 16 = one 1024-thread workgroup per CU (tools/build_ablate.sh) */
+#endif
+constexpr int kCompactWaves = USC_COMPACT_WAVES;   // 8: 512-thread workgroups, two resident per CU when their LDS fits
 
 template <int NB>
 __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_kernel(GemmParams p) {
@@ -1162,7 +1165,10 @@ static GemmPlan plan_table(int64_t n_out, int cin, int cout, int K) {
     // per CU; the tile height is chosen so that the tiles fill an integer number of 256-CU rounds.
     const int cb = cout / 32;
     const int nb = (cb % 3 == 0) ? 3 : (cb % 2 == 0 ? 2 : 1);
-    const int tm_max = nb == 3 ? 192 : 256;
+#ifndef USC_TM_MAX3
+#define USC_TM_MAX3 192
+#endif
+    const int tm_max = nb == 3 ? USC_TM_MAX3 : 256;
 #ifndef USC_TILE_SLOTS
 #define USC_TILE_SLOTS 256   /* whole rounds of 256 CUs; 512 (both resident workgroups of a CU) measured 5 % slower on the 40 k-row map: smaller tiles pad more */
 #endif
