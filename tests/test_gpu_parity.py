@@ -623,11 +623,13 @@ def test_masked_similarity_equals_the_reference_product(device):
     assert torch.equal(A0, A1) and torch.equal(D0, D1)
 
 
-@pytest.mark.parametrize("side", [9, 26, 46])
+@pytest.mark.parametrize("side", [9, 21, 26, 30, 46])
 def test_tridiagonalisation_one_launch_equals_stepwise(device, side, tmp_path):
-    """S = 81 (workgroup count capped by n), 676 (rows in LDS) and 2116 (rows in global memory): the persistent
-    tridiagonalisation and the stepwise one (USC3D_TRI_STEPWISE=1, also the path for n > 4000) must give the
-    same eigenpair bit for bit — same summation trees — and it must be the generalized eigenvector #2 scipy finds."""
+    """S = 81 (workgroup count capped by n), 441, 676 (rows in registers), 900 (wider register form; tridiagonal eigenpair
+    from global memory; four elements per lane in the back-transformation) and 2116 (rows in global memory, 1024-thread
+    back-transformation): the persistent tridiagonalisation and the stepwise one (USC3D_TRI_STEPWISE=1, also the path for
+    n > 4000) must give the same eigenpair bit for bit — same summation trees — and it must be the generalized eigenvector
+    #2 scipy finds.  The earlier back-transformation kernels (kept behind switches) must agree to rounding."""
     import os
     import subprocess
     import sys
@@ -645,6 +647,12 @@ def test_tridiagonalisation_one_launch_equals_stepwise(device, side, tmp_path):
     a, b = outs
     assert np.isfinite(a["vec"]).all()
     assert np.array_equal(a["vec"], b["vec"])
+    for knobs in ({"USC3D_BACKTRANSFORM_QUAD": "0"}, {"USC3D_BACKTRANSFORM_QUAD": "0", "USC3D_BACKTRANSFORM_WAVE": "0"}):
+        out = str(tmp_path / "fiedler_bt.npz")
+        subprocess.run([sys.executable, os.path.join(root, "tools", "fiedler_dump.py"), str(side), out], check=True,
+                       env=dict(os.environ, **knobs), timeout=300)
+        c = np.load(out)["vec"]
+        assert np.abs(c - a["vec"]).max() <= 1e-11 * np.abs(a["vec"]).max(), knobs
     A = np.where(a["A"] > 0, 1.0, 1e-5)
     L, Dm = np.diag(a["D"]) - A, np.diag(a["D"])
     w, v = scipy.linalg.eigh(L, Dm, subset_by_index=[1, 1])
