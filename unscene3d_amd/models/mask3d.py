@@ -174,7 +174,7 @@ class Mask3D(nn.Module):
         Fourier encodings, the segment CSRs, the farthest-point query seeds and their encodings.  ~0.7 ms of
         latency-bound launches (100 dependent FPS rounds, counting sorts, min/max reductions) that the scene prefetcher
         issues on its side stream under the previous step's backward (datasets/prefetch.py); `forward` picks the result
-        up from the coordinate manager, or calls this itself.  Needs the coordinate maps of the pyramid (prepare())."""
+        up from the input tensor `x`, or calls this itself.  Needs the coordinate maps of the pyramid (prepare())."""
         cm = x.coordinate_manager
         n_scenes = len(x.decomposed_coordinates)
         coordinates = me.SparseTensor(features=raw_coordinates.float().contiguous(), coordinate_manager=cm,
@@ -223,7 +223,11 @@ class Mask3D(nn.Module):
                 cm._usc_p2s_batched = rows
             geo["p2s_rows"] = rows
             _child_segment_table(cm, x._ts(), rows)
-        cm.geometry = geo
+        # kept on the INPUT tensor, not on the coordinate manager: the dict holds SparseTensors of this manager, and
+        # manager -> geometry -> SparseTensor -> manager was a reference cycle — every batch's maps, rulebooks and
+        # encodings (~190 MB at 150 k voxels) then lived until a generation-2 collection (tools/soak.py: the allocator
+        # grew by 40 MB per step for 300 steps)
+        x._usc_geometry = geo
         return geo
 
     def _graph_key(self):
@@ -278,7 +282,7 @@ class Mask3D(nn.Module):
         pcd_features, aux = self.backbone(x)
         n_scenes = len(x.decomposed_coordinates)
 
-        geo = getattr(x.coordinate_manager, "geometry", None)
+        geo = getattr(x, "_usc_geometry", None)
         if geo is None or geo.get("n_levels") != len(aux):
             geo = self.precompute_geometry(x, raw_coordinates, point2segment, num_segments, n_levels=len(aux),
                                            is_eval=is_eval)
