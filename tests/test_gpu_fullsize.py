@@ -153,6 +153,68 @@ def test_150k_voxel_scene_indices_rulebooks_and_conv(device, bench_scene):
     assert rel_err(Wd.grad, dW) < 1e-5
 
 
+def test_every_conv_of_the_step_is_self_adjoint_on_the_bench_scene(device, bench_scene):
+    """A size-independent property at configs[1]'s full size, for EVERY (level, channel pair, kernel form) Res16UNet34C
+    runs on the 150 k-voxel bench scene — stride-1 3x3x3 convolutions on all five levels, the k2/s2 down and the
+    transposed up convolutions: the three kernels of a convolution compute one bilinear form,
+        <conv(x; W), dy>  =  <x, dgrad(dy; W)>  =  <W, wgrad(x, dy)>,
+    so forward, input gradient and weight gradient (tile-compacted, mask-sorted, pair-list and weight-gradient kernel
+    families, whichever the dispatcher picks for the shape) must agree with each other without any oracle.  Inner
+    products in f64; bound: 2e-6 of |conv(x)| |dy| (fp32 accumulation over <= 27 * 384 products per output)."""
+    from unscene3d_amd import MinkowskiEngine as ME
+    from unscene3d_amd import ops
+
+    sc = bench_scene
+    c3, umap, _ = ME.utils.sparse_quantize(sc["xyz"], quantization_size=0.02, return_index=True, return_inverse=True,
+                                           device=str(device))
+    coords = torch.cat([torch.zeros((c3.shape[0], 1), dtype=torch.int32, device=device), c3], 1).contiguous()
+    coords = ops.gather_rows_i32(coords, ops.spatial_order(coords))          # the bench's row order
+    x0 = ME.SparseTensor(features=torch.zeros(coords.shape[0], 3, device=device), coordinates=coords, device=device)
+    cm = x0.coordinate_manager
+    cm.prepare(1, n_down=4, ksize=3)
+    same = {1: [(3, 32), (32, 32), (128, 96), (96, 96), (96, 128)], 2: [(32, 32), (128, 96), (96, 96), (96, 128)],
+            4: [(32, 64), (64, 64), (192, 128), (128, 128)], 8: [(64, 128), (128, 128), (384, 256), (256, 256)],
+            16: [(128, 256), (256, 256)]}
+    down = {1: [(32, 32)], 2: [(32, 32)], 4: [(64, 64)], 8: [(128, 128)]}
+    up = {16: [(256, 256)], 8: [(256, 128)], 4: [(128, 96)], 2: [(96, 96)]}
+    g = torch.Generator().manual_seed(77)
+    checked = 0
+
+    def check(kind, ts, cin, cout, fn, n_in, n_out, K):
+        nonlocal checked
+        x = (torch.randn(n_in, cin, generator=g)).to(device).requires_grad_()
+        W = (torch.randn(K, cin, cout, generator=g) / np.sqrt(K * cin)).to(device).requires_grad_()
+        dy = torch.randn(n_out, cout, generator=g).to(device)
+        y = fn(x, W)
+        y.backward(dy)
+        yd, dyd = y.detach().double(), dy.double()
+        s1 = float((yd * dyd).sum())
+        s2 = float((x.detach().double() * x.grad.double()).sum())
+        s3 = float((W.detach().double() * W.grad.double()).sum())
+        scale = float(yd.norm() * dyd.norm())
+        assert abs(s1 - s2) <= 2e-6 * scale and abs(s1 - s3) <= 2e-6 * scale, (kind, ts, cin, cout, s1, s2, s3, scale)
+        checked += 1
+
+    for ts, shapes in same.items():
+        n = cm.coord_map(ts).n
+        nbr = cm.cube_map(ts)["nbr"]
+        for cin, cout in shapes:
+            check("same", ts, cin, cout, lambda x, W: ops.conv_same(x, W, None, nbr, lambda: cm.cube_rulebook(ts)), n, n, 27)
+    for ts, shapes in down.items():
+        d = cm.stride_map(ts)
+        nf, nc = cm.coord_map(ts).n, cm.coord_map(2 * ts).n
+        for cin, cout in shapes:
+            check("down", ts, cin, cout, lambda x, W: ops.conv_down2(x, W, d["nbr2"], lambda: cm.down_rulebook(ts)), nf, nc, 8)
+    for ts, shapes in up.items():
+        fine = ts // 2
+        d = cm.stride_map(fine)
+        nf, nc = cm.coord_map(fine).n, cm.coord_map(ts).n
+        for cin, cout in shapes:
+            check("up", ts, cin, cout,
+                  lambda x, W: ops.conv_tr_up2(x, W, d["nbr2"], lambda: cm.down_rulebook(fine), nf), nc, nf, 8)
+    assert checked == 27
+
+
 def test_150k_voxel_backbone_step_agrees_across_conv_kernel_families(device, bench_scene, monkeypatch):
     """configs[1] at full size end to end: Res16UNet34C forward + backward on the bench scene with the default
     dispatch (tile-compacted + mask-sorted kernels) and with the row-order kernels only (USC3D_CONV=legacy): two
