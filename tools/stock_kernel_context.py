@@ -47,6 +47,10 @@ for q, rs in per_q.items():
         ctx[(name, prev, nxt)] += 1
 t_stock = sum((r[1] - r[0]) for r in step if "usc::" not in r[2]) / 1e3
 print(f"# one step: {n_all} launches on {len(per_q)} queues; stock kernels {sum(stock.values())} launches, {t_stock:.1f} us")
+for q, rs in sorted(per_q.items(), key=lambda kv: -len(kv[1])):
+    st = [r for r in rs if "usc::" not in r[2]]
+    print(f"#   queue {q}: {len(rs)} launches, {sum(r[1] - r[0] for r in rs) / 1e3:.1f} us of kernels; stock {len(st)} launches, "
+          f"{sum(r[1] - r[0] for r in st) / 1e3:.1f} us: " + ", ".join(f"{v} {k[:40]}" for k, v in Counter(short(r[2]) for r in st).most_common(8)))
 for k, v in stock.most_common(40):
     print(f"{v:5d}  {k}")
 print("# stock kernel | previous | next")
