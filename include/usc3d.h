@@ -195,16 +195,6 @@ int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin,
                            const float* bias, float* out, int32_t accumulate, int32_t w_transposed,
                            void* ws, int64_t ws_bytes, usc_stream_t s);
 
-/* The same table-form convolution with the accumulators of a mask-sorted 32-row tile kept in REGISTERS over all of the
- * tile's offsets (csrc/spconv_regacc.hip): no LDS tile, no ordered flush.  perm / tile_mask: usc_rowsort_build of nbr.
- * Bitwise the results of usc_spconv_sorted_gemm.  w_transposed = 1: W is the forward conv's [K, cout', cin'] and the
- * call computes the input gradient of a stride-1 convolution (offsets mirrored).  ws: usc_spconv_regacc_ws_bytes. */
-int32_t usc_spconv_regacc_ok(int64_t n_out, int32_t cin, int32_t cout, int32_t K);
-int64_t usc_spconv_regacc_ws_bytes(int32_t cin, int32_t cout, int32_t K);
-int usc_spconv_regacc_gemm(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
-                           const int32_t* nbr, const int32_t* perm, const uint32_t* tile_mask, int64_t n_out,
-                           const float* bias, float* out, int32_t accumulate, int32_t w_transposed, void* ws,
-                           int64_t ws_bytes, usc_stream_t s);
 /* One-parent form (transposed-conv forward, strided-conv dgrad):
  *   out[rows_out[p],:] = in[rows_in[p],:] @ W[k]   for p in [koff[k], koff[k+1])
  * driven by the per-offset pair lists of usc_rulebook_compact on the child

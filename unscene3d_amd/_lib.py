@@ -77,9 +77,6 @@ SIGNATURES = {
     "usc_rowsort_build": (C.c_int, [_p, _i32, _i64, _p, _p, _p, _i64, _p]),
     "usc_spconv_sorted_ws_bytes": (_i64, [_i64, _i32, _i32, _i32]),
     "usc_spconv_sorted_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
-    "usc_spconv_regacc_ok": (_i32, [_i64, _i32, _i32, _i32]),
-    "usc_spconv_regacc_ws_bytes": (_i64, [_i32, _i32, _i32]),
-    "usc_spconv_regacc_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
     "usc_spconv_pairs_gemm": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p]),
     "usc_spconv_wgrad_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p, _i64, _p]),
