@@ -210,7 +210,7 @@ def make_mask3d_step(args, dev, rank, world):
         else:
             batch = collate(sets[(state["k"] - 1) % n_sets])
         out = module.training_step(batch)
-        if out is None:      # the trainer skips a batch without targets, like the reference (trainer/trainer.py:119-122)
+        if out is None:      # the trainer skips a batch without targets, like the reference (trainer/trainer.py:106-108)
             raise SystemExit("bench.py: training_step skipped the batch (no targets in the synthetic scene): "
                              "--voxels is too small for this benchmark")
         total, _ = out
