@@ -186,6 +186,24 @@ int usc_spconv_sorted_gemm(const float* in, int64_t n_in, int32_t cin,
                            const float* bias, float* out, int32_t accumulate,
                            int32_t w_transposed, void* ws, int64_t ws_bytes,
                            usc_stream_t s);
+/* The same with the slice reduction left to the caller: when the launch plan splits the K offsets over G > 1 partial-sum
+ * slices and `slices_left` is not NULL (and there is no bias), *slices_left = G, the slices f32[G][n_out][cout] stay at
+ * the start of `ws`, and `out` / `accumulate` are NOT applied — the caller sums the slices in slice order, usually fused
+ * with what follows the convolution (usc_bn_tile_forward / usc_bn_tile_backward below; usc_group_reduce is the plain
+ * form).  *slices_left = 0: the call did everything, as usc_spconv_sorted_gemm.  Replaces the same MinkowskiEngine
+ * calls (models/modules/common.py:125-188). */
+int usc_spconv_sorted_gemm_ex(const float* in, int64_t n_in, int32_t cin,
+                              const float* W, int32_t K, int32_t cout,
+                              const int32_t* nbr, const int32_t* perm,
+                              const uint32_t* tile_mask, int64_t n_out,
+                              const float* bias, float* out, int32_t accumulate,
+                              int32_t w_transposed, void* ws, int64_t ws_bytes,
+                              int32_t* slices_left, usc_stream_t s);
+/* out[n,c] = (accumulate ? out : 0) + bias + sum_g partial[g][n][c], g ascending (the reduction the split-K launches
+ * end with; c a multiple of 4). */
+int usc_group_reduce(const float* partial, int32_t G, int64_t n, int32_t c,
+                     const float* bias, int32_t accumulate, float* out,
+                     usc_stream_t s);
 
 int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin,
                                         int32_t cout, int32_t K);
@@ -236,6 +254,11 @@ int usc_spconv_wgrad_table(const float* in, int32_t cin, const float* dy, int32_
  * No pair split and no reduction launch: every (problem, offset, channel tile) workgroup walks its whole pair list and
  * writes (accumulate = 1: adds into) dW[r][k] itself, in a fixed order.  usc_spconv_wgrad_group_ok: whether the grouped
  * form applies (channel pair covered, >= 256 workgroups, <= 2 048 pairs per offset: the coarse levels). */
+/* > 0: usc_spconv_wgrad launches its all-input-tiles kernel with at most that many workgroups along x, each walking
+ * several (offset, split) work items ("background form": the launch leaves wave slots and matrix-core time on every CU
+ * to the kernels of another stream).  0 restores the plain launches.  Process-wide; set by the weight-gradient lane
+ * around its own launches.  Same arithmetic, same results. */
+void usc_spconv_wgrad_grid_limit(int32_t max_workgroups);
 int32_t usc_spconv_wgrad_group_max(void);
 int usc_spconv_wgrad_group_ok(int32_t R, int32_t cin, int32_t cout, int32_t K, int64_t n_rows);
 int usc_spconv_wgrad_group(int32_t R, const float* const* a, const float* const* b, float* const* dW, int32_t cin,
@@ -438,6 +461,38 @@ int usc_bn_backward_dx(const float* x, const float* dy, const float* y_out,
  * mean_g = dbeta/n, mean_gxhat = dgamma/n (both 0 when training==0: eval-mode BN
  * treats the statistics as constants).  g applies the ReLU mask of y_out when given.  accumulate=1 adds dgamma / dbeta into the given
  * buffers (the parameters' gradient tensors) instead of overwriting them. */
+/* TILE FORM of the training-mode batch norm around a split-K convolution, for maps of up to usc_bn_tile_max_rows() rows
+ * (the U-Net's coarse levels, where every launch sits on its latency floor): conv -> BN (+ residual) (+ ReLU) of
+ * models/modules/resnet_block.py:48-64 / models/modules/common.py:22 in TWO launches after the convolution instead of
+ * four (slice reduction, statistics, finalisation, apply):
+ *   forward   y = sum of the G slices `partial` f32[G][n][c] in slice order (G == 0: y already holds the conv output),
+ *             per-tile f64 column sums, then every workgroup of the apply launch adds the <= 64 tile sums in tile order,
+ *             finalises (mean / invstd / scale / shift and the running statistics written once) and applies
+ *             out = [relu](y * scale + shift [+ residual]).  Same statistics as usc_bn_forward_stats up to the order of
+ *             the f64 additions.
+ *   backward  dout' = (accumulate ? dout : 0) + sum of the G input-gradient slices (G == 0: dout is finished),
+ *             g = ReLU-masked dout' (y_out != NULL), tile sums of g and g * xhat; then dgamma / dbeta (added into when
+ *             dbn_accumulate), and dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)) (training == 0: the two
+ *             means are 0).  g is written to dres when given (the residual branch's gradient), else in place into dout
+ *             when it was formed from slices; a finished dout without dres is not written.
+ * ws: usc_bn_tile_ws_bytes(c) bytes.  usc_bn_tile_ok(n, c): does the form cover this map (c a multiple of 32)? */
+int64_t usc_bn_tile_max_rows(void);
+int usc_bn_tile_ok(int64_t n, int32_t c);
+int64_t usc_bn_tile_ws_bytes(int32_t c);
+int usc_bn_tile_forward(const float* partial, int32_t G, float* y, int64_t n,
+                        int32_t c, const float* gamma, const float* beta,
+                        float eps, float momentum, float* running_mean,
+                        float* running_var, int64_t* num_batches_tracked,
+                        float* mean, float* invstd, float* scale, float* shift,
+                        const float* residual, int32_t relu, float* out,
+                        void* ws, int64_t ws_bytes, usc_stream_t s);
+int usc_bn_tile_backward(const float* partial, int32_t G, int32_t accumulate,
+                         float* dout, const float* y, const float* y_out,
+                         const float* mean, const float* invstd,
+                         const float* gamma, int64_t n, int32_t c,
+                         int32_t training, int32_t dbn_accumulate,
+                         float* dgamma, float* dbeta, float* dy, float* dres,
+                         void* ws, int64_t ws_bytes, usc_stream_t s);
 int usc_bn_backward_reduce(const float* x, const float* dy, const float* y_out,
                            const float* mean, const float* invstd, int64_t n,
                            int32_t c, int32_t training, int32_t accumulate, float* dgamma,

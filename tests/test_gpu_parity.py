@@ -257,6 +257,82 @@ def test_conv1x1_with_bias(device):
     assert rel_err(xd.grad, xr.grad) < 1e-5 and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("n", [12000, 9402, 2222, 507, 33, 2])
+@pytest.mark.parametrize("c,relu,res,G,acc", [(32, True, False, 0, 0), (96, True, True, 3, 1), (256, False, False, 27, 0),
+                                              (128, True, True, 9, 1), (384, False, True, 14, 0)])
+def test_tile_form_batch_norm_around_split_k_slices(device, c, relu, res, G, acc, n):
+    """usc_bn_tile_forward / usc_bn_tile_backward — the two-launch form of conv-slices -> BN (+ residual) (+ ReLU) of the
+    coarse levels (reference models/modules/resnet_block.py:48-64; MinkowskiBatchNorm = BatchNorm1d over the rows,
+    models/modules/common.py:22) — against F.batch_norm on the SUM of the slices: forward output, the conv output it
+    leaves behind (bit-equal to the ordered slice sum), statistics, running statistics, and all four gradients."""
+    from unscene3d_amd import _lib
+    from unscene3d_amd._lib import check, lib
+
+    gen = torch.Generator().manual_seed(1000 * c + n + G)
+    Gs = max(G, 1)
+    parts = torch.randn(Gs, n, c, generator=gen) * 2 + 0.3
+    r = torch.randn(n, c, generator=gen) if res else None
+    gamma, beta = torch.rand(c, generator=gen) + 0.5, torch.randn(c, generator=gen)
+    # ---- forward
+    y_ref = torch.zeros(n, c)
+    for g in range(Gs):
+        y_ref = y_ref + parts[g]                      # slice order, fp32: what group_reduce_kernel computes
+    xr, gr, br = y_ref.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rr = r.clone().requires_grad_() if res else None
+    rm, rv = torch.zeros(c), torch.ones(c)
+    if n > 1:
+        o_ref = torch.nn.functional.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.02, eps=1e-5)
+    else:   # one row: torch refuses, the kernels give var = 0 like MinkowskiBatchNorm on a one-voxel map would
+        o_ref = (xr - xr.mean(0)) * torch.rsqrt(xr.var(0, unbiased=False) + 1e-5) * gr + br
+    if res:
+        o_ref = o_ref + rr
+    if relu:
+        o_ref = torch.relu(o_ref)
+    pd = _dev(parts, device)
+    yd = torch.empty(n, c, device=device) if G > 0 else _dev(y_ref, device)
+    rd = _dev(r, device) if res else None
+    gd, bd = _dev(gamma, device), _dev(beta, device)
+    rmd, rvd = torch.zeros(c, device=device), torch.ones(c, device=device)
+    stats = torch.empty(4, c, device=device)
+    out = torch.empty(n, c, device=device)
+    ws = torch.empty(int(lib.usc_bn_tile_ws_bytes(c)), dtype=torch.uint8, device=device)
+    assert lib.usc_bn_tile_ok(n, c) == 1
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    check(lib.usc_bn_tile_forward(p(pd) if G > 0 else None, G, p(yd), n, c, p(gd), p(bd), 1e-5, 0.02, p(rmd), p(rvd), None,
+                                  p(stats[0]), p(stats[1]), p(stats[2]), p(stats[3]), p(rd), int(relu), p(out), p(ws),
+                                  ws.numel(), st), "usc_bn_tile_forward")
+    assert torch.equal(yd.cpu(), y_ref)
+    assert rel_err(out, o_ref.detach()) < 1e-5
+    if n > 1:
+        assert rel_err(rmd, rm) < 1e-5 and rel_err(rvd, rv) < 1e-5
+    assert rel_err(stats[0], y_ref.mean(0)) < 1e-5
+    # ---- backward: dout arrives as `acc` (existing content) + G slices
+    dparts = torch.randn(Gs, n, c, generator=gen)
+    base = torch.randn(n, c, generator=gen)
+    dout_ref = base.clone() if (acc or G == 0) else torch.zeros(n, c)
+    if G > 0:
+        for g in range(Gs):
+            dout_ref = dout_ref + dparts[g]
+    o_ref.backward(dout_ref)
+    dpd = _dev(dparts, device)
+    doutd = _dev(base, device)
+    dy = torch.empty(n, c, device=device)
+    dres = torch.empty(n, c, device=device) if res else None
+    dgam, dbet = torch.full((c,), 0.5, device=device), torch.full((c,), -0.25, device=device)    # accumulate into these
+    check(lib.usc_bn_tile_backward(p(dpd) if G > 0 else None, G, acc, p(doutd), p(yd), p(out) if relu else None,
+                                   p(stats[0]), p(stats[1]), p(gd), n, c, 1, 1, p(dgam), p(dbet), p(dy), p(dres), p(ws),
+                                   ws.numel(), st), "usc_bn_tile_backward")
+    tol = 1e-4 if n > 1 else 1e-3
+    if n > 1:
+        assert rel_err(dy, xr.grad) < tol
+    assert rel_err(dgam - 0.5, gr.grad) < tol and rel_err(dbet + 0.25, br.grad) < tol
+    if res:
+        assert rel_err(dres, rr.grad) < 1e-6
+    if G == 0 and not res:
+        assert torch.equal(doutd.cpu(), base)          # a finished gradient without a residual consumer is not written
+
+
 @pytest.mark.parametrize("n", [7777, 2222, 507, 3])       # two launches | one-launch statistics | one launch both ways
 @pytest.mark.parametrize("c,relu,res", [(32, True, False), (96, True, True), (256, False, False), (100, False, True)])
 def test_batch_norm_act(device, c, relu, res, n):

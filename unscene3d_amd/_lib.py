@@ -77,6 +77,15 @@ SIGNATURES = {
     "usc_rowsort_build": (C.c_int, [_p, _i32, _i64, _p, _p, _p, _i64, _p]),
     "usc_spconv_sorted_ws_bytes": (_i64, [_i64, _i32, _i32, _i32]),
     "usc_spconv_sorted_gemm": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p]),
+    "usc_spconv_sorted_gemm_ex": (C.c_int, [_p, _i64, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p, _i32, _i32, _p, _i64, _p, _p]),
+    "usc_group_reduce": (C.c_int, [_p, _i32, _i64, _i32, _p, _i32, _p, _p]),
+    "usc_bn_tile_max_rows": (C.c_int64, []),
+    "usc_bn_tile_ok": (C.c_int, [_i64, _i32]),
+    "usc_bn_tile_ws_bytes": (C.c_int64, [_i32]),
+    "usc_bn_tile_forward": (C.c_int, [_p, _i32, _p, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p,
+                                      _p, _i64, _p]),
+    "usc_bn_tile_backward": (C.c_int, [_p, _i32, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _p, _p, _p, _p,
+                                       _i64, _p]),
     "usc_spconv_pairs_gemm": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _p]),
     "usc_spconv_wgrad_ws_bytes": (_i64, [_i32, _i32, _i32]),
     "usc_spconv_wgrad": (C.c_int, [_p, _i32, _p, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p, _i64, _p]),
@@ -85,6 +94,7 @@ SIGNATURES = {
     "usc_program_ws_bytes": (_i64, [_sp, _i32]),
     "usc_program_run": (C.c_int, [_sp, _i32, _i32, _p, _i64, _p]),
     "usc_spconv_wgrad_group_max": (_i32, []),
+    "usc_spconv_wgrad_grid_limit": (None, [_i32]),
     "usc_spconv_wgrad_group_ok": (C.c_int, [_i32, _i32, _i32, _i32, _i64]),
     "usc_spconv_wgrad_group": (C.c_int, [_i32, _p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _i64, _i32, _p]),
     "usc_spconv_wgrad_table_ws_bytes": (_i64, [_i32, _i32, _i32]),

@@ -12,6 +12,9 @@
 
 namespace usc {
 
+void launch_group_reduce(const float* partial, int G, int64_t numel4, int cout, const float* bias, int accumulate,
+                         float* out, hipStream_t st);   // spconv.hip
+
 // ---------------------------------------------------------------------------
 // column statistics: two sums per channel over N rows, f64 accumulation,
 // block partials -> ordered final reduction (no float atomics).
@@ -887,6 +890,244 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// TILE FORM of the batch norm around a split-K convolution (maps of a few hundred to ~12 k rows: the U-Net's three
+// coarsest levels).  There every launch sits on its ~4.5 us floor, and a conv -> BN -> ReLU unit was FOUR of them after
+// the convolution itself had written its G partial slices: slice reduction, statistics, finalisation, apply (three on
+// the maps <= 4 096 rows).  Here it is two, neither with a grid-wide wait:
+//   bn_tile_stats_kernel   (row tile x 32-column block): y = sum of the G slices in slice order (the order of
+//                          group_reduce_kernel: bit-identical y), written once, and the tile's f64 column sums
+//                          sum(y), sum(y^2) -> tpart[tile][2][c].  <= 64 row tiles per map.
+//   bn_tile_apply_kernel   every workgroup first adds the <= 64 tile sums of all c columns in tile order (the same order
+//                          in every workgroup: identical statistics; ~130 independent L2 loads per thread) and finalises
+//                          into LDS; workgroup 0 also writes mean / invstd / scale / shift and the running statistics.
+//                          Then scale/shift (+ residual) (+ ReLU) over its rows.
+// Backward the same pair: bn_tile_bwd_stats_kernel forms dout = (accumulate ? dout : 0) + sum of the input-gradient
+// slices the NEXT convolution's backward left behind (usc_program_run hands them over), applies the ReLU mask, writes
+// the masked gradient once and the tile sums sum(g), sum(g * xhat); bn_tile_bwd_dx_kernel finalises (workgroup 0 adds
+// dgamma / dbeta) and writes dy.
+constexpr int kBnTileCols4 = 8;            // float4 columns per workgroup (32 channels, 128 bytes per row)
+constexpr int kBnTileRowLanes = 256 / kBnTileCols4;
+constexpr int kBnTileMaxTiles = 64;
+
+struct BnTileStats {
+  const float* partial;   // [G][n][c] slices, or NULL
+  int G;
+  int64_t slice;          // floats per slice
+  const float* acc_in;    // backward: added first when not NULL (the `accumulate` of the slice reduction)
+  const float* src;       // G == 0: the finished tensor (forward: y, backward: dout)
+  float* dst;             // forward: y (G > 0); backward: masked gradient (or NULL: nothing to write)
+  const float* x;         // backward: the conv output y of the forward pass (for xhat)
+  const float* y_out;     // backward: forward output after ReLU (mask) or NULL
+  const float* mean; const float* invstd;   // backward
+  int64_t n; int c; int tr;
+  double* tpart;          // [ntiles][2][c]
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_tile_stats_kernel(BnTileStats a) {
+  __shared__ double sh[2][kBnTileRowLanes][33];
+  const int tid = threadIdx.x, rl = tid / kBnTileCols4, cq = tid % kBnTileCols4;
+  const int tile = blockIdx.x, cb = blockIdx.y;
+  const int col = (cb * kBnTileCols4 + cq) * 4;
+  const int64_t r_begin = (int64_t)tile * a.tr;
+  int64_t r_end = r_begin + a.tr;
+  if (r_end > a.n) r_end = a.n;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  float mu[4] = {0, 0, 0, 0}, is[4] = {0, 0, 0, 0};
+  if (BWD) {
+    const float4 m4 = *reinterpret_cast<const float4*>(a.mean + col);
+    const float4 i4 = *reinterpret_cast<const float4*>(a.invstd + col);
+    mu[0] = m4.x; mu[1] = m4.y; mu[2] = m4.z; mu[3] = m4.w;
+    is[0] = i4.x; is[1] = i4.y; is[2] = i4.z; is[3] = i4.w;
+  }
+  for (int64_t r = r_begin + rl; r < r_end; r += kBnTileRowLanes) {
+    const int64_t off = r * a.c + col;
+    float4 v;
+    float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), ov = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (BWD) {
+      xv = *reinterpret_cast<const float4*>(a.x + off);
+      if (a.y_out) ov = *reinterpret_cast<const float4*>(a.y_out + off);
+    }
+    if (a.G == 0) {
+      v = *reinterpret_cast<const float4*>(a.src + off);
+    } else {
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (BWD && a.acc_in) v = *reinterpret_cast<const float4*>(a.acc_in + off);
+      const float* pp = a.partial + off;
+      int g = 0;
+      for (; g + 8 <= a.G; g += 8) {       // eight slices in flight; the adds keep the order g ascending
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(pp + (int64_t)(g + u) * a.slice);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+      }
+      for (; g < a.G; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(pp + (int64_t)g * a.slice);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+    }
+    float vs[4] = {v.x, v.y, v.z, v.w};
+    if (BWD) {
+      const float os[4] = {ov.x, ov.y, ov.z, ov.w};
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (a.y_out && !(os[q] > 0.f)) vs[q] = 0.f;
+        const float xhat = (xs[q] - mu[q]) * is[q];
+        s1[q] += (double)vs[q];
+        s2[q] += (double)vs[q] * (double)xhat;
+      }
+      if (a.dst) *reinterpret_cast<float4*>(a.dst + off) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+    } else {
+      if (a.G > 0) *reinterpret_cast<float4*>(a.dst + off) = v;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s1[q] += (double)vs[q];
+        s2[q] += (double)vs[q] * (double)vs[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sh[0][rl][cq * 4 + q] = s1[q];
+    sh[1][rl][cq * 4 + q] = s2[q];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, j = tid & 31;
+    double t = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < kBnTileRowLanes; ++r) t += sh[which][r][j];
+    a.tpart[((int64_t)tile * 2 + which) * a.c + cb * 32 + j] = t;
+  }
+}
+
+// sum of the tile partials of one column, tile order; 16 tiles' loads in flight (a plain loop is one L2 round trip per
+// tile: ~60 dependent trips for the 9 402-row level)
+__device__ inline void tile_sums(const double* __restrict__ tpart, int ntiles, int c, int ch, double& s1, double& s2) {
+  s1 = 0.0; s2 = 0.0;
+  for (int t0 = 0; t0 < ntiles; t0 += 16) {
+    double a1[16], a2[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int t = t0 + u < ntiles ? t0 + u : ntiles - 1;
+      a1[u] = tpart[((int64_t)t * 2 + 0) * c + ch];
+      a2[u] = tpart[((int64_t)t * 2 + 1) * c + ch];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (t0 + u < ntiles) { s1 += a1[u]; s2 += a2[u]; }
+    }
+  }
+}
+
+struct BnTileApply {
+  const double* tpart; int ntiles;
+  BnFwdOut o;
+  const float* y; const float* res; int relu; float* out; int64_t nvec; int c;
+};
+__global__ __launch_bounds__(256) void bn_tile_apply_kernel(BnTileApply a) {
+  extern __shared__ float tile_sh[];            // scale[c] | shift[c]
+  const int c = a.c;
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    double s1, s2;
+    tile_sums(a.tpart, a.ntiles, c, ch, s1, s2);
+    const double n = (double)a.o.n;
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.o.eps));
+    const float sc = a.o.gamma[ch] * invstd;
+    const float sf = a.o.beta[ch] - mean * sc;
+    tile_sh[ch] = sc;
+    tile_sh[c + ch] = sf;
+    if (blockIdx.x == 0) bn_finalize_channel(ch, s1, s2, a.o);      // the same numbers, written once
+  }
+  __syncthreads();
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < a.nvec; j += (int64_t)gridDim.x * 256) {
+    const int64_t e = j * 4;
+    const int ch = (int)(e % c);
+    float4 v = *reinterpret_cast<const float4*>(a.y + e);
+    const float4 sc = *reinterpret_cast<const float4*>(tile_sh + ch);
+    const float4 sf = *reinterpret_cast<const float4*>(tile_sh + c + ch);
+    v.x = v.x * sc.x + sf.x; v.y = v.y * sc.y + sf.y; v.z = v.z * sc.z + sf.z; v.w = v.w * sc.w + sf.w;
+    if (a.res) {
+      const float4 r = *reinterpret_cast<const float4*>(a.res + e);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(a.out + e) = v;
+  }
+}
+
+struct BnTileDx {
+  const double* tpart; int ntiles;
+  BnBwdOut o;                 // dgamma, dbeta (workgroup 0), mean_g / mean_gx unused (NULL)
+  const float* g;             // masked gradient (or dout when mask_src is given)
+  const float* mask_src;      // forward output after ReLU when g is still unmasked, else NULL
+  const float* x; const float* mean; const float* invstd; const float* gamma;
+  float* dx; int64_t nvec; int c;
+};
+__global__ __launch_bounds__(256) void bn_tile_bwd_dx_kernel(BnTileDx a) {
+  extern __shared__ float tile_sh[];            // mean_g[c] | mean_gx[c]
+  const int c = a.c;
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    double sg, sgx;
+    tile_sums(a.tpart, a.ntiles, c, ch, sg, sgx);
+    tile_sh[ch] = a.o.training ? (float)(sg / (double)a.o.n) : 0.f;
+    tile_sh[c + ch] = a.o.training ? (float)(sgx / (double)a.o.n) : 0.f;
+    if (blockIdx.x == 0) {
+      a.o.dbeta[ch] = a.o.accumulate ? a.o.dbeta[ch] + (float)sg : (float)sg;
+      a.o.dgamma[ch] = a.o.accumulate ? a.o.dgamma[ch] + (float)sgx : (float)sgx;
+    }
+  }
+  __syncthreads();
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < a.nvec; j += (int64_t)gridDim.x * 256) {
+    const int64_t e = j * 4;
+    const int ch0 = (int)(e % c);
+    const float4 xv = *reinterpret_cast<const float4*>(a.x + e);
+    float4 gv = *reinterpret_cast<const float4*>(a.g + e);
+    if (a.mask_src) {
+      const float4 ov = *reinterpret_cast<const float4*>(a.mask_src + e);
+      if (!(ov.x > 0.f)) gv.x = 0.f;
+      if (!(ov.y > 0.f)) gv.y = 0.f;
+      if (!(ov.z > 0.f)) gv.z = 0.f;
+      if (!(ov.w > 0.f)) gv.w = 0.f;
+    }
+    const float4 mu = *reinterpret_cast<const float4*>(a.mean + ch0);
+    const float4 is = *reinterpret_cast<const float4*>(a.invstd + ch0);
+    const float4 mg = *reinterpret_cast<const float4*>(tile_sh + ch0);
+    const float4 mx = *reinterpret_cast<const float4*>(tile_sh + c + ch0);
+    const float ga0 = a.gamma[ch0], ga1 = a.gamma[ch0 + 1], ga2 = a.gamma[ch0 + 2], ga3 = a.gamma[ch0 + 3];
+    float4 o;
+    o.x = ga0 * is.x * (gv.x - mg.x - (xv.x - mu.x) * is.x * mx.x);
+    o.y = ga1 * is.y * (gv.y - mg.y - (xv.y - mu.y) * is.y * mx.y);
+    o.z = ga2 * is.z * (gv.z - mg.z - (xv.z - mu.z) * is.z * mx.z);
+    o.w = ga3 * is.w * (gv.w - mg.w - (xv.w - mu.w) * is.w * mx.w);
+    *reinterpret_cast<float4*>(a.dx + e) = o;
+  }
+}
+
+struct BnTileGeom { int tr, ntiles, ncb; };
+static BnTileGeom bn_tile_geom(int64_t n, int c) {
+  BnTileGeom g;
+  const int64_t per = ceil_div(n, (int64_t)kBnTileMaxTiles);
+  g.tr = (int)(ceil_div(per, (int64_t)kBnTileRowLanes) * kBnTileRowLanes);
+  g.ntiles = (int)ceil_div(n, (int64_t)g.tr);
+  g.ncb = c / 32;
+  return g;
+}
+static int bn_apply_grid(int64_t nvec) {
+  int64_t g = ceil_div(nvec, (int64_t)256 * 2);
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
 }  // namespace usc
 
 using namespace usc;
@@ -989,6 +1230,78 @@ int usc_bn_backward_dx(const float* x, const float* dy, const float* y_out, cons
     hipLaunchKernelGGL((bn_bwd_dx_kernel<1>), dim3(stream_grid(numel, 256)), dim3(256), 0, as_stream(s), x, dy, y_out,
                        mean, invstd, gamma, mean_g, mean_gxhat, dx, dres, numel, (int)c);
   USC_CHECK_LAUNCH("usc_bn_backward_dx");
+  return USC_OK;
+}
+
+int64_t usc_bn_tile_max_rows(void) {
+  static const int64_t knob = getenv("USC3D_BN_TILE_ROWS") ? (int64_t)atoll(getenv("USC3D_BN_TILE_ROWS")) : (int64_t)4096;
+  // 0: the tile form is off (A/B switch).  4 096: the two coarsest levels of a 150 k-voxel scene; measured per unit
+  // (tools/bn_tile_bench.py) 17.3 -> 11.5 / 20.9 -> 9.5 us forward / backward at 507 rows, 18.5 -> 15.4 / 24.9 -> 17.9 at
+  // 2 222 x 128; at 9 402 rows the old launches are as fast (21.1 vs 22.3 / 24.3 vs 25.9): left as they were
+  return knob;
+}
+
+int usc_bn_tile_ok(int64_t n, int32_t c) { return n >= 1 && n <= usc_bn_tile_max_rows() && c >= 32 && c % 32 == 0 && c <= 1024; }
+
+int64_t usc_bn_tile_ws_bytes(int32_t c) { return (int64_t)kBnTileMaxTiles * 2 * c * 8; }
+
+int usc_group_reduce(const float* partial, int32_t G, int64_t n, int32_t c, const float* bias, int32_t accumulate,
+                     float* out, usc_stream_t s) {
+  USC_REQUIRE(partial && out && G >= 1 && n >= 0 && c >= 4 && c % 4 == 0, "usc_group_reduce: bad argument");
+  if (n == 0) return USC_OK;
+  launch_group_reduce(partial, (int)G, n * c / 4, (int)c, bias, (int)accumulate, out, as_stream(s));
+  USC_CHECK_LAUNCH("usc_group_reduce");
+  return USC_OK;
+}
+
+int usc_bn_tile_forward(const float* partial, int32_t G, float* y, int64_t n, int32_t c, const float* gamma,
+                        const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                        int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                        const float* residual, int32_t relu, float* out, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(usc_bn_tile_ok(n, c), "usc_bn_tile_forward: map of %lld rows x %d channels is outside the tile form", (long long)n, (int)c);
+  USC_REQUIRE(y && gamma && beta && mean && invstd && scale && shift && out && ws && G >= 0 && (G == 0 || partial),
+              "usc_bn_tile_forward: null pointer");
+  USC_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "usc_bn_tile_forward: running stats mismatch");
+  USC_REQUIRE(ws_bytes >= usc_bn_tile_ws_bytes(c), "usc_bn_tile_forward: workspace too small");
+  hipStream_t st = as_stream(s);
+  const BnTileGeom g = bn_tile_geom(n, c);
+  BnTileStats a{};
+  a.partial = partial; a.G = G; a.slice = n * c; a.src = y; a.dst = y; a.n = n; a.c = c; a.tr = g.tr; a.tpart = (double*)ws;
+  hipLaunchKernelGGL((bn_tile_stats_kernel<false>), dim3((unsigned)g.ntiles, (unsigned)g.ncb), dim3(256), 0, st, a);
+  BnTileApply b{};
+  b.tpart = (const double*)ws; b.ntiles = g.ntiles;
+  b.o = BnFwdOut{gamma, beta, running_mean, running_var, mean, invstd, scale, shift, eps, momentum, n, num_batches_tracked};
+  b.y = y; b.res = residual; b.relu = relu; b.out = out; b.nvec = n * c / 4; b.c = c;
+  hipLaunchKernelGGL(bn_tile_apply_kernel, dim3((unsigned)bn_apply_grid(b.nvec)), dim3(256), (size_t)2 * c * 4, st, b);
+  USC_CHECK_LAUNCH("usc_bn_tile_forward");
+  return USC_OK;
+}
+
+int usc_bn_tile_backward(const float* partial, int32_t G, int32_t accumulate, float* dout, const float* y, const float* y_out,
+                         const float* mean, const float* invstd, const float* gamma, int64_t n, int32_t c, int32_t training,
+                         int32_t dbn_accumulate, float* dgamma, float* dbeta, float* dy, float* dres, void* ws,
+                         int64_t ws_bytes, usc_stream_t s) {
+  USC_REQUIRE(usc_bn_tile_ok(n, c), "usc_bn_tile_backward: map of %lld rows x %d channels is outside the tile form", (long long)n, (int)c);
+  USC_REQUIRE(dout && y && mean && invstd && gamma && dgamma && dbeta && dy && ws && G >= 0 && (G == 0 || partial),
+              "usc_bn_tile_backward: null pointer");
+  USC_REQUIRE(ws_bytes >= usc_bn_tile_ws_bytes(c), "usc_bn_tile_backward: workspace too small");
+  hipStream_t st = as_stream(s);
+  const BnTileGeom g = bn_tile_geom(n, c);
+  BnTileStats a{};
+  a.partial = partial; a.G = G; a.slice = n * c; a.acc_in = (G > 0 && accumulate) ? dout : nullptr; a.src = dout;
+  // the masked gradient goes to the residual branch's buffer when there is one; else (slices: dout is this program's
+  // own buffer) in place; a finished dout without a residual consumer is left alone and masked again in the dx pass
+  a.dst = dres ? dres : (G > 0 ? dout : nullptr);
+  a.x = y; a.y_out = y_out; a.mean = mean; a.invstd = invstd; a.n = n; a.c = c; a.tr = g.tr; a.tpart = (double*)ws;
+  hipLaunchKernelGGL((bn_tile_stats_kernel<true>), dim3((unsigned)g.ntiles, (unsigned)g.ncb), dim3(256), 0, st, a);
+  BnTileDx b{};
+  b.tpart = (const double*)ws; b.ntiles = g.ntiles;
+  b.o = BnBwdOut{dgamma, dbeta, nullptr, nullptr, n, (int)training, (int)dbn_accumulate};
+  b.g = a.dst ? a.dst : dout;
+  b.mask_src = a.dst ? nullptr : y_out;
+  b.x = y; b.mean = mean; b.invstd = invstd; b.gamma = gamma; b.dx = dy; b.nvec = n * c / 4; b.c = c;
+  hipLaunchKernelGGL(bn_tile_bwd_dx_kernel, dim3((unsigned)bn_apply_grid(b.nvec)), dim3(256), (size_t)2 * c * 4, st, b);
+  USC_CHECK_LAUNCH("usc_bn_tile_backward");
   return USC_OK;
 }
 

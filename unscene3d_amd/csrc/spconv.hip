@@ -695,6 +695,7 @@ struct WgradParams {
   int cin, cout, K, S;
   float* direct;   // wgrad_full_kernel, S == 1: dW itself (no partial slice, no reduction launch)
   int accumulate;  //   ... added into it when set
+  int vblocks;     // wgrad_full_kernel: > 0 = number of (problem, offset, split) work items a smaller grid walks
 };
 
 // ALIGNED: cin % 32 == 0 and cout % (32*NB) == 0 -> unconditional vector loads; the lane's NB
@@ -834,13 +835,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradParams p) {
 constexpr int kMaxWgradGroup = 16;
 struct WgradGroup { const float* a[kMaxWgradGroup]; const float* b[kMaxWgradGroup]; float* dW[kMaxWgradGroup]; int R; };
 
+// CT * NB <= 9: two workgroups per CU (256 registers per lane).  The 12-tile form <4,3> (128 -> 96 channels, which
+// otherwise falls to the per-input-tile kernel) gets the whole register file: 192 accumulator registers in the AGPR
+// half, one workgroup per CU.
 template <int CT, int NB>
-__global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p, WgradGroup g) {
+__global__ __launch_bounds__(256, (CT * NB > 9) ? 1 : 2) void wgrad_full_kernel(WgradParams p, WgradGroup g) {
   extern __shared__ float red[];  // [4 waves][NB*16 regs][64 lanes]
   constexpr int NA = CT * NB;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
-  int bx = blockIdx.x;
+  // p.vblocks > 0: a SMALL grid walks the (problem, offset, split) work items — the launch then leaves wave slots and
+  // matrix-core time on every CU to whatever runs beside it (the background form of the weight-gradient lane)
+  const int vtotal = p.vblocks > 0 ? p.vblocks : (int)gridDim.x;
+  for (int vb = blockIdx.x; vb < vtotal; vb += gridDim.x) {
+  int bx = vb;
   if (g.R > 0) {
     const int per = p.K * p.S, r = bx / per;
     bx -= r * per;
@@ -967,6 +975,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_full_kernel(WgradParams p, Wgrad
         for (int nb = 0; nb < NB; ++nb) o[nb] = rmw ? o[nb] + v[nb] : v[nb];
       }
     }
+  }
+  __syncthreads();   // `red` is reused by the next work item
   }
 }
 
@@ -1111,7 +1121,16 @@ static int wgrad_splits(int K, int cin, int cout, int NB, int64_t n_rows) {
   return (int)S;
 }
 static int wgrad_full_nb(int cb) { return (cb % 3 == 0) ? 3 : (cb % 4 == 0 ? 4 : (cb % 2 == 0 ? 2 : 1)); }
+static bool wgrad_big_tiles() {      // USC3D_WGRAD_BIG=0: without the 12-tile forms (A/B switch)
+  static const bool on = !getenv("USC3D_WGRAD_BIG") || atoi(getenv("USC3D_WGRAD_BIG")) != 0;
+  return on;
+}
 static int wgrad_full_ct(int ctiles, int NBf) {
+  if (wgrad_big_tiles()) {
+    if (NBf == 3 && ctiles % 3 != 0 && ctiles % 4 == 0) return 4;     // e.g. 128 -> 96: 148 -> 134 us per launch on average
+    // (the mirror form <3,4> for 96 -> 128 measured SLOWER than one input tile per workgroup, 167 vs 75 us on the K = 1
+    //  layer of the finest level: not used)
+  }
   return (ctiles % 3 == 0 && NBf * 3 <= 9) ? 3 : ((ctiles % 4 == 0 && NBf * 4 <= 9) ? 4 : ((ctiles % 2 == 0 && NBf * 2 <= 9) ? 2 : 1));
 }
 static int64_t wgrad_full_splits(int K, int ctiles, int cb, int CT, int NBf, int64_t n_rows) {
@@ -1259,7 +1278,7 @@ int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout, int32_t 
     // wgrad: mirror usc_spconv_wgrad's choice (full kernel: NB | 1<<8 | 1<<13 | CT<<16)
     const int ctiles = cin / 32, cb = cout / 32;
     const int NBf = (cb % 3 == 0) ? 3 : (cb % 4 == 0 ? 4 : (cb % 2 == 0 ? 2 : 1));
-    if (cin % 32 == 0 && cout % 32 == 0 && !(NBf == 3 && ctiles % 3 != 0)) {
+    if (cin % 32 == 0 && cout % 32 == 0 && (!(NBf == 3 && ctiles % 3 != 0) || (wgrad_big_tiles() && ctiles % 4 == 0))) {
       const int CT = (ctiles % 3 == 0 && NBf * 3 <= 9) ? 3 : ((ctiles % 4 == 0 && NBf * 4 <= 9) ? 4 : ((ctiles % 2 == 0 && NBf * 2 <= 9) ? 2 : 1));
       return NBf | (1 << 8) | (1 << 13) | (CT << 16);
     }
@@ -1366,7 +1385,7 @@ int64_t usc_spconv_wgrad_ws_bytes_rows(int32_t K, int32_t cin, int32_t cout, int
   const int ctiles = cin / 32, cb = cout / 32;
   if (cin % 32 == 0 && cout % 32 == 0 && cb > 0) {
     const int NBf = wgrad_full_nb(cb);
-    if (!(NBf == 3 && ctiles % 3 != 0))
+    if (!(NBf == 3 && ctiles % 3 != 0) || (wgrad_big_tiles() && ctiles % 4 == 0))
       return wgrad_full_splits(K, ctiles, cb, wgrad_full_ct(ctiles, NBf), NBf, n_rows) * numel * 4;
   }
 #endif
@@ -1394,6 +1413,12 @@ int usc_spconv_wgrad_table(const float* in, int32_t cin, const float* dy, int32_
   return USC_OK;
 }
 
+// > 0: usc_spconv_wgrad launches its all-input-tiles kernel with at most this many workgroups along x, each walking
+// several (offset, split) work items — set around the launches of the weight-gradient lane (units.hip), which run
+// BESIDE the backward pass's own chain and must leave it wave slots on every CU
+static int g_wgrad_grid_limit = getenv("USC3D_WGRAD_GRID_LIMIT") ? atoi(getenv("USC3D_WGRAD_GRID_LIMIT")) : 0;
+void usc_spconv_wgrad_grid_limit(int32_t max_workgroups) { g_wgrad_grid_limit = max_workgroups; }
+
 int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, int32_t K, const int32_t* a_idx,
                      const int32_t* b_idx, const int64_t* koff, int64_t n_rows, float* dW, int32_t accumulate, void* ws, int64_t ws_bytes,
                      usc_stream_t s) {
@@ -1410,7 +1435,7 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
   const int NBf = wgrad_full_nb(cb);
   // (128 -> 96 channels would need 4x3 tiles = 256 VGPRs + scratch, or 2x3 twice: both measured slower than the
   //  per-input-tile kernel below, 0.78 / 0.82 vs 0.73 ms)
-  if (cin % 32 == 0 && cout % 32 == 0 && !(NBf == 3 && ctiles % 3 != 0)) {
+  if (cin % 32 == 0 && cout % 32 == 0 && (!(NBf == 3 && ctiles % 3 != 0) || (wgrad_big_tiles() && ctiles % 4 == 0))) {
     // CT input tiles x NB column tiles per wave, CT*NB <= 9 accumulator tiles
     const int CT = wgrad_full_ct(ctiles, NBf);
     const int64_t S = wgrad_full_splits(K, ctiles, cb, CT, NBf, n_rows);
@@ -1418,12 +1443,17 @@ int usc_spconv_wgrad(const float* a, int32_t cin, const float* b, int32_t cout, 
     p.S = (int)S;
     if (S == 1) { p.direct = dW; p.accumulate = accumulate; }   // one slice: written (added) straight into dW
     dim3 grid((unsigned)(K * S), (unsigned)(ctiles / CT), (unsigned)(cb / NBf));
+    if (g_wgrad_grid_limit > 0 && (int64_t)K * S > g_wgrad_grid_limit) {   // background form (usc_spconv_wgrad_grid_limit)
+      p.vblocks = (int)(K * S);
+      grid.x = (unsigned)g_wgrad_grid_limit;
+    }
     const size_t lds = (size_t)4 * NBf * 16 * 64 * sizeof(float);   // four waves x one input-channel tile
 #define USC_WF(C, N) if (CT == C && NBf == N) { \
       static bool attr_set = false; auto kfn = wgrad_full_kernel<C, N>; \
       if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; } \
       hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, p, WgradGroup{}); }
     USC_WF(3, 3) USC_WF(2, 3) USC_WF(1, 3) USC_WF(2, 4) USC_WF(1, 4) USC_WF(4, 2) USC_WF(3, 2) USC_WF(2, 2) USC_WF(1, 2) USC_WF(4, 1) USC_WF(3, 1) USC_WF(2, 1) USC_WF(1, 1)
+    USC_WF(4, 3)
 #undef USC_WF
     if (S > 1)
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(numel, 256)), dim3(256), 0, st, (const float*)ws, (int)S,

@@ -461,6 +461,15 @@ int usc_spconv_sorted_gemm(const float* in, int64_t n_in, int32_t cin, const flo
                            const int32_t* nbr, const int32_t* perm, const uint32_t* tile_mask, int64_t n_out,
                            const float* bias, float* out, int32_t accumulate, int32_t w_transposed, void* ws,
                            int64_t ws_bytes, usc_stream_t s) {
+  return usc_spconv_sorted_gemm_ex(in, n_in, cin, W, K, cout, nbr, perm, tile_mask, n_out, bias, out, accumulate,
+                                   w_transposed, ws, ws_bytes, nullptr, s);
+}
+
+int usc_spconv_sorted_gemm_ex(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
+                              const int32_t* nbr, const int32_t* perm, const uint32_t* tile_mask, int64_t n_out,
+                              const float* bias, float* out, int32_t accumulate, int32_t w_transposed, void* ws,
+                              int64_t ws_bytes, int32_t* slices_left, usc_stream_t s) {
+  if (slices_left) *slices_left = 0;
   USC_REQUIRE(n_in >= 0 && n_out >= 0 && K >= 1 && K <= 32, "usc_spconv_sorted_gemm: bad sizes");
   USC_REQUIRE(cin >= 32 && cin % 32 == 0 && cout >= 32 && cout % 32 == 0 && cin <= kZeroFloats,
               "usc_spconv_sorted_gemm: channels must be multiples of 32 (cin <= 4096)");
@@ -481,7 +490,12 @@ int usc_spconv_sorted_gemm(const float* in, int64_t n_in, int32_t cin, const flo
   else if (pl.NB == 3) hipLaunchKernelGGL((gather_gemm_sorted_kernel<3, 8>), grid, dim3(512), 0, st, p);
   else if (pl.NB == 2) hipLaunchKernelGGL((gather_gemm_sorted_kernel<2, 8>), grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL((gather_gemm_sorted_kernel<1, 8>), grid, dim3(512), 0, st, p);
-  if (pl.G > 1) launch_group_reduce((const float*)ws, pl.G, n_out * cout / 4, (int)cout, bias, (int)accumulate, out, st);
+  if (pl.G > 1) {
+    // slices_left: the caller sums the G slices [G][n_out][cout] at the start of `ws` itself (fused with what it does
+    // next: usc_bn_tile_forward / _backward) — `out`, `bias` and `accumulate` are then the caller's business too
+    if (slices_left && !bias) *slices_left = pl.G;
+    else launch_group_reduce((const float*)ws, pl.G, n_out * cout / 4, (int)cout, bias, (int)accumulate, out, st);
+  }
   USC_CHECK_LAUNCH("usc_spconv_sorted_gemm");
   return USC_OK;
 }

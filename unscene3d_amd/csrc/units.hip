@@ -49,17 +49,24 @@ int64_t table_gemm_ws(const usc_kmap* m, int64_t n_out, int cin, int cout, int K
 
 // out[o] (+)= sum_k in[nbr[k][o]] W[k]; `wt`: W is given as the forward [K, cout, cin] and the mirrored transpose
 // W'[k][c][n] = W[K-1-k][n][c] is meant (mirror only when K > 1).  `nbr` NULL: identity rows (1x1).
+// slices the split-K launch left un-reduced for whoever consumes `out` next (usc_spconv_sorted_gemm_ex)
+struct Slices { const float* partial = nullptr; int G = 0; };
+
 int table_gemm(const usc_kmap* m, const int32_t* nbr, const float* in, int64_t n_in, int cin, const float* W, int K,
                int cout, int64_t n_out, const float* bias, float* out, int accumulate, int wt, WsCursor ws,
-               usc_stream_t s) {
+               usc_stream_t s, Slices* left = nullptr) {
+  if (left) *left = Slices{};
   if (n_out == 0) return USC_OK;
   const bool compact = nbr && table_is_compact(n_out, cin, cout, K);
   if (nbr && nbr == m->nbr && sorted_ok(m, cin, cout) && !compact) {
     const int64_t b = usc_spconv_sorted_ws_bytes(n_out, cin, cout, K);
     void* w = b > 0 ? ws.take(b) : nullptr;
     USC_REQUIRE(b == 0 || w, "usc unit: workspace too small (sorted gemm)");
-    return usc_spconv_sorted_gemm(in, n_in, cin, W, K, cout, nbr, m->perm, m->tile_mask, n_out, bias, out, accumulate,
-                                  wt, w, b, s);
+    int32_t G = 0;
+    const int rc = usc_spconv_sorted_gemm_ex(in, n_in, cin, W, K, cout, nbr, m->perm, m->tile_mask, n_out, bias, out,
+                                             accumulate, wt, w, b, left ? &G : nullptr, s);
+    if (!rc && left && G > 0) { left->partial = (const float*)w; left->G = G; }
+    return rc;
   }
   if (wt && !compact) {
     float* Wt = (float*)ws.take((int64_t)K * cin * cout * 4);
@@ -285,8 +292,17 @@ int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin, int32_t 
   return (fwd > bwd ? fwd : bwd) + 256;
 }
 
+static int conv_forward_impl(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                             const float* bias, float* y, void* ws, int64_t ws_bytes, usc_stream_t s, Slices* left);
+
 int usc_conv_forward(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
                      const float* bias, float* y, void* ws, int64_t ws_bytes, usc_stream_t s) {
+  return conv_forward_impl(m, kind, x, cin, W, cout, bias, y, ws, ws_bytes, s, nullptr);
+}
+
+static int conv_forward_impl(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                             const float* bias, float* y, void* ws, int64_t ws_bytes, usc_stream_t s, Slices* left) {
+  if (left) *left = Slices{};
   int rc = check_map(m, kind, cin, cout, "usc_conv_forward");
   if (rc) return rc;
   const ConvShape sh = conv_shape(m, kind);
@@ -299,12 +315,40 @@ int usc_conv_forward(const usc_kmap* m, int32_t kind, const float* x, int32_t ci
     USC_REQUIRE(!bias, "usc_conv_forward: bias is not supported on the pair-list form");
     return usc_spconv_pairs_gemm(x, cin, W, m->K, cout, m->pair_out, m->pair_in, m->koff, sh.n_out, y, s);
   }
-  return table_gemm(m, m->nbr, x, sh.n_in, cin, W, m->K, cout, sh.n_out, bias, y, 0, 0, cur, s);
+  return table_gemm(m, m->nbr, x, sh.n_in, cin, W, m->K, cout, sh.n_out, bias, y, 0, 0, cur, s, left);
 }
+
+// the input gradient of a convolution whose split-K slices are still to be summed: dx = (accumulate ? dx : 0) + sum of
+// the G slices; consumed by the batch norm backward of the unit whose output gradient dx is (tile form), or reduced by
+// flush_pending
+struct Pending { float* dx = nullptr; const float* partial = nullptr; int G = 0; int64_t n = 0; int c = 0; int accumulate = 0; };
+
+static int flush_pending(Pending& p, usc_stream_t s) {
+  if (p.G <= 0) return USC_OK;
+  const int rc = usc_group_reduce(p.partial, p.G, p.n, p.c, nullptr, p.accumulate, p.dx, s);
+  p = Pending{};
+  return rc;
+}
+
+static bool tile_form_on() {
+  static const bool on = usc_bn_tile_max_rows() > 0;
+  return on;
+}
+
+static int conv_backward_impl(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                              const float* dy, float* dx, int32_t dx_accumulate, float* dW, int32_t dW_accumulate, void* ws,
+                              int64_t ws_bytes, usc_stream_t s, Pending* out);
 
 int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
                       const float* dy, float* dx, int32_t dx_accumulate, float* dW, int32_t dW_accumulate, void* ws,
                       int64_t ws_bytes, usc_stream_t s) {
+  return conv_backward_impl(m, kind, x, cin, W, cout, dy, dx, dx_accumulate, dW, dW_accumulate, ws, ws_bytes, s, nullptr);
+}
+
+static int conv_backward_impl(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                              const float* dy, float* dx, int32_t dx_accumulate, float* dW, int32_t dW_accumulate, void* ws,
+                              int64_t ws_bytes, usc_stream_t s, Pending* out) {
+  if (out) *out = Pending{};
   int rc = check_map(m, kind, cin, cout, "usc_conv_backward");
   if (rc) return rc;
   const ConvShape sh = conv_shape(m, kind);
@@ -338,6 +382,16 @@ int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t c
   SideStream* side = (dx && dW && sh.n_in > 0 && sh.n_in <= kForkMaxRows && sh.n_out <= kForkMaxRows) ? side_for_current_device() : nullptr;
   hipStream_t wst = as_stream(s);
   int64_t dgrad_bytes = 0;
+  // slices may stay behind only when the consumer can take them (tile-form batch norm on the input map) and nothing in
+  // this call overwrites them: the weight gradient then takes its scratch behind the input gradient's region
+  Slices left;
+  const bool may_defer = out && dx && !side && tile_form_on() && usc_bn_tile_ok(sh.n_in, cin);
+  if (may_defer) {
+    int64_t f_, w_;
+    conv_ws_parts(m, kind, cin, cout, &f_, &dgrad_bytes, &w_);
+    if (dgrad_bytes + w_ > cur.bytes) dgrad_bytes = 0;
+  }
+  Slices* want = (may_defer && dgrad_bytes > 0) ? &left : nullptr;
   if (side) {
     // disjoint scratch: [0, dgrad_bytes) for this stream, the rest for the side stream
     int64_t f_, w_;
@@ -353,7 +407,7 @@ int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t c
   if (dx && sh.n_in > 0) {
     if (kind == USC_CONV_SAME) {
       // stride-1 map: the mirrored offset reaches the rows that read row i; transpose folded where the kernel can
-      rc = table_gemm(m, m->nbr, dy, sh.n_out, cout, W, K, cin, sh.n_in, nullptr, dx, dx_accumulate, 1, cur, s);
+      rc = table_gemm(m, m->nbr, dy, sh.n_out, cout, W, K, cin, sh.n_in, nullptr, dx, dx_accumulate, 1, cur, s, want);
     } else if (kind == USC_CONV_DOWN) {
       USC_REQUIRE(!dx_accumulate, "usc_conv_backward: accumulate is not supported on the pair-list form");
       USC_REQUIRE(m->pair_in && m->pair_out && m->koff, "usc_conv_backward: strided conv needs the pair lists");
@@ -366,13 +420,16 @@ int usc_conv_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t c
       USC_REQUIRE(Wt, "usc_conv_backward: workspace too small");
       rc = usc_weight_transpose(W, K, cin, cout, 0, Wt, s);
       // dx[coarse] = sum_k dy[child k of coarse] W[k]^T: the child table again, gather form
-      if (!rc) rc = table_gemm(m, m->nbr, dy, sh.n_out, cout, Wt, K, cin, sh.n_in, nullptr, dx, dx_accumulate, 0, cur, s);
+      if (!rc) rc = table_gemm(m, m->nbr, dy, sh.n_out, cout, Wt, K, cin, sh.n_in, nullptr, dx, dx_accumulate, 0, cur, s, want);
+    }
+    if (!rc && left.G > 0) {
+      out->dx = dx; out->partial = left.partial; out->G = left.G; out->n = sh.n_in; out->c = cin; out->accumulate = dx_accumulate;
     }
     if (rc) dW = nullptr;   // skip the weight gradient, still join below
   }
   if (dW) {
     // same stream: the weight gradient reuses the scratch from the start (stream order); forked: its own region
-    WsCursor wc{(char*)ws, ws ? ws_bytes : 0, side ? dgrad_bytes : 0};
+    WsCursor wc{(char*)ws, ws ? ws_bytes : 0, (side || left.G > 0) ? dgrad_bytes : 0};
     const int64_t rows = m->nbr ? m->pair_capacity : sh.n_in;
     const int64_t b = usc_spconv_wgrad_ws_bytes_rows(K, cin, cout, rows);
     void* w = wc.take(b);
@@ -414,10 +471,17 @@ int usc_conv_bn_act_forward(const usc_kmap* m, int32_t kind, const float* x, int
   const int64_t sb = usc_colstats_ws_bytes(sh.n_out, cout);
   void* sws = cur.take(sb);                       // BN partials first: the conv's scratch takes the rest
   USC_REQUIRE(sws, "usc_conv_bn_act_forward: workspace too small");
-  int rc = usc_conv_forward(m, kind, x, cin, W, cout, nullptr, y, cur.rest(), cur.left(), s);
+  // tile form (coarse levels): the convolution leaves its split-K slices behind, two launches do the rest
+  const bool tile = bn->training && tile_form_on() && usc_bn_tile_ok(sh.n_out, cout) && sb >= usc_bn_tile_ws_bytes(cout);
+  Slices left;
+  int rc = conv_forward_impl(m, kind, x, cin, W, cout, nullptr, y, cur.rest(), cur.left(), s, tile ? &left : nullptr);
   if (rc) return rc;
   if (sh.n_out == 0) return USC_OK;
   float* mean = stats, *invstd = stats + cout, *scale = stats + 2 * cout, *shift = stats + 3 * cout;
+  if (tile)
+    return usc_bn_tile_forward(left.partial, left.G, y, sh.n_out, cout, bn->gamma, bn->beta, bn->eps, bn->momentum,
+                               bn->running_mean, bn->running_var, bn->num_batches_tracked, mean, invstd, scale, shift,
+                               residual, relu, out, sws, sb, s);
   if (bn->training) {
     rc = usc_bn_forward_stats(y, sh.n_out, cout, bn->gamma, bn->beta, bn->eps, bn->momentum, bn->running_mean,
                               bn->running_var, bn->num_batches_tracked, mean, invstd, scale, shift, sws, sb, s);
@@ -430,11 +494,29 @@ int usc_conv_bn_act_forward(const usc_kmap* m, int32_t kind, const float* x, int
   return usc_bn_apply(y, scale, shift, residual, relu, out, sh.n_out, cout, s);
 }
 
+static int unit_backward_impl(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                              const usc_bn* bn, const float* y, const float* stats, const float* out_relu,
+                              const float* dout, float* dy, float* dres, float* dx, int32_t dx_accumulate, float* dW,
+                              int32_t dW_accumulate, float* dgamma, float* dbeta, int32_t dbn_accumulate, void* ws,
+                              int64_t ws_bytes, usc_stream_t s, Pending* in, Pending* out);
+
 int usc_conv_bn_act_backward(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
                              const usc_bn* bn, const float* y, const float* stats, const float* out_relu,
                              const float* dout, float* dy, float* dres, float* dx, int32_t dx_accumulate, float* dW,
                              int32_t dW_accumulate, float* dgamma, float* dbeta, int32_t dbn_accumulate, void* ws,
                              int64_t ws_bytes, usc_stream_t s) {
+  return unit_backward_impl(m, kind, x, cin, W, cout, bn, y, stats, out_relu, dout, dy, dres, dx, dx_accumulate, dW,
+                            dW_accumulate, dgamma, dbeta, dbn_accumulate, ws, ws_bytes, s, nullptr, nullptr);
+}
+
+// in: slices of THIS unit's output gradient (in->dx == dout) left by the previous step, or NULL / empty;
+// out: receives the slices of this unit's input gradient when they may stay un-reduced (else left empty)
+static int unit_backward_impl(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
+                              const usc_bn* bn, const float* y, const float* stats, const float* out_relu,
+                              const float* dout, float* dy, float* dres, float* dx, int32_t dx_accumulate, float* dW,
+                              int32_t dW_accumulate, float* dgamma, float* dbeta, int32_t dbn_accumulate, void* ws,
+                              int64_t ws_bytes, usc_stream_t s, Pending* in, Pending* out) {
+  if (out) *out = Pending{};
   USC_REQUIRE(bn && bn->c == cout, "usc_conv_bn_act_backward: batch-norm width must equal the conv's output width");
   USC_REQUIRE(y && stats && dout && dy && dgamma && dbeta && bn->gamma, "usc_conv_bn_act_backward: null pointer");
   const ConvShape sh = conv_shape(m, kind);
@@ -445,17 +527,29 @@ int usc_conv_bn_act_backward(const usc_kmap* m, int32_t kind, const float* x, in
   float* red = (float*)cur.take(2 * (int64_t)cout * 4);   // mean_g | mean_gxhat
   USC_REQUIRE(sws && red, "usc_conv_bn_act_backward: workspace too small");
   const float* mean = stats, *invstd = stats + cout;
-  int rc = usc_bn_backward_reduce(y, dout, out_relu, mean, invstd, sh.n_out, cout, bn->training, dbn_accumulate, dgamma,
-                                  dbeta, red, red + cout, sws, sb, s);
-  if (rc) return rc;
-  rc = usc_bn_backward_dx(y, dout, out_relu, mean, invstd, bn->gamma, red, red + cout, dy, dres, sh.n_out, cout, s);
-  if (rc) return rc;
-  return usc_conv_backward(m, kind, x, cin, W, cout, dy, dx, dx_accumulate, dW, dW_accumulate, cur.rest(), cur.left(), s);
+  int rc;
+  const bool has_in = in && in->G > 0;
+  if (has_in) USC_REQUIRE(in->dx == dout && in->n == sh.n_out && in->c == cout, "usc unit: pending slices do not belong to this unit");
+  if (tile_form_on() && usc_bn_tile_ok(sh.n_out, cout) && sb >= usc_bn_tile_ws_bytes(cout)) {
+    rc = usc_bn_tile_backward(has_in ? in->partial : nullptr, has_in ? in->G : 0, has_in ? in->accumulate : 0, (float*)dout, y,
+                              out_relu, mean, invstd, bn->gamma, sh.n_out, cout, bn->training, dbn_accumulate, dgamma,
+                              dbeta, dy, dres, sws, sb, s);
+    if (has_in) *in = Pending{};
+    if (rc) return rc;
+  } else {
+    if (has_in) { rc = flush_pending(*in, s); if (rc) return rc; }
+    rc = usc_bn_backward_reduce(y, dout, out_relu, mean, invstd, sh.n_out, cout, bn->training, dbn_accumulate, dgamma,
+                                dbeta, red, red + cout, sws, sb, s);
+    if (rc) return rc;
+    rc = usc_bn_backward_dx(y, dout, out_relu, mean, invstd, bn->gamma, red, red + cout, dy, dres, sh.n_out, cout, s);
+    if (rc) return rc;
+  }
+  return conv_backward_impl(m, kind, x, cin, W, cout, dy, dx, dx_accumulate, dW, dW_accumulate, cur.rest(), cur.left(), s, out);
 }
 
 int32_t usc_step_size(void) { return (int32_t)sizeof(usc_step); }
 
-int64_t usc_program_ws_bytes(const usc_step* steps, int32_t n_steps) {
+static int64_t program_half_bytes(const usc_step* steps, int32_t n_steps) {
   int64_t need = 256;
   if (!steps) return need;
   for (int i = 0; i < n_steps; ++i) {
@@ -465,16 +559,31 @@ int64_t usc_program_ws_bytes(const usc_step* steps, int32_t n_steps) {
       if (b > need) need = b;
     }
   }
-  return need;
+  return align_up(need, 256);
 }
 
-int usc_program_run(const usc_step* steps, int32_t begin, int32_t end, void* ws, int64_t ws_bytes, usc_stream_t s) {
+// two halves: step i works in half i & 1, so the input-gradient slices a backward step leaves for the next one survive it
+int64_t usc_program_ws_bytes(const usc_step* steps, int32_t n_steps) { return 2 * program_half_bytes(steps, n_steps) + 256; }
+
+int usc_program_run(const usc_step* steps, int32_t begin, int32_t end, void* ws_all, int64_t ws_all_bytes, usc_stream_t s) {
   USC_REQUIRE(steps && begin >= 0 && end >= begin, "usc_program_run: bad step range");
   hipStream_t st = as_stream(s);
   DeferredWgrads q;
+  Pending pend;
   int rc = USC_OK;
+  // the scratch in two halves (see usc_program_ws_bytes); a caller that sized it for one step only gets the old behaviour
+  const int64_t half = ws_all_bytes > 256 ? (((ws_all_bytes - 256) / 2) & ~(int64_t)255) : 0;
+  const bool two = ws_all && half >= program_half_bytes(steps + begin, end - begin);
+  void* ws = ws_all;
+  int64_t ws_bytes = two ? half : ws_all_bytes;
   for (int i = begin; i < end && !rc; ++i) {
     const usc_step& t = steps[i];
+    if (two) ws = (char*)ws_all + (i & 1) * half;
+    // slices left by the previous step: only the backward of the unit whose output gradient they are can take them
+    if (pend.G > 0 && !(t.op == USC_STEP_UNIT_BWD && t.dout == pend.dx)) {
+      rc = flush_pending(pend, s);
+      if (rc) break;
+    }
     switch (t.op) {
       case USC_STEP_UNIT_FWD:
         rc = usc_conv_bn_act_forward(t.map, t.kind, t.x, t.cin, t.W, t.cout, t.bn, t.residual, t.relu, t.y, t.stats, t.out,
@@ -482,14 +591,22 @@ int usc_program_run(const usc_step* steps, int32_t begin, int32_t end, void* ws,
         break;
       case USC_STEP_UNIT_BWD: {
         USC_REQUIRE(t.map, "usc_program_run: step %d has no kernel map", i);
-        const bool defer = t.defer_wgrad && t.dW && t.dW_accumulate && t.kind == USC_CONV_SAME && t.map->K > 1 && t.map->pair_in;
+        // the same rule as units.py::_defer_wgrad: only shapes the grouped launch can take are postponed (the 3-channel
+        // stem keeps its table-form kernel, fine-level convolutions that can never group run at once)
+        const bool defer = t.defer_wgrad && t.dW && t.dW_accumulate && t.kind == USC_CONV_SAME && t.map->K > 1 && t.map->pair_in &&
+                           t.cin % 32 == 0 && t.cout % 32 == 0 &&
+                           (usc_spconv_wgrad_group_ok(2, t.cin, t.cout, t.map->K, t.map->pair_capacity) ||
+                            usc_spconv_wgrad_group_ok(usc_spconv_wgrad_group_max(), t.cin, t.cout, t.map->K, t.map->pair_capacity));
         if (defer && q.n > 0 && (q.map != t.map || q.cin != t.cin || q.cout != t.cout || q.n == 16)) {
-          rc = flush_deferred(q, ws, ws_bytes, s);
+          rc = flush_deferred(q, ws, ws_bytes, s);       // (this step's half: the previous step's slices are in the other)
           if (rc) break;
         }
-        rc = usc_conv_bn_act_backward(t.map, t.kind, t.x, t.cin, t.W, t.cout, t.bn, t.y, t.stats, t.out, t.dout, t.dy, t.dres,
-                                      t.dx, t.dx_accumulate, defer ? nullptr : t.dW, t.dW_accumulate, t.dgamma, t.dbeta,
-                                      t.dbn_accumulate, ws, ws_bytes, s);
+        Pending next;
+        rc = unit_backward_impl(t.map, t.kind, t.x, t.cin, t.W, t.cout, t.bn, t.y, t.stats, t.out, t.dout, t.dy, t.dres,
+                                t.dx, t.dx_accumulate, defer ? nullptr : t.dW, t.dW_accumulate, t.dgamma, t.dbeta,
+                                t.dbn_accumulate, ws, ws_bytes, s, &pend, two ? &next : nullptr);
+        if (!rc && pend.G > 0) rc = flush_pending(pend, s);       // (not consumed: cannot happen, kept for safety)
+        pend = next;
         if (!rc && defer) {          // x and this step's own dy stay valid until the end of the call (caller's arenas)
           q.map = t.map; q.cin = t.cin; q.cout = t.cout;
           q.a[q.n] = t.x; q.b[q.n] = t.dy; q.dW[q.n] = t.dW;
@@ -522,8 +639,11 @@ int usc_program_run(const usc_step* steps, int32_t begin, int32_t end, void* ws,
         rc = USC_ERR_ARG;
     }
   }
+  const int rc3 = flush_pending(pend, s);
+  // the queued weight gradients last: with two halves, the one the pending slices (just reduced, in stream order) were not in
   const int rc2 = flush_deferred(q, ws, ws_bytes, s);
   if (rc) return rc;
+  if (rc3) return rc3;
   if (rc2) return rc2;
   USC_CHECK_LAUNCH("usc_program_run");
   return USC_OK;

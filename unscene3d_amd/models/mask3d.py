@@ -594,7 +594,12 @@ class _PaddedRows:
         self.table, self.q = table, q
 
     def __getitem__(self, i):
-        return (self.table[i], self.q)
+        t = self.table
+        if t.shape[0] == 1 and i == 0:
+            # a view, not a select: SelectBackward would zero-fill a [1, Qp, d] tensor and copy the gradient into it
+            # (two stock launches per mask_module call)
+            return (t.view(t.shape[1], t.shape[2]), self.q)
+        return (t[i], self.q)
 
 
 def _mask_logits(feats, mask_embed):

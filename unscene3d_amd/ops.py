@@ -714,7 +714,11 @@ class _SampleKeys(torch.autograd.Function):
         check(lib.usc_sample_keys(_ptr(feats), c, _ptr(mask), q, _ptr(pos), p, _ptr(idx), n_scenes, K, nv, _ptr(of),
                                   _ptr(om), _ptr(op), _ptr(ws), ws.numel(), _stream()), "usc_sample_keys")
         ctx.save_for_backward(idx)
+        # the mask and positional outputs never carry a gradient: without this the engine hands backward() zero-filled
+        # [B, K, Q] / [B, K, p] tensors for them (two stock fills per decoder pass, up to 26 us for the bool one)
+        ctx.set_materialize_grads(False)
         ctx.n_src, ctx.unique = feats.shape[0], bool(unique)
+        ctx.K, ctx.n_valid = int(K), [min(int(v), int(K)) for v in n_valid]
         ctx.sink = sink if (sink is not None and ctx.needs_input_grad[0]) else None     # (forward runs under no_grad)
         if ctx.sink is not None:
             ctx.sink.pending += 1
@@ -727,26 +731,46 @@ class _SampleKeys(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dfeats, *_):
         (idx,) = ctx.saved_tensors
-        dfeats = dfeats.contiguous().view(idx.shape[0], -1)
         sink = ctx.sink
+        if dfeats is None:                     # nothing downstream used the sampled features
+            if sink is not None:
+                sink.pending -= 1
+                if sink.pending == 0 and sink.buf is not None:
+                    dsrc, sink.buf = sink.buf, None
+                    return (dsrc,) + (None,) * 9
+            return (None,) * 10
+        dfeats = dfeats.contiguous().view(idx.shape[0], -1)
+        c = dfeats.shape[1]
+
+        def scatter(dst, add):
+            # The first n_valid[b] keys of a scene are distinct rows (a random subset, or every row of the scene); the
+            # rest is padding that repeats row 0 and is masked for every query, so its gradient rows are exact zeros:
+            # only the distinct prefix is scattered, with plain (or read-modify-write) row stores.  (Scattering the
+            # padding with float atomics serialised on row 0: 214 us per pass on a 20 k-voxel scene.)
+            fn = lib.usc_scatter_rows_unique_add if add else lib.usc_scatter_rows_unique
+            if ctx.unique or all(v == ctx.K for v in ctx.n_valid):
+                check(fn(_ptr(dfeats), c, _ptr(idx), idx.shape[0], _ptr(dst), _stream()), "usc_scatter_rows")
+                return
+            for b, nv in enumerate(ctx.n_valid):
+                if nv > 0:
+                    check(fn(dfeats.data_ptr() + 4 * b * ctx.K * c, c, idx.data_ptr() + 8 * b * ctx.K, nv, _ptr(dst),
+                             _stream()), "usc_scatter_rows")
+
         if sink is not None:
             first = sink.buf is None
             if first:
-                sink.buf = torch.zeros((ctx.n_src, dfeats.shape[1]), dtype=torch.float32, device=dfeats.device)
+                sink.buf = torch.zeros((ctx.n_src, c), dtype=torch.float32, device=dfeats.device)
                 if not sink.check_queued:
                     sink.check_queued = True
                     torch.autograd.Variable._execution_engine.queue_callback(sink._check)
-            fn = (lib.usc_scatter_rows_unique if first else lib.usc_scatter_rows_unique_add) if ctx.unique \
-                else lib.usc_scatter_add_rows
-            check(fn(_ptr(dfeats), dfeats.shape[1], _ptr(idx), idx.shape[0], _ptr(sink.buf), _stream()), "usc_scatter_rows")
+            scatter(sink.buf, add=not first)
             sink.pending -= 1
             if sink.pending > 0:
                 return (None,) * 10
             dsrc, sink.buf = sink.buf, None
             return (dsrc,) + (None,) * 9
-        dsrc = torch.zeros((ctx.n_src, dfeats.shape[1]), dtype=torch.float32, device=dfeats.device)
-        fn = lib.usc_scatter_rows_unique if ctx.unique else lib.usc_scatter_add_rows
-        check(fn(_ptr(dfeats), dfeats.shape[1], _ptr(idx), idx.shape[0], _ptr(dsrc), _stream()), "usc_scatter_add_rows")
+        dsrc = torch.zeros((ctx.n_src, c), dtype=torch.float32, device=dfeats.device)
+        scatter(dsrc, add=False)
         return (dsrc,) + (None,) * 9
 
 
