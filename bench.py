@@ -50,14 +50,22 @@ def parse(argv=None):
     ap.add_argument("--no-prefetch", action="store_true",
                     help="voxelise and build the coordinate maps at the start of the step on the compute stream "
                          "instead of ahead of time on a side stream")
-    ap.add_argument("--spatial-sort", type=int, default=5, metavar="SHIFT",
-                    help="voxel rows grouped into z-ordered cells of (2^SHIFT)^3 voxels by the collate (a consistent row "
-                         "permutation; sparse_quantize itself stays bit-exact).  5 = 64 cm cells: same step time as the "
-                         "reference's first-occurrence order, 2.3x instead of 6.9x the algorithmic bytes fetched by the "
-                         "dominant conv kernel (profiles/r02_spatial_sort_sweep.txt).  0 = off")
+    ap.add_argument("--prefetch-ahead", type=int, default=0, metavar="N",
+                    help="DIAGNOSTIC (not the metric: the collate leaves the timed region): prepare N batches before the "
+                         "timed loop and consume them without issuing new ones — the step without the prefetch stream's "
+                         "kernels running beside it")
+    ap.add_argument("--spatial-sort", type=int, default=0, metavar="SHIFT",
+                    help="row order of `value`.  0 (default) = the reference's first-occurrence order "
+                         "(ME.utils.sparse_quantize, datasets/utils.py:403-408): FPS and key sampling pick the rows the "
+                         "reference would pick.  SHIFT > 0: voxel rows grouped into z-ordered cells of (2^SHIFT)^3 voxels by "
+                         "the collate (a consistent row permutation; sparse_quantize itself stays bit-exact)")
+    ap.add_argument("--zorder-shift", type=int, default=5, metavar="SHIFT",
+                    help="the second timed loop (`value_zorder`) runs the same steps with the rows in z-ordered cells of "
+                         "(2^SHIFT)^3 voxels: 5 = 64 cm cells, 2.3x instead of 6.9x the algorithmic bytes fetched by the "
+                         "dominant conv kernel at the same step time (profiles/r02_spatial_sort_sweep.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-reference-order", action="store_true",
-                    help="skip the second timed loop in the reference's own row order (`value_reference_order`)")
+    ap.add_argument("--no-reference-order", "--no-zorder", dest="no_second_order", action="store_true",
+                    help="skip the second timed loop in the other row order (`value_zorder`)")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, the measured configuration); gloo only to smoke-test the N>1 code path on a box "
                          "with fewer GPUs than ranks (ranks then share devices)")
@@ -65,9 +73,13 @@ def parse(argv=None):
                     help="scenes per rank and step (the reference trains with batch_size 5-8 per GPU, conf/data/indoor.yaml:25; "
                          "the headline metric is quoted at 1): B distinct synthetic scenes collated into one sparse batch, "
                          "decoder passes captured for batch B")
-    ap.add_argument("--rotate", type=int, default=0, metavar="N",
-                    help="rotate N distinct scene sets (voxel counts spread over +-20 %% of --voxels) through the steps "
-                         "instead of replaying one; per-step times p10/p50/p90 are added to the line")
+    ap.add_argument("--rotate", type=int, default=8, metavar="N",
+                    help="rotate N distinct scene sets through the steps (per-step times p10/p50/p90 are added to the "
+                         "line); 0 or 1 = replay one scene")
+    ap.add_argument("--rotate-spread", type=float, default=0.02, metavar="F",
+                    help="voxel counts of the rotated scenes spread over +-F of --voxels: 0.02 = SURVEY.md 8(d)'s "
+                         "tolerance for a `150 k-voxel` scene (the metric's scene size); 0.2 = ScanNet-like size spread "
+                         "(what the N-rank sampler / skew report is exercised with)")
     ap.add_argument("--bucket-window", type=int, default=8, metavar="K",
                     help="with --rotate on N > 1 ranks the scenes are drawn through datasets/sampler.py "
                          "(DistributedSampler semantics): K steps' worth of scenes are sorted by size and dealt so that "
@@ -163,7 +175,8 @@ def make_mask3d_step(args, dev, rank, world):
         # the scenes of its own plan resident
         from unscene3d_amd.datasets.sampler import BucketedDistributedSampler
         n_pool = world * n_sets * B
-        scale = 0.8 + 0.4 * ((np.arange(n_pool) * 5) % n_pool) / max(1, n_pool - 1)
+        sp = float(args.rotate_spread)
+        scale = 1.0 - sp + 2 * sp * ((np.arange(n_pool) * 5) % n_pool) / max(1, n_pool - 1)
         sizes = (voxels * scale).astype(np.int64)
         sampler = BucketedDistributedSampler(sizes, world, rank, batch_size=B, window=max(1, args.bucket_window), seed=2000)
         plain = BucketedDistributedSampler(sizes, world, rank, batch_size=B, window=1, seed=2000)
@@ -180,7 +193,8 @@ def make_mask3d_step(args, dev, rank, world):
                      "planned_voxel_max_over_mean": sampler.imbalance(), "unbucketed_voxel_max_over_mean": plain.imbalance()}
     else:
         for j in range(n_sets):
-            scale = 1.0 if n_sets == 1 else 0.8 + 0.4 * ((j * 5) % n_sets) / max(1, n_sets - 1)   # spread, not sorted
+            sp = float(args.rotate_spread)
+            scale = 1.0 if n_sets == 1 else 1.0 - sp + 2 * sp * ((j * 5) % n_sets) / max(1, n_sets - 1)   # spread, not sorted
             seed = 2000 + rank if (B == 1 and j == 0) else 2000 + 1000 * rank + 16 * j
             ds = SyntheticFreeMaskDataset(n_scenes=B, target_voxels=int(voxels * scale), seed=seed)
             sets.append([resident(ds[i]) for i in range(B)])
@@ -202,10 +216,20 @@ def make_mask3d_step(args, dev, rank, world):
                                    threaded=os.environ.get("USC3D_PREFETCH_THREAD", "1") == "1")
         prefetch.submit(sets[0])       # the first batch, outside the timed region like the resident raw arrays
     state = {"k": 0, "marks": None}
+    ahead = []
+    if prefetch is not None and getattr(args, "prefetch_ahead", 0) > 0:
+        from unscene3d_amd.datasets.prefetch import _record_streams
+        prefetch.take()
+        ahead = [prefetch._issue(sets[k % n_sets]) for k in range(args.prefetch_ahead)]
+        torch.cuda.synchronize()
 
     def step(w):
         state["k"] += 1
-        if prefetch is not None:
+        if ahead:
+            batch, done = ahead.pop(0)
+            torch.cuda.current_stream().wait_event(done)
+            _record_streams(batch, torch.cuda.current_stream(), set())
+        elif prefetch is not None:
             batch = prefetch.take()
         else:
             batch = collate(sets[(state["k"] - 1) % n_sets])
@@ -229,8 +253,8 @@ def make_mask3d_step(args, dev, rank, world):
             flat.div_(w)
         opt.step()
         state["sched"].step()
-        if prefetch is not None:       # the next step's voxelisation + coordinate maps, on a side stream under backward
-            prefetch.submit(sets[state["k"] % n_sets])
+        if prefetch is not None and not ahead and not getattr(args, "prefetch_ahead", 0):
+            prefetch.submit(sets[state["k"] % n_sets])      # the next step's voxelisation + coordinate maps, on a side stream under backward
         return total.detach(), batch[0].coordinates.shape[0]
 
     state["sched"] = sched
@@ -623,10 +647,13 @@ def main():
         own["marks"] = []                  # per step: the point where this rank's backward is queued (before the exchange)
     if marks:
         marks[0].record()
+    nvox_sum = 0
     for k in range(args.steps):
         loss, nvox = step(world)
+        nvox_sum += int(nvox)
         if marks:
             marks[k + 1].record()          # device-side step boundaries (no host wait inside the timed loop)
+    nvox = nvox_sum / max(1, args.steps)   # mean voxels per step over the timed loop (the rotated scenes differ)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -640,12 +667,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # The same K steps once more with the collate in the REFERENCE's row order (ME.utils.sparse_quantize's
-    # first-occurrence order, datasets/utils.py:403-408): FPS starts at row 0 and key sampling indexes rows, so this is
-    # the order in which the step picks the queries / keys the reference would pick on the same raw scene.
+    # The same K steps once more in the OTHER row order: `value` is measured in the reference's first-occurrence order
+    # (ME.utils.sparse_quantize, datasets/utils.py:403-408 — FPS starts at row 0 and key sampling indexes rows, so this is
+    # the order in which the step picks the queries / keys the reference would pick on the same raw scene);
+    # `value_zorder` groups the rows into z-ordered cells (a consistent permutation of every per-voxel array).  When
+    # --spatial-sort SHIFT makes z-order the measured order, the second loop is the reference order instead.
     ref_order = None
-    if args.mode == "mask3d" and args.spatial_sort and not args.no_reference_order and hasattr(step, "set_spatial_sort"):
-        step.set_spatial_sort(0)
+    other = 0 if args.spatial_sort else args.zorder_shift
+    if args.mode == "mask3d" and not args.no_second_order and hasattr(step, "set_spatial_sort") and (other or args.spatial_sort):
+        step.set_spatial_sort(other)
         for _ in range(max(2, args.warmup)):
             step(world)
         torch.cuda.synchronize()
@@ -664,8 +694,9 @@ def main():
             t = torch.tensor([rdt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rdt = float(t.item())
-        ref_order = {"value_reference_order": world * getattr(step, "scenes_per_rank", 1) * args.steps / rdt,
-                     "ms_per_step_reference_order": 1e3 * rdt / args.steps}
+        tag = "zorder" if other else "reference_order"
+        ref_order = {f"value_{tag}": world * getattr(step, "scenes_per_rank", 1) * args.steps / rdt,
+                     f"ms_per_step_{tag}": 1e3 * rdt / args.steps}
         step.set_spatial_sort(args.spatial_sort)
         step(world)                         # back in the measured configuration for the instrumented step below
 
@@ -693,7 +724,7 @@ def main():
     if marks:
         per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
         q = lambda f: per[min(len(per) - 1, int(round(f * (len(per) - 1))))]
-        rot = {"rotated_scene_sets": args.rotate, "step_ms_p10": q(0.1), "step_ms_p50": q(0.5), "step_ms_p90": q(0.9),
+        rot = {"rotated_scene_sets": args.rotate, "rotate_spread": args.rotate_spread, "step_ms_p10": q(0.1), "step_ms_p50": q(0.5), "step_ms_p90": q(0.9),
                "step_ms_min": per[0], "step_ms_max": per[-1]}
     skew = None
     if own_marks is not None and len(own_marks) == args.steps:
@@ -717,7 +748,9 @@ def main():
                        "parallelism": f"dp{world}", "row_order": (f"z-order cells of {2 ** args.spatial_sort}^3 voxels "
                                                                    f"(value); first-occurrence (value_reference_order)"
                                                                    if args.mode == "mask3d" and args.spatial_sort else
-                                                                   "first-occurrence (reference)"), **(rot or {}), **({"rank_skew": skew} if skew else {}),
+                                                                   "first-occurrence = the reference's (value)" +
+                                                                   (f"; z-order cells of {2 ** args.zorder_shift}^3 voxels (value_zorder)"
+                                                                    if ref_order else "")), **(rot or {}), **({"rank_skew": skew} if skew else {}),
                        "loss": float(loss), "grad_allreduce": _allreduce_note(step, world),
                        **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,

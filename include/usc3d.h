@@ -54,6 +54,17 @@ int usc_device_count(void);
 int usc_voxel_floor_f64(const double* xyz, int64_t n, double voxel_size,
                         int32_t* coords_out, usc_stream_t s);
 
+/* HIP-FREE, fork-safe host forms (plain C++ over HOST pointers; no HIP call, no global state): the reference voxelises
+ * in forked DataLoader workers on the CPU (datasets/utils.py:403-414, conf/data/indoor.yaml:24), where the parent's HIP
+ * runtime must not be touched.  usc_voxel_floor_f64_host = usc_voxel_floor_f64; usc_unique_coords_host = the unique_idx /
+ * inverse pair of usc_coordmap_build(quant = 1) on coords i32[n,d], d = 3 (x,y,z) or 4 (b,x,y,z): first-occurrence rows
+ * in ascending order — ME.utils.sparse_quantize(return_index=True, return_inverse=True).  Bit-equal to the device path. */
+int usc_voxel_floor_f64_host(const double* xyz, int64_t n, double voxel_size,
+                             int32_t* coords_out);
+int usc_unique_coords_host(const int32_t* coords, int64_t n, int32_t d,
+                           int64_t* unique_idx, int64_t* inverse,
+                           int64_t* n_out);
+
 /* Hash-table capacity (slots, power of two) required for n coordinates. */
 int64_t usc_coordmap_capacity(int64_t n);
 /* Scratch bytes for usc_coordmap_build on n rows. */

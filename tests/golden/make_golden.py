@@ -13,6 +13,7 @@ not installed: SURVEY.md Appendix A), feeds them seeded inputs and stores inputs
     python tests/golden/make_golden.py export     # eval/export post-processing fixtures (trainer.eval_instance_step)
     python tests/golden/make_golden.py dataset    # self-train mask merge + validation-mode scene reader fixtures
     python tests/golden/make_golden.py elastic    # elastic distortion fixtures (datasets.semseg.elastic_distortion)
+    python tests/golden/make_golden.py state_dict # parameter names + shapes of the reference's Res16UNet34C / Mask3D module trees
 """
 import importlib
 import os
@@ -668,9 +669,117 @@ def make_elastic():
     np.savez_compressed(os.path.join(HERE, "elastic.npz"), **out)
 
 
+def make_state_dict():
+    """The parameter / buffer names and shapes of the reference's OWN module tree — models/res16unet.py:Res16UNet34C and
+    models/mask3d.py:Mask3D with conf/model/mask3d.yaml's values — as the contract "published checkpoints load by key".
+    The reference's classes are instantiated in place; MinkowskiEngine (not in the reference tree) is replaced by
+    parameter-only stand-ins that follow ME 0.5.4's published layer definitions: MinkowskiConvolution[Transpose] owns
+    `kernel` f32[K, Cin, Cout] (f32[Cin, Cout] for a kernel volume of 1) and `bias` f32[1, Cout]; MinkowskiBatchNorm
+    wraps `bn = nn.BatchNorm1d`.  The module NAMES (conv0p1s1, block1.0.conv1, cross_attention.0.2.multihead_attn ...)
+    and channel widths are the reference's."""
+    import json
+    from enum import Enum
+    from types import SimpleNamespace
+    import math
+
+    me = types.ModuleType("MinkowskiEngine")
+
+    class RegionType(Enum):
+        HYPER_CUBE = 0
+        HYPER_CROSS = 1
+        CUSTOM = 2
+
+    def _vol(ks, D):
+        ks = [ks] * D if isinstance(ks, int) else list(ks)
+        return int(math.prod(ks))
+
+    class KernelGenerator:
+        def __init__(self, kernel_size=-1, stride=1, dilation=1, is_transpose=False, region_type=RegionType.HYPER_CUBE,
+                     region_offsets=None, expand_coordinates=False, axis_types=None, dimension=-1):
+            assert region_type == RegionType.HYPER_CUBE
+            self.kernel_volume = _vol(kernel_size, dimension)
+
+    class _ConvBase(nn.Module):
+        def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                     kernel_generator=None, expand_coordinates=False, convolution_mode=None, dimension=-1):
+            super().__init__()
+            K = kernel_generator.kernel_volume if kernel_generator is not None else _vol(kernel_size, dimension)
+            self.kernel = nn.Parameter(torch.zeros(K, in_channels, out_channels) if K > 1
+                                       else torch.zeros(in_channels, out_channels))
+            if bias:
+                self.bias = nn.Parameter(torch.zeros(1, out_channels))
+
+    class MinkowskiConvolution(_ConvBase):
+        pass
+
+    class MinkowskiConvolutionTranspose(_ConvBase):
+        pass
+
+    class MinkowskiBatchNorm(nn.Module):
+        def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+            super().__init__()
+            self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                     track_running_stats=track_running_stats)
+
+    class _NoParams(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    class MinkowskiNetwork(nn.Module):
+        def __init__(self, D):
+            super().__init__()
+            self.D = D
+
+    for name, obj in dict(RegionType=RegionType, KernelGenerator=KernelGenerator, MinkowskiConvolution=MinkowskiConvolution,
+                          MinkowskiConvolutionTranspose=MinkowskiConvolutionTranspose, MinkowskiBatchNorm=MinkowskiBatchNorm,
+                          MinkowskiNetwork=MinkowskiNetwork).items():
+        setattr(me, name, obj)
+    for name in ("MinkowskiReLU", "MinkowskiAvgPooling", "MinkowskiSumPooling", "MinkowskiInstanceNorm",
+                 "MinkowskiGlobalPooling", "MinkowskiDropout", "MinkowskiLeakyReLU", "MinkowskiELU", "MinkowskiSigmoid",
+                 "MinkowskiBroadcastMultiplication", "MinkowskiGlobalSumPooling", "MinkowskiLinear"):
+        setattr(me, name, type(name, (_NoParams,), {}))
+    ops_mod = types.ModuleType("MinkowskiEngine.MinkowskiOps")
+    ops_mod.cat = lambda *a, **k: None
+    pool_mod = types.ModuleType("MinkowskiEngine.MinkowskiPooling")
+    pool_mod.MinkowskiAvgPooling = me.MinkowskiAvgPooling
+    me.MinkowskiOps, me.MinkowskiPooling = ops_mod, pool_mod
+    sys.modules["MinkowskiEngine"] = me
+    sys.modules["MinkowskiEngine.MinkowskiOps"] = ops_mod
+    sys.modules["MinkowskiEngine.MinkowskiPooling"] = pool_mod
+    stub("custom_cuda_utils", "detectron2", "detectron2.utils", "detectron2.utils.comm", "detectron2.projects",
+         "detectron2.projects.point_rend", "detectron2.projects.point_rend.point_features", "hydra", "torch_scatter",
+         "pointnet2", "pointnet2._ext", "torchvision", "third_party", "third_party.pointnet2",
+         "third_party.pointnet2.pointnet2_utils")
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    res16unet = importlib.import_module("models.res16unet")
+    mask3d = importlib.import_module("models.mask3d")
+    out = {}
+    # conf/model/mask3d.yaml: config.backbone = Res16UNet34C(in_channels = data.in_channels (3), out_channels = data.num_labels,
+    # config = {dialations, conv1_kernel_size 3, bn_momentum 0.02}, out_fpn = true)
+    cfg = SimpleNamespace(dialations=[1, 1, 1, 1], dilations=[1, 1, 1, 1], conv1_kernel_size=3, bn_momentum=0.02)
+    for name in ("Res16UNet34C", "Res16UNet14"):
+        bb = getattr(res16unet, name)(in_channels=3, out_channels=20, config=cfg, out_fpn=True)
+        out[name] = sorted([k, list(v.shape)] for k, v in bb.state_dict().items())
+    bb = res16unet.Res16UNet34C(in_channels=3, out_channels=20, config=cfg, out_fpn=True)
+    m = mask3d.Mask3D(config=SimpleNamespace(backbone=bb), hidden_dim=128, num_queries=100, num_heads=8, dim_feedforward=1024,
+                      sample_sizes=[200, 800, 3200, 12800, 51200], shared_decoder=True, num_classes=3, num_decoders=3,
+                      dropout=0.0, pre_norm=False, positional_encoding_type="fourier", non_parametric_queries=True,
+                      train_on_segments=True, normalize_pos_enc=True, use_level_embed=False, scatter_type="mean",
+                      hlevels=[0, 1, 2, 3], use_np_features=False, voxel_size=0.02, max_sample_size=False,
+                      random_queries=False, gauss_scale=1.0, random_query_both=False, random_normal=False)
+    out["Mask3D"] = sorted([k, list(v.shape)] for k, v in m.state_dict().items())
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(out, f, indent=0, separators=(",", ":"))
+    for k, v in out.items():
+        print(k, len(v), "entries", sum(int(np.prod(sh)) for _, sh in v), "elements")
+
+
 if __name__ == "__main__":
     cwd = os.getcwd()
-    if len(sys.argv) > 1 and sys.argv[1] == "ncut":
+    if len(sys.argv) > 1 and sys.argv[1] == "state_dict":
+        make_state_dict()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ncut":
         make_ncut(import_reference_ncut())
     elif len(sys.argv) > 1 and sys.argv[1] == "ncut_b":
         make_ncut_b(import_reference_ncut())

@@ -66,7 +66,7 @@ def test_two_rank_runs_are_bit_reproducible_across_processes():
     for k in range(3):
         for overlap in ("1", "0"):
             out = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--voxels",
-                             "40000", "--dist-backend", _backend(), "--no-cpu-baseline"], _free_port(),
+                             "40000", "--dist-backend", _backend(), "--no-cpu-baseline", "--rotate", "0"], _free_port(),
                             {"USC3D_OVERLAP_ALLREDUCE": overlap})
             rec = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
             losses.add(rec["config"]["loss"])

@@ -98,6 +98,9 @@ def test_150k_voxel_scene_indices_rulebooks_and_conv(device, bench_scene):
     assert abs(N - 150_000) <= 3000
     assert np.array_equal(umap.cpu().numpy(), eu) and np.array_equal(inv.cpu().numpy(), einv)
     assert np.array_equal(c3.cpu().numpy(), ec[eu])
+    # the HIP-free host entry (forked DataLoader workers, datasets/utils.py:403-414) gives the device path's indices
+    hc, hu, hinv = ME.utils.sparse_quantize(xyz, quantization_size=0.02, return_index=True, return_inverse=True, device="cpu")
+    assert torch.equal(hu, umap.cpu()) and torch.equal(hinv, inv.cpu()) and torch.equal(hc, c3.cpu())
     coords4, _ = R.sparse_collate([ec[eu]], [sc["colors"][eu]])
     x = ME.SparseTensor(features=_dev(sc["colors"][eu], device), coordinates=_dev(coords4, device), device=device)
     cm = x.coordinate_manager

@@ -15,7 +15,7 @@ def test_training_steps_free_their_batch_without_the_cycle_collector(device, mon
     # the next batch issued by the main thread: with the worker thread the two measurement points may or may not
     # include the batch being prefetched (one 20 k-voxel batch is ~20 MB: the test would be flaky, not the step)
     monkeypatch.setenv("USC3D_PREFETCH_THREAD", "0")
-    args = bench.parse(["--no-cpu-baseline", "--voxels", "20000"])
+    args = bench.parse(["--no-cpu-baseline", "--voxels", "20000", "--rotate", "0"])
     step = bench.make_mask3d_step(args, device, 0, 1)
     try:
         for _ in range(3):

@@ -26,7 +26,7 @@ def _run(overlap, port):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", USC3D_OVERLAP_ALLREDUCE=overlap)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline"]
+           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline", "--rotate", "0"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -52,7 +52,7 @@ def test_bench_two_ranks():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline"]
+           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline", "--rotate", "0"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -78,7 +78,7 @@ def test_uneven_ranks_neither_hang_nor_diverge(overlap):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "2", "--voxels-by-rank", "150000,20000", "--eager-ranks", "1", "--dist-backend", _backend(),
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--rotate", "0"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -93,7 +93,7 @@ def test_bench_gpus_2_without_a_launcher_spawns_two_ranks():
     and the line reports n_gpus == 2 (gloo here because the test box has one device; the default backend is RCCL)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline"]
+           "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline", "--rotate", "0"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -107,7 +107,7 @@ def test_bench_refuses_rccl_ranks_without_devices():
     import torch
     n = torch.cuda.device_count() + 1
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--rotate", "0"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode != 0
@@ -116,7 +116,7 @@ def test_bench_refuses_rccl_ranks_without_devices():
 
 def _run_single(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--voxels", "40000",
-           "--no-cpu-baseline"] + extra
+           "--no-cpu-baseline", "--rotate", "0"] + extra
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])

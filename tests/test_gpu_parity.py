@@ -461,7 +461,7 @@ def test_fourier_posenc(device):
     assert float((got.cpu() - exp).abs().max()) < 2e-5
 
 
-def _backbone_case(device, cls_name, layers, seed, n_points, grad):
+def _backbone_case(device, cls_name, layers, seed, n_points, grad, input_points=None):
     """config 1 / config 2 at oracle-friendly size: voxelise a synthetic scene, run the device
     backbone and the CPU restatement from the SAME state_dict."""
     from types import SimpleNamespace
@@ -473,6 +473,9 @@ def _backbone_case(device, cls_name, layers, seed, n_points, grad):
 
     sc = make_scene(seed, target_voxels=n_points, tol=0.05)
     xyz, colors = sc["xyz"], sc["colors"]
+    if input_points is not None:        # exactly that many INPUT points (the scene's points are in random order)
+        assert xyz.shape[0] >= input_points, xyz.shape
+        xyz, colors = xyz[:input_points], colors[:input_points]
     # device voxelisation (V1) vs oracle
     coords_dev = ME.utils.sparse_quantize(xyz, quantization_size=0.02, return_index=True, return_inverse=True,
                                           device=str(device))
@@ -535,6 +538,13 @@ def _backbone_case(device, cls_name, layers, seed, n_points, grad):
 
 def test_config1_res16unet14_forward(device):
     _backbone_case(device, "Res16UNet14", (1,) * 8, seed=1000, n_points=8000, grad=False)
+
+
+def test_config1_literal_20000_input_points(device):
+    """BASELINE.json configs[0] as written: ONE synthetic scene of exactly 20 000 input points, 2 cm voxelisation,
+    Res16UNet14 forward — unique / inverse maps, per-level coordinates and rulebooks bit-exact, features < 1e-3 against
+    the f64 oracle (reference call sites datasets/utils.py:403-414, models/res16unet.py:224-302)."""
+    _backbone_case(device, "Res16UNet14", (1,) * 8, seed=1000, n_points=11000, grad=False, input_points=20000)
 
 
 def test_config2_res16unet34c_forward_backward_small(device):

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 
-args = bench.parse(["--no-cpu-baseline"])
+args = bench.parse(["--no-cpu-baseline", "--rotate", "0"])
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 step = bench.make_mask3d_step(args, dev, 0, 1)

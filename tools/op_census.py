@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--voxels", type=int, default=150_000)
     ap.add_argument("--top", type=int, default=120)
     a = ap.parse_args()
-    args = bench.parse(["--voxels", str(a.voxels), "--no-graphs", "--no-prefetch"])
+    args = bench.parse(["--voxels", str(a.voxels), "--no-graphs", "--no-prefetch", "--rotate", "0"])
     dev = torch.device("cuda:0")
     step = bench.make_mask3d_step(args, dev, 0, 1)
     for _ in range(3):

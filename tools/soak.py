@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--rotate", type=int, default=8)
     a = ap.parse_args()
-    args = bench.parse(["--no-cpu-baseline", "--rotate", str(a.rotate)])
+    args = bench.parse(["--no-cpu-baseline", "--rotate", str(a.rotate), "--rotate-spread", "0.2"])
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     step = bench.make_mask3d_step(args, dev, 0, 1)

@@ -44,7 +44,7 @@ def ncut_soak(dev, K=16, rounds=6):
 
 def eval_soak(dev, steps=12):
     import bench
-    args = bench.parse(["--no-cpu-baseline", "--voxels", "60000"])
+    args = bench.parse(["--no-cpu-baseline", "--voxels", "60000", "--rotate", "0"])
     step = bench.make_mask3d_step(args, dev, 0, 1)
     module = step.module
     from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset

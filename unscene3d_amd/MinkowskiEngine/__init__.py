@@ -269,7 +269,12 @@ class SparseTensor:
 
     @property
     def decomposed_features(self):
-        return [self._F[s] for s in self.coordinate_manager.batch_slices(self._ts())]
+        F, n = self._F, self._F.shape[0]
+        # a slice that covers every row (one scene per batch) is the tensor itself as a view: `F[0:n]` would be a
+        # SliceBackward node whose backward zero-fills an [n, C] tensor and copies the gradient into it (41 us at
+        # 148 k voxels x 128 channels, once per training step)
+        return [F.view(F.shape) if (isinstance(s, slice) and s.start in (0, None) and s.stop == n and s.step in (1, None))
+                else F[s] for s in self.coordinate_manager.batch_slices(self._ts())]
 
     @property
     def decomposed_coordinates(self):

@@ -25,6 +25,9 @@ def sparse_quantize(coordinates, features=None, labels=None, ignore_label=-100, 
     `coordinates` [N,D] already floored (np.floor(x / voxel), reference datasets/utils.py:403)
     unless `quantization_size` is given.  Runs on the HIP device."""
     dev = torch.device(device)
+    if dev.type == "cpu":
+        return _sparse_quantize_host(coordinates, features, labels, return_index, return_inverse, return_maps_only,
+                                     quantization_size)
     c = coordinates
     if quantization_size is not None:
         cf = _to_dev(c, torch.float64, dev)
@@ -46,6 +49,45 @@ def sparse_quantize(coordinates, features=None, labels=None, ignore_label=-100, 
     if labels is not None:
         l = labels if isinstance(labels, torch.Tensor) else torch.from_numpy(np.asarray(labels))
         outs.append(l.to(dev)[unique_idx])
+    if return_index:
+        outs.append(unique_idx)
+    if return_inverse:
+        outs.append(inverse)
+    return outs[0] if len(outs) == 1 else tuple(outs)
+
+
+def _sparse_quantize_host(coordinates, features, labels, return_index, return_inverse, return_maps_only,
+                          quantization_size):
+    """device="cpu": the HIP-FREE path (usc_voxel_floor_f64_host / usc_unique_coords_host) — what a forked DataLoader
+    worker of the reference's collate (datasets/utils.py:403-414, conf/data/indoor.yaml:24) can call; it touches no
+    device and returns CPU tensors, bit-equal to the device path's indices."""
+    from .._lib import check, lib
+    c = coordinates.detach().cpu().numpy() if isinstance(coordinates, torch.Tensor) else np.asarray(coordinates)
+    n, d = c.shape
+    if quantization_size is not None or not np.issubdtype(c.dtype, np.integer):
+        cf = np.ascontiguousarray(c, dtype=np.float64)
+        ci = np.empty((n, d), dtype=np.int32)
+        if d != 3:
+            raise RuntimeError("sparse_quantize(device='cpu'): floating-point coordinates must be [N, 3]")
+        check(lib.usc_voxel_floor_f64_host(cf.ctypes.data, n, float(quantization_size or 1.0), ci.ctypes.data),
+              "usc_voxel_floor_f64_host")
+    else:
+        ci = np.ascontiguousarray(c, dtype=np.int32)
+    uniq = np.empty(n, dtype=np.int64)
+    inv = np.empty(n, dtype=np.int64)
+    import ctypes
+    n_out = ctypes.c_int64(0)
+    check(lib.usc_unique_coords_host(ci.ctypes.data, n, d, uniq.ctypes.data, inv.ctypes.data, ctypes.byref(n_out)),
+          "usc_unique_coords_host")
+    unique_idx = torch.from_numpy(uniq[:n_out.value].copy())
+    inverse = torch.from_numpy(inv)
+    if return_maps_only:
+        return (unique_idx, inverse) if return_inverse else unique_idx
+    outs = [torch.from_numpy(ci)[unique_idx]]
+    for extra in (features, labels):
+        if extra is not None:
+            t = extra if isinstance(extra, torch.Tensor) else torch.from_numpy(np.asarray(extra))
+            outs.append(t.cpu()[unique_idx])
     if return_index:
         outs.append(unique_idx)
     if return_inverse:

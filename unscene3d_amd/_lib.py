@@ -61,6 +61,8 @@ SIGNATURES = {
     "usc_abi_version": (C.c_int, []),
     "usc_device_count": (C.c_int, []),
     "usc_voxel_floor_f64": (C.c_int, [_p, _i64, _f64, _p, _p]),
+    "usc_voxel_floor_f64_host": (C.c_int, [_p, _i64, C.c_double, _p]),
+    "usc_unique_coords_host": (C.c_int, [_p, _i64, _i32, _p, _p, _p]),
     "usc_coordmap_capacity": (_i64, [_i64]),
     "usc_coordmap_ws_bytes": (_i64, [_i64]),
     "usc_coordmap_build": (C.c_int, [_p, _i64, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p]),

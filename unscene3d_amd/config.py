@@ -25,7 +25,8 @@ def default_config():
                     "filter_out_instances": False, "scores_threshold": 0.1, "iou_threshold": 0.66,
                     "topk_per_image": 100, "save_for_freemask": False, "save_dir": "saved"},
         "data": {"voxel_size": 0.02, "in_channels": 3, "num_labels": 20, "add_raw_coordinates": True,
-                 "add_colors": True, "add_normals": False, "ignore_label": 255, "batch_size": 8},
+                 "add_colors": True, "add_normals": False, "ignore_label": 255, "batch_size": 8,
+                 "test_mode": "validation"},          # conf/data/indoor.yaml:9 ("test": eval_step skips the criterion)
         "model": {"hidden_dim": 128, "dim_feedforward": 1024, "num_queries": 100, "num_heads": 8, "num_decoders": 3,
                   "dropout": 0.0, "pre_norm": False, "use_level_embed": False, "normalize_pos_enc": True,
                   "positional_encoding_type": "fourier", "gauss_scale": 1.0, "hlevels": [0, 1, 2, 3],

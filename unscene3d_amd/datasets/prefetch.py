@@ -62,6 +62,11 @@ class ScenePrefetcher:
         """precompute: optional `Mask3D.precompute_geometry` (bound method): the parameter-free, geometry-only part
         of the model's forward pass is then issued here as well.
         threaded: issue the batch from a worker thread (the reference's DataLoader workers, conf/data/indoor.yaml:24).
+        Random draws made while issuing (the decoder's key samples, `Mask3D._draw_key_samples` -> torch.randperm on the
+        default generator) then happen on the worker: they stay in batch order — one batch is issued at a time — but a
+        main thread that ALSO draws from the default HIP generator during the step (dropout > 0, random query
+        initialisation) interleaves with them nondeterministically: seeded runs that need the reference's draw order
+        use threaded=False (or hand the model its own `randperm` source).
         The ~6 ms of host time a 150 k-voxel batch takes to issue — about a third of it blocked in the count read-backs
         of the voxel unique / coordinate maps, which release the interpreter lock — then overlap with the main thread
         issuing the step instead of extending it; submit() returns at once, take() joins."""
@@ -100,6 +105,12 @@ class ScenePrefetcher:
         if worker is not None:
             self._jobs.put(None)
             worker.join(timeout=30)
+            if worker.is_alive():
+                # still inside a native call (a count read-back behind a hung stream): say so instead of pretending the
+                # prefetcher is closed — the daemon thread dies with the process
+                import warnings
+                warnings.warn("ScenePrefetcher.close(): the worker thread did not finish within 30 s and is left "
+                              "running (daemon); a batch may still be in flight on the side stream")
 
     def submit(self, samples):
         if self._worker is not None:

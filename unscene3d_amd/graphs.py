@@ -33,6 +33,13 @@ class _Runner:
         self.static_grad_in = None
         self.grad_ptrs = None
         self.data_ptrs = None
+        # chained input (capture_passes(chain_input=...)): position, the runner whose output buffer it aliases, and
+        # whether THIS runner's output of the current step may still be read by autograd consumers (replayed with
+        # gradients on, backward not yet run)
+        self.chain_pos = None
+        self.chain_prev = None
+        self.live = False
+        self.shared_pos = ()
 
     def check_param_data(self):
         """The captured kernels hold each parameter's device address: a parameter whose storage moved after capture
@@ -54,13 +61,41 @@ class _Runner:
                     "buffers alive (optimizer.zero_grad(set_to_none=False) or ddp.flatten_grads) or disable the graphs")
 
 
+# data pointer of a captured pass's OUTPUT buffer -> the static buffer its backward graph reads the output gradient from.
+# The operator that produces that gradient (the decoder's LayerNorm over the pass output, ops._LayerNorm.backward) asks
+# here and writes straight into the buffer: no copy in front of the backward replay (12 per training step).
+_GRAD_OUT_BUFFERS = {}
+
+
+def grad_buffer_for(t):
+    """-> the static output-gradient buffer of the captured pass whose output buffer `t` is, or None."""
+    hit = _GRAD_OUT_BUFFERS.get((t.device.index, t.data_ptr()))
+    if hit is None or hit.shape != t.shape or hit.dtype != t.dtype or not hit.is_contiguous():
+        return None
+    return hit
+
+
+def forget_grad_buffers():
+    _GRAD_OUT_BUFFERS.clear()
+
+
 class _GraphedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, runner, *inputs):
         runner.check_param_data()
-        for s, a in zip(runner.static_in, inputs):
+        if runner.chain_prev is None:          # the first pass of a step: nothing of the previous step is in flight any more
+            for r in getattr(runner, "group", ()):
+                r.live = False
+        for j, (s, a) in enumerate(zip(runner.static_in, inputs)):
             if s.data_ptr() == a.data_ptr():
                 continue                       # the producer wrote straight into the buffer (or it is the previous pass's output)
+            if j == runner.chain_pos and runner.chain_prev is not None and runner.chain_prev.live:
+                # this input ALIASES the previous pass's output buffer, and that output was produced with gradients on
+                # in this step: its autograd consumers (the decoder's LayerNorm saves it) still read the buffer in
+                # backward — copying another tensor over it would silently corrupt their gradients
+                raise RuntimeError("graphed decoder pass: the chained input is not the previous pass's output, whose "
+                                   "buffer is still needed by this step's backward; run this pass eagerly "
+                                   "(Mask3D._eager_pass) or capture the passes without chain_input")
             hold = getattr(s, "_usc_holds", None)
             if hold is not None and hold[0] is a and hold[1] == a._version:
                 continue                       # a buffer SHARED by several passes already holds this very tensor
@@ -69,6 +104,7 @@ class _GraphedFn(torch.autograd.Function):
                 s._usc_holds = (a, a._version)  # (keeps `a` alive: its storage cannot be handed to another tensor)
         runner.fwd_graph.replay()
         ctx.runner = runner
+        runner.live = torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in inputs)
         return runner.static_out.detach()
 
     @staticmethod
@@ -78,6 +114,11 @@ class _GraphedFn(torch.autograd.Function):
         if r.static_grad_out.data_ptr() != g.data_ptr():
             r.static_grad_out.copy_(g)
         r.bwd_graph.replay()
+        r.live = False
+        if r.chain_prev is None:               # the step's last backward replay: let go of the tensors the shared buffers held
+            for j in r.shared_pos:
+                if getattr(r.static_in[j], "_usc_holds", None) is not None:
+                    r.static_in[j]._usc_holds = (None, -1)
         # the replayed graph added into every parameter's .grad: report it like the eager kernels do, so that a
         # gradient reducer never starts a bucket while replays that write into it are still to come (and so that
         # ranks running the same pass eagerly / graphed count the same number of writes)
@@ -147,6 +188,7 @@ def capture_passes(modules, sample_inputs, warmup_iters: int = 3, shared_inputs=
             # a fresh leaf over the previous pass's output storage (same strides): replaying pass k then pass k+1 hands
             # the queries over without a copy; any other tensor given at replay is copied into it as before
             r.static_in[chain_input] = prev.static_out.detach().requires_grad_(r.static_in[chain_input].requires_grad)
+            r.chain_pos, r.chain_prev = chain_input, prev
         with torch.cuda.graph(r.fwd_graph, pool=pool, capture_error_mode=_CAPTURE_MODE):
             r.static_out = r.module(*r.static_in)
         prev = r
@@ -161,7 +203,11 @@ def capture_passes(modules, sample_inputs, warmup_iters: int = 3, shared_inputs=
             if dst:
                 torch._foreach_add_(dst, src)
         r.static_grad_in = list(grads[:n_in])
+        _GRAD_OUT_BUFFERS[(r.static_out.device.index, r.static_out.data_ptr())] = r.static_grad_out
         r.grad_ptrs = [p.grad.data_ptr() for p in r.params]
         r.data_ptrs = [p.data_ptr() for p in r.params]
+    for r in runners:
+        r.group = runners
+        r.shared_pos = tuple(shared_inputs)
     torch.cuda.synchronize()
     return [GraphedPass(r) for r in runners]

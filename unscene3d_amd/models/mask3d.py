@@ -150,6 +150,8 @@ class Mask3D(nn.Module):
 
     def disable_decoder_graphs(self):
         object.__setattr__(self, "_graphed_passes", None)
+        from ..graphs import forget_grad_buffers
+        forget_grad_buffers()
 
     def get_pos_encs(self, coords):
         """Per level, per scene Fourier encodings [N_l, d] of the pooled raw coordinates
@@ -479,7 +481,11 @@ class Mask3D(nn.Module):
             # one applies sigmoid < 0.5 (reference :418-436).  Several scenes: the segment tables are stacked and the
             # row index carries each scene's segment offset (the voxel rows of a batch are one table already).
             for i, seg_feat in enumerate(mask_segments):
-                output_segments.append(_mask_logits(seg_feat, mask_embed[i]))
+                if _CHAIN_SEGMENT_GRADS:
+                    logits, mask_segments[i] = _mask_logits(seg_feat, mask_embed[i], chain=True)   # (the caller's list)
+                else:
+                    logits = _mask_logits(seg_feat, mask_embed[i])
+                output_segments.append(logits)
             cm, ts = mask_features.coordinate_manager, mask_features._ts()
             if len(output_segments) == 1:
                 pooled = output_segments[0].detach()
@@ -602,27 +608,36 @@ class _PaddedRows:
         return (t[i], self.q)
 
 
-def _mask_logits(feats, mask_embed):
+def _mask_logits(feats, mask_embed, chain=False):
     """feats [S, d] @ mask_embed[Q, d]^T -> [S, Q] (reference mask3d.py:425,430).  On the device the Q query
     embeddings are padded to a multiple of 32 so that the product runs on this library's row GEMM kernels (forward,
-    d feats, d mask_embed); the padded columns are cut off again as a view."""
+    d feats, d mask_embed); the padded columns are cut off again as a view.
+    chain: -> (logits, feats'), feats' = `feats` as a second output of the product's autograd node: the NEXT consumer
+    of the segment features takes feats', and its gradient is then summed inside this product's input-gradient launch
+    (the segment table has 13 consumers per step: 12 autograd adds of [S, d] otherwise)."""
     if isinstance(mask_embed, tuple):          # already zero-extended by the producing launch (_PaddedRows)
         W, Q = mask_embed
         pad = W.shape[0] - Q
         if not (feats.is_cuda and feats.dtype == torch.float32 and feats.shape[1] % 32 == 0):
-            return feats @ W[:Q].T
+            out = feats @ W[:Q].T
+            return (out, feats) if chain else out
     else:
         Q = mask_embed.shape[0]
         if not (feats.is_cuda and feats.dtype == torch.float32 and feats.shape[1] % 32 == 0):
-            return feats @ mask_embed.T
+            out = feats @ mask_embed.T
+            return (out, feats) if chain else out
         pad = (-Q) % 32
         W = F.pad(mask_embed, (0, 0, 0, pad)) if pad else mask_embed
-    out = ops.linear(feats, W.contiguous())
-    if not pad:
-        return out
-    view = out[:, :Q]
-    view._usc_padded = out        # the device criterion reads (and differentiates) the padded table directly
-    return view
+    nxt = feats
+    if chain and feats.requires_grad and torch.is_grad_enabled():
+        out, nxt = ops.linear(feats, W.contiguous(), passthrough=True)
+    else:
+        out = ops.linear(feats, W.contiguous())
+    if pad:
+        view = out[:, :Q]
+        view._usc_padded = out        # the device criterion reads (and differentiates) the padded table directly
+        out = view
+    return (out, nxt) if chain else out
 
 
 def multihead_attention(mha: nn.MultiheadAttention, query, key, value, attn_mask=None, mask_bsl=None, pos_q=None,
@@ -706,6 +721,7 @@ class _DecoderPass(nn.Module):
 
 
 _FUSED_ATTN_MASK = os.environ.get("USC3D_FUSED_ATTN_MASK", "1") != "0"
+_CHAIN_SEGMENT_GRADS = os.environ.get("USC3D_CHAIN_SEGMENT_GRADS", "1") != "0"
 
 
 _PAD_CACHE = {}

@@ -933,6 +933,7 @@ class _LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x2, weight, mean, rstd)
         ctx.shape = x.shape
         ctx.w_param, ctx.b_param = weight, bias
+        ctx.passthrough = bool(passthrough)
         # passthrough: x comes back as a second output; the gradient that arrives there (x's other consumer) is summed
         # inside the backward launch (usc_layernorm_bwd_ex: dx_add) instead of by a separate autograd add
         return (y.view(x.shape), x) if passthrough else y.view(x.shape)
@@ -945,7 +946,11 @@ class _LayerNorm(torch.autograd.Function):
             return (None if dpass is None else dpass), None, None, None, None
         dy2 = dy.contiguous().view(rows, d)
         dadd = None if dpass is None else dpass.contiguous().view(rows, d)
-        dx = torch.empty_like(x2)
+        # x is the output buffer of a captured decoder pass: its gradient goes straight into the buffer the pass's
+        # backward graph reads (graphs.grad_buffer_for), which saves the copy in front of the replay
+        from .graphs import grad_buffer_for
+        buf = grad_buffer_for(x2) if getattr(ctx, "passthrough", False) else None
+        dx = buf.view(rows, d) if buf is not None and buf.numel() == x2.numel() else torch.empty_like(x2)
         tg, tb = _grad_target(ctx.w_param), _grad_target(ctx.b_param)
         in_place = tg is not None and tb is not None
         dgamma = tg if in_place else torch.empty_like(weight)

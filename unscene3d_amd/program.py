@@ -142,10 +142,17 @@ def _plan(model):
     return pl
 
 
+def _module_key(model):
+    """Identity of every module the plan references: a conversion that swaps modules after the first forward pass (a
+    batch-norm conversion, a re-built block) must not be served the old plan, which holds the old modules' parameters."""
+    return tuple(id(m) for m in model.modules())
+
+
 def plan_of(model):
     cached = model.__dict__.get("_usc_program_plan")
-    if cached is None:
-        cached = model.__dict__["_usc_program_plan"] = (_plan(model) or False,)
+    key = _module_key(model)
+    if cached is None or cached[1] != key:
+        cached = model.__dict__["_usc_program_plan"] = (_plan(model) or False, key)
     return cached[0] or None
 
 
@@ -206,9 +213,16 @@ def usable(model, x):
     if pl is None:
         return None
     if torch.is_grad_enabled():
-        for p in pl.params:
-            if p.requires_grad and ops._grad_target(p) is None:
-                return None                      # gradients go through autograd: the per-block path returns them
+        need = [p.requires_grad for p in pl.params]
+        if any(need):
+            # the backward walk writes EVERY unit's parameter gradients in place and returns no input gradient: a
+            # partly frozen trunk, a parameter without a gradient buffer or an input that wants its own gradient go
+            # through the per-block path, which hands gradients back through autograd
+            if not all(need) or x.F.requires_grad:
+                return None
+            for p in pl.params:
+                if ops._grad_target(p) is None:
+                    return None
     return pl
 
 

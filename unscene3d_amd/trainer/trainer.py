@@ -100,8 +100,14 @@ class InstanceSegmentation(nn.Module):
         -> None (skipped scene), or {"losses": {val_<k>: float}, "instances": [per scene dict]}."""
         from .postprocess import export_instances, save_for_freemask
         data, target, file_names = batch
-        if len(target) == 0 or data.features.shape[0] == 0:
+        # (the reference returns 0. for an empty batch, :373-381; its "no targets" early exit is commented out, :369-371 —
+        # an unlabeled export run has targets that only carry point2segment)
+        if data.features.shape[0] == 0 or len(target) == 0:
             return None
+        # a deferred assignment-status word of an earlier TRAINING step must not surface as this scene's error
+        chk = getattr(self.criterion, "check_lsap_status", None)
+        if chk is not None:
+            chk(wait=True)
         feats, raw_coordinates = data.features, None
         if self.config.data.add_raw_coordinates:
             raw_coordinates = feats[:, -3:].contiguous()
@@ -117,11 +123,13 @@ class InstanceSegmentation(nn.Module):
             if err.args and err.args[0] == SINGLE_POINT_ERROR:
                 return None
             raise
-        losses = self.criterion(output, target, mask_type=self.mask_type, coords=x.C)
-        wd = self.criterion.weight_dict
-        keys = [k for k in losses if k in wd]
-        host = torch.stack([losses[k].detach() for k in keys]).cpu().tolist()           # one read-back, not 52
-        val = {f"val_{k}": v * wd[k] for k, v in zip(keys, host)}                       # :410-416, :441
+        val = {}
+        if getattr(self.config.data, "test_mode", "validation") != "test":     # :400: no criterion on the test split
+            losses = self.criterion(output, target, mask_type=self.mask_type, coords=x.C)
+            wd = self.criterion.weight_dict
+            keys = [k for k in losses if k in wd]
+            host = torch.stack([losses[k].detach() for k in keys]).cpu().tolist()       # one read-back, not 52
+            val = {f"val_{k}": v * wd[k] for k, v in zip(keys, host)}                   # :410-416, :441
         g = self.config.general
         instances = export_instances(output, target, data.target_full, data.inverse_maps, raw_coordinates, g,
                                      num_classes=self.model.num_classes, decoder_id=g.decoder_id,
