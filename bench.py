@@ -89,6 +89,11 @@ def parse(argv=None):
                          "device-bound; the collectives must line up all the same); default: --voxels on every rank")
     ap.add_argument("--eager-ranks", default="", metavar="R0,R1,...",
                     help="ranks that do NOT capture the decoder passes as HIP graphs (mixed eager / graphed ranks)")
+    ap.add_argument("--dry-collectives", action="store_true",
+                    help="N ranks: run ONLY the collectives of a training step — the criterion's 13 scalar `num_masks` "
+                         "all-reduces (models/criterion.py:258-260) and the gradient exchange in the reducer's bucket "
+                         "schedule, next to one flat all-reduce — timed per bucket, without building a scene: what the "
+                         "exchange costs when nothing hides it, to be read beside `ms_per_step` on an N-GPU node")
     ap.add_argument("--cpu-sample-voxels", type=int, default=10_000,
                     help="scene size of the cpu_baseline legs (3 warm-up + up to 10 timed passes of the CPU restatement each)")
     return ap.parse_args(argv)
@@ -590,6 +595,79 @@ def spawn_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def run_dry_collectives(args, dev, rank, world):
+    """The collectives of one step, alone: 13 x scalar all-reduce, then the flat gradient buffer of the
+    real model in the BucketedGradReducer's buckets (last bucket first: the order backward finishes them), then the
+    same bytes as ONE all-reduce.  Device time per collective from HIP events around blocking calls; median of `--steps`
+    repetitions after `--warmup`.  Prints one JSON line on rank 0."""
+    from unscene3d_amd.config import apply_overrides, default_config
+    from unscene3d_amd.ddp import BucketedGradReducer, flatten_grads
+    from unscene3d_amd.trainer.trainer import InstanceSegmentation
+
+    cfg = apply_overrides(default_config(), ["general.num_targets=3", f"data.batch_size={world}"])
+    torch.manual_seed(1234)
+    module = InstanceSegmentation(cfg).to(dev).train()
+    params = [p for n, p in module.named_parameters() if ".backbone.final." not in n]
+    flat = flatten_grads(params)
+    red = BucketedGradReducer(params, flat, world)
+    bounds = red.bounds
+    nm = torch.ones(1, device=dev)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0)
+
+    def masks():
+        for _ in range(13):
+            dist.all_reduce(nm)
+
+    def one_flat():
+        dist.all_reduce(flat)
+
+    per_bucket = [[] for _ in bounds]
+    t_masks, t_flat, t_buckets_async = [], [], []
+    for it in range(args.warmup + args.steps):
+        keep = it >= args.warmup
+        a = timed(masks)
+        for b in reversed(range(len(bounds))):
+            s_, e_ = bounds[b]
+            t = timed(lambda: dist.all_reduce(flat[s_:e_]))
+            if keep:
+                per_bucket[b].append(t)
+
+        def all_async():
+            hs = [dist.all_reduce(flat[s_:e_], async_op=True) for s_, e_ in reversed(bounds)]
+            for h in hs:
+                h.wait()
+        c = timed(all_async)
+        d = timed(one_flat)
+        if keep:
+            t_masks.append(a); t_buckets_async.append(c); t_flat.append(d)
+        flat.zero_()
+    med = lambda v: float(np.median(v)) if v else None
+    ts = [med(t_masks), med(t_buckets_async), med(t_flat)] + [med(v) for v in per_bucket]
+    t = torch.tensor(ts, device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ts = t.tolist()
+    if rank == 0:
+        mb = [(e - s) * 4 / 1e6 for s, e in bounds]
+        print(json.dumps({
+            "mode": "dry-collectives", "n_gpus": world, "backend": args.dist_backend, "steps": args.steps,
+            "gradient_mb": flat.numel() * 4 / 1e6, "num_masks_13_allreduces_ms": ts[0],
+            "buckets_async_in_schedule_order_ms": ts[1], "one_flat_allreduce_ms": ts[2],
+            "buckets": [{"index": b, "mb": mb[b], "blocking_ms": ts[3 + b],
+                         "algbw_gbs": (mb[b] / 1e3) / (ts[3 + b] / 1e3) if ts[3 + b] else None} for b in range(len(bounds))],
+            "note": "max over ranks of per-rank medians; the bucketed exchange of a real step starts during backward "
+                    "(5 of 6 buckets at 150 k voxels) and can hide under the ~9 ms the backward pass still runs after "
+                    "the first bucket is complete; compare buckets_async_in_schedule_order_ms with ms_per_step"}))
+
+
 def main():
     args = parse()
     if args.mode == "ncut":
@@ -622,6 +700,12 @@ def main():
     from unscene3d_amd.ddp import flatten_grads
     from unscene3d_amd.synthetic import make_scene
 
+    if args.dry_collectives:
+        if world < 2:
+            raise SystemExit("bench.py --dry-collectives: needs --gpus N with N >= 2 (one rank has no collective)")
+        run_dry_collectives(args, dev, rank, world)
+        dist.destroy_process_group()
+        return
     if args.mode == "backbone":
         model = build_model(dev)
         params = [p for n, p in model.named_parameters() if not n.startswith("final.")]  # unused in forward

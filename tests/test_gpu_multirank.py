@@ -100,6 +100,29 @@ def test_bench_gpus_2_without_a_launcher_spawns_two_ranks():
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["config"]["parallelism"] == "dp2"
+    import torch
+    if torch.cuda.device_count() >= 2:
+        # a box with a device per rank: the collectives really spanned two RCCL ranks on two different devices
+        c = rec["config"]
+        assert c["dist_backend"] == "nccl" and c["rccl_ranks_seen"] == 2 and c["distinct_devices"] == 2, c
+        assert c["weights_equal_across_ranks"] is True
+
+
+def test_dry_collectives_mode_times_the_step_exchange_alone():
+    """`bench.py --gpus 2 --dry-collectives`: the 13 num_masks all-reduces (reference models/criterion.py:258-260) and
+    the bucket schedule of the gradient exchange without a training step around them — the figure to read beside
+    ms_per_step on an N-GPU node."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--dist-backend", _backend(), "--dry-collectives"]
+    env = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["mode"] == "dry-collectives" and rec["n_gpus"] == 2
+    assert 150 < rec["gradient_mb"] < 170 and len(rec["buckets"]) >= 4
+    assert abs(sum(b["mb"] for b in rec["buckets"]) - rec["gradient_mb"]) < 1e-3
+    assert all(b["blocking_ms"] > 0 for b in rec["buckets"]) and rec["one_flat_allreduce_ms"] > 0
 
 
 def test_bench_refuses_rccl_ranks_without_devices():

@@ -37,7 +37,9 @@ def test_wgrad_plan_matches_design():
     assert p["full"] == 1 and p["NB"] == 3 and p["hi"] == 3            # 3 x 3 accumulator tiles per wave
     p = _plan(2, 253854, 128, 128, 27)
     assert p["full"] == 1 and p["NB"] == 4 and p["hi"] == 2
-    assert _plan(2, 4011228, 128, 96, 27)["full"] == 0                  # kept on the per-input-tile kernel
+    p = _plan(2, 4011228, 128, 96, 27)                                  # round 5: 4 x 3 tiles, accumulators in the AGPR half
+    assert p["full"] == 1 and p["NB"] == 3 and p["hi"] == 4
+    assert _plan(2, 148564, 96, 128, 1)["hi"] == 1                      # (the mirror form <3,4> measured slower: not used)
     assert _plan(2, 4011228, 3, 32, 27)["full"] == 0 and _plan(2, 4011228, 3, 32, 27)["aligned"] == 0
 
 

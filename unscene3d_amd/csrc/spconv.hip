@@ -1279,7 +1279,7 @@ int usc_spconv_plan(int32_t kind, int64_t n, int32_t cin, int32_t cout, int32_t 
     const int ctiles = cin / 32, cb = cout / 32;
     const int NBf = (cb % 3 == 0) ? 3 : (cb % 4 == 0 ? 4 : (cb % 2 == 0 ? 2 : 1));
     if (cin % 32 == 0 && cout % 32 == 0 && (!(NBf == 3 && ctiles % 3 != 0) || (wgrad_big_tiles() && ctiles % 4 == 0))) {
-      const int CT = (ctiles % 3 == 0 && NBf * 3 <= 9) ? 3 : ((ctiles % 4 == 0 && NBf * 4 <= 9) ? 4 : ((ctiles % 2 == 0 && NBf * 2 <= 9) ? 2 : 1));
+      const int CT = wgrad_full_ct(ctiles, NBf);
       return NBf | (1 << 8) | (1 << 13) | (CT << 16);
     }
     const int NB = pick_nb(cout);
