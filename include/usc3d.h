@@ -486,7 +486,9 @@ int usc_bn_backward_dx(const float* x, const float* dy, const float* y_out,
  *             dbn_accumulate), and dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)) (training == 0: the two
  *             means are 0).  g is written to dres when given (the residual branch's gradient), else in place into dout
  *             when it was formed from slices; a finished dout without dres is not written.
- * ws: usc_bn_tile_ws_bytes(c) bytes.  usc_bn_tile_ok(n, c): does the form cover this map (c a multiple of 32)? */
+ * ws: usc_bn_tile_ws_bytes(c) bytes.  usc_bn_tile_ok(n, c): do the kernels cover this map (c a multiple of 32, <= 1024)?
+ * usc_bn_tile_max_rows(): the map size up to which usc_conv_bn_act_forward / _backward and usc_program_run TAKE this form
+ * (default 4 096 rows; USC3D_BN_TILE_ROWS, 0 = never). */
 int64_t usc_bn_tile_max_rows(void);
 int usc_bn_tile_ok(int64_t n, int32_t c);
 int64_t usc_bn_tile_ws_bytes(int32_t c);

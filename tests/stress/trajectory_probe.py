@@ -43,7 +43,8 @@ def main():
             kids.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "stress", "step_probe.py"), "--child", "--graphs",
                                           "--prefetch", "--iters", "1000000", "--seconds", "100000", "--voxels", "40000"],
                                          env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
-    args = bench.parse(["--gpus", str(world), "--voxels", str(a.voxels), "--no-cpu-baseline", "--dist-backend", backend]
+    args = bench.parse(["--gpus", str(world), "--voxels", str(a.voxels), "--no-cpu-baseline", "--dist-backend", backend,
+                        "--rotate", "0"]           # ONE scene replayed: every trial must see the same four batches
                        + (["--no-graphs"] if a.no_graphs else []) + (["--no-prefetch"] if a.no_prefetch else []))
     step = bench.make_mask3d_step(args, dev, rank, world)
     opt, module = step.opt, step.module

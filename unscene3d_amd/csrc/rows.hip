@@ -1241,7 +1241,9 @@ int64_t usc_bn_tile_max_rows(void) {
   return knob;
 }
 
-int usc_bn_tile_ok(int64_t n, int32_t c) { return n >= 1 && n <= usc_bn_tile_max_rows() && c >= 32 && c % 32 == 0 && c <= 1024; }
+// what the kernels cover (any number of rows: <= 64 row tiles of whatever height); usc_bn_tile_max_rows() is the POLICY
+// the unit calls apply on top (units.hip)
+int usc_bn_tile_ok(int64_t n, int32_t c) { return n >= 1 && c >= 32 && c % 32 == 0 && c <= 1024; }
 
 int64_t usc_bn_tile_ws_bytes(int32_t c) { return (int64_t)kBnTileMaxTiles * 2 * c * 8; }
 

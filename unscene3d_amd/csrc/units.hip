@@ -334,6 +334,8 @@ static bool tile_form_on() {
   static const bool on = usc_bn_tile_max_rows() > 0;
   return on;
 }
+// the unit calls take the tile form on maps of up to usc_bn_tile_max_rows() rows (the kernels themselves cover any size)
+static bool tile_rows_ok(int64_t n, int c) { return tile_form_on() && n <= usc_bn_tile_max_rows() && usc_bn_tile_ok(n, c); }
 
 static int conv_backward_impl(const usc_kmap* m, int32_t kind, const float* x, int32_t cin, const float* W, int32_t cout,
                               const float* dy, float* dx, int32_t dx_accumulate, float* dW, int32_t dW_accumulate, void* ws,
@@ -385,7 +387,7 @@ static int conv_backward_impl(const usc_kmap* m, int32_t kind, const float* x, i
   // slices may stay behind only when the consumer can take them (tile-form batch norm on the input map) and nothing in
   // this call overwrites them: the weight gradient then takes its scratch behind the input gradient's region
   Slices left;
-  const bool may_defer = out && dx && !side && tile_form_on() && usc_bn_tile_ok(sh.n_in, cin);
+  const bool may_defer = out && dx && !side && tile_rows_ok(sh.n_in, cin);
   if (may_defer) {
     int64_t f_, w_;
     conv_ws_parts(m, kind, cin, cout, &f_, &dgrad_bytes, &w_);
@@ -472,7 +474,7 @@ int usc_conv_bn_act_forward(const usc_kmap* m, int32_t kind, const float* x, int
   void* sws = cur.take(sb);                       // BN partials first: the conv's scratch takes the rest
   USC_REQUIRE(sws, "usc_conv_bn_act_forward: workspace too small");
   // tile form (coarse levels): the convolution leaves its split-K slices behind, two launches do the rest
-  const bool tile = bn->training && tile_form_on() && usc_bn_tile_ok(sh.n_out, cout) && sb >= usc_bn_tile_ws_bytes(cout);
+  const bool tile = bn->training && tile_rows_ok(sh.n_out, cout) && sb >= usc_bn_tile_ws_bytes(cout);
   Slices left;
   int rc = conv_forward_impl(m, kind, x, cin, W, cout, nullptr, y, cur.rest(), cur.left(), s, tile ? &left : nullptr);
   if (rc) return rc;
@@ -530,7 +532,7 @@ static int unit_backward_impl(const usc_kmap* m, int32_t kind, const float* x, i
   int rc;
   const bool has_in = in && in->G > 0;
   if (has_in) USC_REQUIRE(in->dx == dout && in->n == sh.n_out && in->c == cout, "usc unit: pending slices do not belong to this unit");
-  if (tile_form_on() && usc_bn_tile_ok(sh.n_out, cout) && sb >= usc_bn_tile_ws_bytes(cout)) {
+  if (tile_rows_ok(sh.n_out, cout) && sb >= usc_bn_tile_ws_bytes(cout)) {
     rc = usc_bn_tile_backward(has_in ? in->partial : nullptr, has_in ? in->G : 0, has_in ? in->accumulate : 0, (float*)dout, y,
                               out_relu, mean, invstd, bn->gamma, sh.n_out, cout, bn->training, dbn_accumulate, dgamma,
                               dbeta, dy, dres, sws, sb, s);

@@ -379,7 +379,7 @@ class Mask3D(nn.Module):
                     batched_aux, batched_attn, batched_pos_enc = ops.sample_keys(
                         feats_l.contiguous(), attn_mask.F.contiguous(), pos_l.contiguous(), plan["gidx"], n_scenes,
                         curr_sample_size, [min(n, curr_sample_size) for n in sizes], outs=outs,
-                        unique=plan["all_sampled"],
+                        unique=plan["all_sampled"], valid_unique=True,     # (the plan's keys: distinct rows, then masked padding)
                         sink=sinks.setdefault((hlevel, bool(plan["all_sampled"])), ops.GradSink()) if _GRAD_SINKS else None)
                 elif bufs is not None:
                     # ONE gather for the whole batch: rows of the level's feature / mask tables addressed by

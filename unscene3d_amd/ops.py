@@ -689,7 +689,7 @@ class GradSink:
 
 class _SampleKeys(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, mask, pos, idx, n_scenes, K, n_valid, outs, unique, sink=None):
+    def forward(ctx, feats, mask, pos, idx, n_scenes, K, n_valid, outs, unique, sink=None, valid_unique=False):
         c, q = feats.shape[1], mask.shape[1]
         p = 0 if pos is None else pos.shape[1]
         dev = feats.device
@@ -718,6 +718,7 @@ class _SampleKeys(torch.autograd.Function):
         # [B, K, Q] / [B, K, p] tensors for them (two stock fills per decoder pass, up to 26 us for the bool one)
         ctx.set_materialize_grads(False)
         ctx.n_src, ctx.unique = feats.shape[0], bool(unique)
+        ctx.valid_unique = bool(valid_unique)
         ctx.K, ctx.n_valid = int(K), [min(int(v), int(K)) for v in n_valid]
         ctx.sink = sink if (sink is not None and ctx.needs_input_grad[0]) else None     # (forward runs under no_grad)
         if ctx.sink is not None:
@@ -737,16 +738,22 @@ class _SampleKeys(torch.autograd.Function):
                 sink.pending -= 1
                 if sink.pending == 0 and sink.buf is not None:
                     dsrc, sink.buf = sink.buf, None
-                    return (dsrc,) + (None,) * 9
-            return (None,) * 10
+                    return (dsrc,) + (None,) * 10
+            return (None,) * 11
         dfeats = dfeats.contiguous().view(idx.shape[0], -1)
         c = dfeats.shape[1]
 
         def scatter(dst, add):
-            # The first n_valid[b] keys of a scene are distinct rows (a random subset, or every row of the scene); the
-            # rest is padding that repeats row 0 and is masked for every query, so its gradient rows are exact zeros:
-            # only the distinct prefix is scattered, with plain (or read-modify-write) row stores.  (Scattering the
-            # padding with float atomics serialised on row 0: 214 us per pass on a 20 k-voxel scene.)
+            # unique: all K keys of every scene are distinct rows.  valid_unique (the decoder's plans, models/mask3d.py
+            # _draw_key_samples): the first n_valid[b] keys of a scene are distinct — a random subset, or every row of the
+            # scene — and the rest is padding that repeats row 0 and is masked for every query, so its gradient rows are
+            # exact zeros: only the distinct prefix is scattered, with plain (or read-modify-write) row stores.
+            # (Scattering the padding with float atomics serialised on row 0: 214 us per pass on a 20 k-voxel scene.)
+            # Neither: duplicates anywhere — float atomics over all keys.
+            if not (ctx.unique or ctx.valid_unique):
+                check(lib.usc_scatter_add_rows(_ptr(dfeats), c, _ptr(idx), idx.shape[0], _ptr(dst), _stream()),
+                      "usc_scatter_add_rows")
+                return
             fn = lib.usc_scatter_rows_unique_add if add else lib.usc_scatter_rows_unique
             if ctx.unique or all(v == ctx.K for v in ctx.n_valid):
                 check(fn(_ptr(dfeats), c, _ptr(idx), idx.shape[0], _ptr(dst), _stream()), "usc_scatter_rows")
@@ -766,21 +773,22 @@ class _SampleKeys(torch.autograd.Function):
             scatter(sink.buf, add=not first)
             sink.pending -= 1
             if sink.pending > 0:
-                return (None,) * 10
+                return (None,) * 11
             dsrc, sink.buf = sink.buf, None
-            return (dsrc,) + (None,) * 9
+            return (dsrc,) + (None,) * 10
         dsrc = torch.zeros((ctx.n_src, c), dtype=torch.float32, device=dfeats.device)
         scatter(dsrc, add=False)
-        return (dsrc,) + (None,) * 9
+        return (dsrc,) + (None,) * 10
 
 
-def sample_keys(feats, mask, pos, idx, n_scenes, K, n_valid, outs=None, unique=False, sink=None):
+def sample_keys(feats, mask, pos, idx, n_scenes, K, n_valid, outs=None, unique=False, sink=None, valid_unique=False):
     """The cross-attention keys of one decoder pass (reference models/mask3d.py:306-346) in two launches:
     rows `idx` (i64[n_scenes*K], batch-wide row numbers) of the level's features f32[n,c], thresholded attention
     masks bool[n,Q] and positional encodings f32[n,p] (or None) -> ([B,K,c], bool[B,K,Q], [B,K,p]); a query column
     masked in all K rows of its scene is cleared; rows k >= n_valid[b] (padding) are fully masked.
     outs: the caller's three buffers (e.g. the inputs of a captured pass).  Gradient: features only (scatter;
-    `unique` as in gather_rows).  sink: a GradSink shared by every call that samples the SAME `feats` in this forward
+    `unique` as in gather_rows; valid_unique: only the first n_valid[b] keys of every scene are distinct and the padding
+    behind them carries no gradient).  sink: a GradSink shared by every call that samples the SAME `feats` in this forward
     pass — their gradients are then accumulated into one buffer."""
     _chk(feats, torch.float32, "feats")
     _chk(mask, torch.bool, "mask")
@@ -791,7 +799,8 @@ def sample_keys(feats, mask, pos, idx, n_scenes, K, n_valid, outs=None, unique=F
             raise RuntimeError("sample_keys: pos and feats must have the same rows")
     if mask.shape[0] != feats.shape[0] or idx.shape[0] != n_scenes * K or len(n_valid) != n_scenes:
         raise RuntimeError("sample_keys: inconsistent sizes")
-    return _SampleKeys.apply(feats, mask, pos, idx, int(n_scenes), int(K), list(n_valid), outs, unique, sink)
+    return _SampleKeys.apply(feats, mask, pos, idx, int(n_scenes), int(K), list(n_valid), outs, unique, sink,
+                             valid_unique)
 
 
 def gather_rows_i32(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
