@@ -296,6 +296,23 @@ def make_ncut(ref):
     np.savez_compressed(os.path.join(HERE, "ncut.npz"), **out)
 
 
+def make_ncut_l2(ref):
+    """get_affinity_matrix(similarity_metric='l2') of the reference (unscene3d_pseudo_main.py:89-119 -> l2_sim,
+    utils/freemask_utils.py:20-36) on clustered single-modality features: thresholded affinity bits + degrees."""
+    rng = np.random.default_rng(123)
+    S, d, k = 150, 24, 7
+    centres = rng.normal(0, 1, (k, d))
+    lab = rng.integers(0, k, S)
+    feats = (centres[lab] + rng.normal(0, 0.35, (S, d))).astype(np.float32)
+    out = {"feats": feats}
+    for tau in (0.5, 0.7):
+        A, D = ref.get_affinity_matrix(torch.from_numpy(feats.copy()), tau=tau, similarity_metric="l2")
+        out[f"tau{tau}/A"] = np.packbits(A > 0.5, axis=1)
+        out[f"tau{tau}/deg"] = np.diag(D).copy()
+        print("ncut_l2 tau", tau, "ones", int((A > 0.5).sum()), "of", S * S)
+    np.savez_compressed(os.path.join(HERE, "ncut_l2.npz"), **out)
+
+
 def make_aggregate(ref):
     """N1: `aggregate_features` (pseudo_masks/unscene3d_pseudo_main.py:350-402) on seeded point features: segment ids
     with gaps, ~20 % all-zero (invalid) rows, segments whose rows are ALL zero — filled from the connected segments of
@@ -781,6 +798,8 @@ if __name__ == "__main__":
         make_state_dict()
     elif len(sys.argv) > 1 and sys.argv[1] == "ncut":
         make_ncut(import_reference_ncut())
+    elif len(sys.argv) > 1 and sys.argv[1] == "ncut_l2":
+        make_ncut_l2(import_reference_ncut())
     elif len(sys.argv) > 1 and sys.argv[1] == "ncut_b":
         make_ncut_b(import_reference_ncut())
     elif len(sys.argv) > 1 and sys.argv[1] == "elastic":

@@ -594,6 +594,26 @@ def _ncut_case(name):
     return z, feats, S, masks
 
 
+def test_l2_similarity_metric_matches_the_reference(device):
+    """similarity_metric='l2' (reference unscene3d_pseudo_main.py:95 -> utils/freemask_utils.py:20-36; off the shipped
+    configurations): thresholded affinity and degrees against tests/golden/ncut_l2.npz, generated by the reference's own
+    get_affinity_matrix in the build container."""
+    from unscene3d_amd.pseudo_masks import ncut
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "ncut_l2.npz"))
+    feats = _dev(z["feats"], device)
+    S = feats.shape[0]
+    for tau in (0.5, 0.7):
+        A, deg = ncut.get_affinity_matrix(feats, tau=tau, similarity_metric="l2")
+        want = np.unpackbits(z[f"tau{tau}/A"], axis=1)[:, :S].astype(bool)
+        got = A.cpu().numpy().astype(bool)
+        assert (got != want).sum() <= 2e-4 * S * S + 2, int((got != want).sum())     # borderline fp32 entries at the threshold
+        d_want = z[f"tau{tau}/deg"]
+        assert np.abs(deg.cpu().numpy() - d_want).max() <= 3.0 + 1e-9                 # (a flipped bit moves a degree by ~1)
+    with pytest.raises(ValueError):
+        ncut.get_affinity_matrix(feats, similarity_metric="l1")
+
+
 @pytest.mark.parametrize("name", ["single", "dual"])
 def test_config5_ncut_matches_reference(device, name):
     """Config 5.  Golden vectors = the reference's own unscene3d() traced in the build container.

@@ -1048,7 +1048,17 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int S, in
     const int64_t n4 = numel >> 2;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n4; j += (int64_t)gridDim.x * blockDim.x) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s = 0; s < S; ++s) {
+      // eight slices in flight per thread (one load per iteration was one memory round trip per slice: 51 dependent trips
+      // for the 12 800-row projections of the decoder, 64 on the finest level); the adds keep the slice order
+      int s = 0;
+      for (; s + 8 <= S; s += 8) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = reinterpret_cast<const float4*>(partial)[(int64_t)(s + u) * n4 + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+      }
+      for (; s < S; ++s) {
         const float4 t = reinterpret_cast<const float4*>(partial)[(int64_t)s * n4 + j];
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
       }

@@ -57,8 +57,8 @@ class Mask3D(nn.Module):
         sizes = self.backbone.PLANES[-5:]
 
         self.mask_features_head = conv(self.backbone.PLANES[7], self.mask_dim, kernel_size=1, stride=1, bias=True, D=3)
-        if scatter_type != "mean":
-            raise NotImplementedError("scatter_type 'max' is not used by the shipped configs (conf/model/mask3d.yaml:31)")
+        if scatter_type not in ("mean", "max"):
+            raise ValueError(f"Scatter function not known: {scatter_type!r}")          # reference :68-69 asserts
         assert (not use_np_features) or non_parametric_queries, "np features only with np queries"
 
         if non_parametric_queries:
@@ -294,7 +294,13 @@ class Mask3D(nn.Module):
         mask_segments, seg_csr = None, None
         if self.train_on_segments:
             seg_csr = geo["seg_csr"]
-            mask_segments = [ops.segment_mean(f, csr) for f, csr in zip(mask_features.decomposed_features, seg_csr)]
+            if self.scatter_type == "mean":
+                mask_segments = [ops.segment_mean(f, csr) for f, csr in zip(mask_features.decomposed_features, seg_csr)]
+            else:
+                # scatter_type 'max' (reference :66-67, :223: torch_scatter.scatter_max(...)[0]; not used by the shipped
+                # configs, conf/model/mask3d.yaml:31): per-segment channel maximum, empty segments 0, the gradient goes to
+                # the maximal row — plain device tensor ops
+                mask_segments = [_segment_max(f, csr.seg, csr.S) for f, csr in zip(mask_features.decomposed_features, seg_csr)]
 
         sampled_coords = None
         if self.non_parametric_queries:
@@ -755,6 +761,11 @@ def _child_segment_table(cm, ts, rows):
         tab = torch.where(nbr2 >= 0, rows.to(torch.int32)[nbr2.clamp(min=0).long()], nbr2).contiguous()
         hit = cache[ts] = (rows.data_ptr(), tab, rows)
     return hit[1]
+
+
+def _segment_max(feats, seg, S):
+    out = torch.zeros((int(S), feats.shape[1]), dtype=feats.dtype, device=feats.device)
+    return out.scatter_reduce(0, seg.to(torch.int64)[:, None].expand(-1, feats.shape[1]), feats, "amax", include_self=False)
 
 
 def _stack(tensors):

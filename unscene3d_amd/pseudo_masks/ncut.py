@@ -31,6 +31,24 @@ def _similarity(feats: torch.Tensor, cosine_mode: bool, zero_rows=None) -> torch
     return sim
 
 
+def _l2_similarity(feats: torch.Tensor, zero_rows=None, block: int = 256) -> torch.Tensor:
+    """`l2_sim(F.normalize(feats), F.normalize(feats))` of the reference (utils/freemask_utils.py:20-36; selected by
+    similarity_metric='l2', unscene3d_pseudo_main.py:95): pairwise Euclidean distances of the L2-normalised rows, per-row
+    min-max normalisation (no epsilon, as the reference), 1 - distance.  Not used by the shipped configurations
+    (pseudo_masks/config/default.yaml: cos): plain device tensor ops in the reference's operation order, keys in blocks."""
+    f = feats.float()
+    if zero_rows is not None:
+        f = f * (1.0 - zero_rows.to(f.dtype))[:, None]       # get_masked_affinity_matrix's product (:122-135)
+    f = torch.nn.functional.normalize(f, p=2, dim=-1)
+    S = f.shape[0]
+    attn = torch.empty((S, S), dtype=torch.float32, device=f.device)
+    for k0 in range(0, S, block):
+        attn[:, k0:k0 + block] = torch.linalg.norm(f[:, None, :] - f[None, k0:k0 + block, :], dim=-1)
+    attn -= attn.min(-1, keepdim=True)[0]
+    attn /= attn.max(-1, keepdim=True)[0]
+    return (1.0 - attn).contiguous()
+
+
 def normalize_mat(A: torch.Tensor, eps=1e-5) -> torch.Tensor:
     """In place (reference :82-86), on the device."""
     ws = torch.empty(12288, dtype=torch.uint8, device=A.device)
@@ -48,9 +66,11 @@ def get_affinity_matrix(feats, tau=0.15, eps=1e-5, normalize_sim=True, similarit
     reference's `A[painting] = eps; A[:, painting] = eps` (unscene3d :426-427) in the same launch.
     `zero_rows` (device u8[S]): rows of `feats` to read as `0 * row` — get_masked_affinity_matrix's product formed
     inside the row normalisation (the cut loop passes the ORIGINAL features and the painting so far)."""
-    if similarity_metric != "cos":
-        raise NotImplementedError("only the cosine metric is used by the published pipeline")
-    if isinstance(feats, tuple):
+    if similarity_metric not in ("cos", "l2"):
+        raise ValueError(f"similarity_metric must be 'cos' or 'l2', not {similarity_metric!r}")
+    if similarity_metric == "l2" and not isinstance(feats, tuple):
+        sims = [_l2_similarity(feats, zero_rows)]           # reference :95 -> utils/freemask_utils.py:20-36
+    elif isinstance(feats, tuple):
         sims = [_similarity(f, cosine_mode=False, zero_rows=zero_rows) for f in feats]
     else:
         sims = [_similarity(feats, cosine_mode=True, zero_rows=zero_rows)]
