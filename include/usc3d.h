@@ -565,7 +565,10 @@ int usc_scatter_rows_unique_add(const float* src, int32_t c, const int64_t* idx,
  *   out_mask[b,k,:]  = mask[idx[b*K+k],:] (bool bytes [n,q], q <= 128), then
  *     - a query column that is masked in ALL K gathered rows of its scene is cleared in the scene's real rows,
  *     - rows k >= n_valid[b] (padding; their idx repeats a real row) are fully masked.
- * n_valid: HOST array i32[n_scenes] (n_scenes <= 16).  ws: usc_sample_keys_ws_bytes(). */
+ * n_valid: HOST array i32[n_scenes] (n_scenes <= 16).  ws: usc_sample_keys_ws_bytes().
+ * Partial calls: feats == NULL with c == 0 gathers the mask rows only (the part of a pass's keys that depends on the
+ * queries, :337-346); mask == NULL with q == 0 the feature / positional rows only (query-independent: a caller may
+ * issue it ahead of the decoder loop on another stream; one launch, no ws). */
 int64_t usc_sample_keys_ws_bytes(int32_t n_scenes, int32_t K, int32_t q);
 int usc_sample_keys(const float* feats, int32_t c, const uint8_t* mask, int32_t q, const float* pos, int32_t p,
                     const int64_t* idx, int32_t n_scenes, int32_t K, const int32_t* n_valid, float* out_feats,
@@ -953,6 +956,12 @@ int usc_unproject_depth(const float* depth, const float* views, const float* int
  * (16-byte aligned): p *= 1 - lr*wd; m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
  * p -= (lr / (1 - b1^step)) * m / (sqrt(v) / sqrt(1 - b2^step) + eps).  step counts from 1.
  * ---------------------------------------------------------------------- */
+/* Diagnostic, no reference counterpart: `wgs` workgroups that spin for `microseconds` on stream s.  HIP multiplexes its
+ * streams onto a few hardware queues (4 per priority by default), and two streams that share one do not overlap however
+ * independent their work is: unscene3d_amd/streams.py times pairs of these launches to pick streams that really run
+ * beside the compute stream. */
+int usc_spin(int64_t microseconds, int wgs, usc_stream_t s);
+
 int usc_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                    int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int64_t step, usc_stream_t s);

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Compute-stream time of the sections of the bench step, free-running (events on the default stream, no host syncs
+added): backbone forward | decoder forward | criterion | criterion + decoder backward | backbone backward | optimizer.
+Made to see what a second stream (USC3D_KV_SIDE_STREAM) takes off the compute stream, section by section.
+Usage (GPU box): python tools/decoder_spans.py [bench.py flags]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+args = bench.parse()
+dev = torch.device("cuda:0")
+step = bench.make_mask3d_step(args, dev, 0, 1)
+model = step.module.model
+main = torch.cuda.default_stream(0)
+marks = []            # per step: dict name -> event
+
+
+def mark(name):
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(main)
+    marks[-1][name] = ev
+    if name == "dec_bwd_done":          # where the key-preparation stream is when the host has issued the decoder's backward
+        for st in model.__dict__.get("_usc_side_streams", {}).values():
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(st)
+            marks[-1]["side_done"] = ev
+
+
+orig_bb = model.backbone.forward
+
+
+def bb_forward(*a, **k):
+    mark("bb0")
+    out = orig_bb(*a, **k)
+    mark("bb1")
+    feats = [t.F for t in (out[1] if isinstance(out, tuple) else [out]) if hasattr(t, "F")]
+    if isinstance(out, tuple) and hasattr(out[0], "F"):
+        feats.append(out[0].F)
+    for f in feats:
+        if f.requires_grad:
+            f.register_hook(lambda g: (mark("dec_bwd_done"), None)[1])      # the last firing overwrites: all decoder gradients in
+    return out
+
+
+model.backbone.forward = bb_forward
+orig_fwd = model.forward
+
+
+def fwd(*a, **k):
+    out = orig_fwd(*a, **k)
+    mark("dec_fwd_done")
+    return out
+
+
+model.forward = fwd
+orig_backward = torch.Tensor.backward
+
+
+def backward(self, *a, **k):
+    mark("bwd0")
+    r = orig_backward(self, *a, **k)
+    mark("bwd1")
+    return r
+
+
+torch.Tensor.backward = backward
+n = args.steps + args.warmup
+for i in range(n):
+    marks.append({})
+    mark("t0")
+    step(1)
+    mark("t1")
+torch.cuda.synchronize()
+rows = [("backbone forward", "bb0", "bb1"), ("decoder forward", "bb1", "dec_fwd_done"), ("criterion", "dec_fwd_done", "bwd0"),
+        ("criterion + decoder backward", "bwd0", "dec_bwd_done"), ("backbone backward", "dec_bwd_done", "bwd1"),
+        ("reduce + optimizer", "bwd1", "t1"), ("step", "t0", "t1"),
+        ("key-preparation stream done AFTER the compute stream's decoder backward by", "dec_bwd_done", "side_done")]
+use = marks[args.warmup:]
+for name, a, b in rows:
+    v = [m[a].elapsed_time(m[b]) for m in use if a in m and b in m]
+    print(f"{sum(v) / max(1, len(v)):8.3f} ms  {name}")
+step.close()

@@ -154,6 +154,7 @@ SIGNATURES = {
     "usc_project_reduce": (C.c_int, [_p, _i32, _p, _p, _i64, _i32, _p, _p, _p]),
     "usc_project_predictions": (C.c_int, [_p, _i32, _p, _i64, _p, _p]),
     "usc_unproject_depth": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p]),
+    "usc_spin": (C.c_int, [_i64, C.c_int, _p]),
     "usc_adamw_step": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _p]),
     "usc_elastic_displace": (C.c_int, [_p, _i32, _i64, _i32, _p, _i32, _i32, _i32, _p, _p, _p, _f64, _p, _p]),
     "usc_attn_ws_bytes": (_i64, [_i32, _i32, _i32, _i32]),

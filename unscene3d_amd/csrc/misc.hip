@@ -274,11 +274,24 @@ __global__ __launch_bounds__(256) void color_lut_kernel(const float* __restrict_
   }
 }
 
+// occupies `wgs` workgroups for `ticks` of the 100 MHz constant clock (usc_spin: stream placement probe)
+__global__ void spin_kernel(long ticks) {
+  long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+
 }  // namespace usc
 
 using namespace usc;
 
 extern "C" {
+
+int usc_spin(int64_t microseconds, int wgs, usc_stream_t s) {
+  USC_REQUIRE(microseconds >= 0 && microseconds <= 100000 && wgs >= 1 && wgs <= 4096, "usc_spin: bad arguments");
+  hipLaunchKernelGGL(spin_kernel, dim3((unsigned)wgs), dim3(64), 0, as_stream(s), (long)(100 * microseconds));
+  USC_CHECK_LAUNCH("usc_spin");
+  return USC_OK;
+}
 
 int usc_knn1(const float* query, int64_t nq, const float* ref, int64_t nr, int64_t* idx, float* dist2, usc_stream_t s) {
   USC_REQUIRE(nq >= 0 && nr >= 1, "usc_knn1: bad sizes");

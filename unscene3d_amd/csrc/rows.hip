@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void sample_keys_kernel(SampleArgs a) {
   for (int r = 0; r < 4; ++r) {
     const float4* f = reinterpret_cast<const float4*>(a.feats + src[r] * a.c);
     const float4* ps = reinterpret_cast<const float4*>(a.pos + src[r] * a.p);
-    const unsigned char* ms = a.mask + src[r] * a.q;
+    const unsigned char* ms = a.mask + src[r] * a.q;       // (q == 0: never dereferenced, qa / qb are false)
     f0[r] = fa ? f[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
     f1[r] = fb ? f[lane + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
     q0[r] = pa ? ps[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1365,25 +1365,32 @@ int64_t usc_sample_keys_ws_bytes(int32_t n_scenes, int32_t K, int32_t q) {
 int usc_sample_keys(const float* feats, int32_t c, const uint8_t* mask, int32_t q, const float* pos, int32_t p,
                     const int64_t* idx, int32_t n_scenes, int32_t K, const int32_t* n_valid, float* out_feats,
                     uint8_t* out_mask, float* out_pos, void* ws, int64_t ws_bytes, usc_stream_t s) {
-  USC_REQUIRE(n_scenes >= 1 && n_scenes <= usc::kSampleMaxScenes && K >= 1 && c >= 4 && c % 4 == 0 && q >= 1 &&
-                  c <= 512 && q <= usc::kSampleMaxQ && (pos == nullptr || (p >= 4 && p % 4 == 0 && p <= 512)),
+  // feats == NULL with c == 0: mask rows only (the part of a pass's keys that depends on the queries); mask == NULL with
+  // q == 0: feature / positional rows only (the part that does not: issued ahead of the decoder loop, on another stream)
+  USC_REQUIRE(n_scenes >= 1 && n_scenes <= usc::kSampleMaxScenes && K >= 1 && c >= 0 && c % 4 == 0 && q >= 0 &&
+                  c <= 512 && q <= usc::kSampleMaxQ && (pos == nullptr || (p >= 4 && p % 4 == 0 && p <= 512)) &&
+                  (c > 0 || q > 0),
               "usc_sample_keys: unsupported sizes (scenes <= 16, queries <= 128, channel counts multiples of 4 up to 512)");
-  USC_REQUIRE(feats && mask && idx && n_valid && out_feats && out_mask && ws && (pos == nullptr || out_pos),
+  USC_REQUIRE(idx && n_valid && (c == 0 || (feats && out_feats)) && (q == 0 || (mask && out_mask && ws)) &&
+                  (pos == nullptr || out_pos),
               "usc_sample_keys: null pointer");
+  if (c == 0) { feats = nullptr; out_feats = nullptr; }
+  if (q == 0) { mask = nullptr; out_mask = nullptr; }
   usc::SampleArgs a{};
   a.feats = feats; a.mask = mask; a.pos = pos; a.idx = idx;
   a.out_feats = out_feats; a.out_mask = out_mask; a.out_pos = out_pos; a.part = (unsigned char*)ws;
   a.c = c; a.q = q; a.p = p; a.K = K;
   a.nblk = (int)ceil_div((int64_t)K, (int64_t)usc::kSampleRows);
   a.qs = (q + 3) / 4 * 4;
-  USC_REQUIRE(((uintptr_t)ws & 3) == 0, "usc_sample_keys: workspace must be 4-byte aligned");
-  USC_REQUIRE(ws_bytes >= usc_sample_keys_ws_bytes(n_scenes, K, q), "usc_sample_keys: workspace too small");
+  USC_REQUIRE(q == 0 || ((uintptr_t)ws & 3) == 0, "usc_sample_keys: workspace must be 4-byte aligned");
+  USC_REQUIRE(q == 0 || ws_bytes >= usc_sample_keys_ws_bytes(n_scenes, K, q), "usc_sample_keys: workspace too small");
   for (int b = 0; b < n_scenes; ++b) {
     USC_REQUIRE(n_valid[b] >= 1, "usc_sample_keys: a scene without rows");
     a.n_valid[b] = n_valid[b];
   }
   hipLaunchKernelGGL(usc::sample_keys_kernel, dim3((unsigned)a.nblk, (unsigned)n_scenes), dim3(256), 0, as_stream(s), a);
-  hipLaunchKernelGGL(usc::sample_fix_kernel, dim3((unsigned)a.nblk, (unsigned)n_scenes), dim3(256), 0, as_stream(s), a);
+  if (q > 0)
+    hipLaunchKernelGGL(usc::sample_fix_kernel, dim3((unsigned)a.nblk, (unsigned)n_scenes), dim3(256), 0, as_stream(s), a);
   USC_CHECK_LAUNCH("usc_sample_keys");
   return USC_OK;
 }

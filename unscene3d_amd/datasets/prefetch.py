@@ -73,7 +73,9 @@ class ScenePrefetcher:
         self.collate, self.add_raw, self.n_down, self.ksize = collate, add_raw_coordinates, n_down, ksize
         self.precompute = precompute
         self.device = torch.device(device)
-        self.side = torch.cuda.Stream(device=self.device)
+        # a stream measured to run beside the compute stream (streams.py: two HIP streams may share a hardware queue)
+        from .. import streams
+        self.side = streams.pick(self.device, "prefetch", high_priority_first=False)
         self._pending = None
         self._keep = collections.deque(maxlen=2)
         self._jobs = self._worker = None
@@ -92,9 +94,9 @@ class ScenePrefetcher:
             job = self._jobs.get()
             if job is None:
                 return
-            samples, box = job
+            samples, box, gate = job
             try:
-                box["result"] = self._issue(samples)
+                box["result"] = self._issue(samples, gate)
             except BaseException as err:                     # handed to the thread that calls take()
                 box["error"] = err
             box["done"].set()
@@ -112,16 +114,19 @@ class ScenePrefetcher:
                 warnings.warn("ScenePrefetcher.close(): the worker thread did not finish within 30 s and is left "
                               "running (daemon); a batch may still be in flight on the side stream")
 
-    def submit(self, samples):
+    def submit(self, samples, gate=None):
+        """gate: an event (of the compute stream, say) that the batch's device work waits for."""
         if self._worker is not None:
             box = {"done": threading.Event()}
-            self._jobs.put((samples, box))
+            self._jobs.put((samples, box, gate))
             self._pending = box
             return
-        self._pending = self._issue(samples)
+        self._pending = self._issue(samples, gate)
 
-    def _issue(self, samples):
+    def _issue(self, samples, gate=None):
         with torch.cuda.stream(self.side):
+            if gate is not None:
+                self.side.wait_event(gate)
             data, target, names = self.collate(samples)
             feats, raw = data.features, None
             if self.add_raw:

@@ -102,7 +102,11 @@ class BucketedGradReducer:
         if self.expected is not None:
             if self.launched and self.launched[self.bucket_of[id(param)]]:
                 self._late = True        # the kernels of this write race with the bucket's collective already in flight
-            self._advance()
+            from . import ops
+            if not (self.flat.is_cuda and ops.on_side_stream()):
+                # (a report from the decoder's key-preparation stream only counts: a collective started here would be
+                # ordered behind THAT stream alone; the next report on the compute stream, or finish(), starts it)
+                self._advance()
 
     def _complete(self, b):
         return all(self.counts[i] >= self.expected[i] for i in self.members[b])
@@ -113,8 +117,9 @@ class BucketedGradReducer:
         if self.flat.is_cuda:
             # weight gradients queued on the lane stream (units.py) are not in this stream's order yet: the collective
             # reads the bucket in the order of the current stream
-            from . import units
+            from . import ops, units
             units.join_lane(self.flat.device)
+            ops.join_side_streams()          # (the decoder's key-preparation stream writes lin_squeeze / in_proj gradients)
         self.handles.append(dist.all_reduce(self.flat[s:e], async_op=True))
         self.launched[b] = True
 

@@ -9,6 +9,7 @@ kernels, as planned in SURVEY.md §7.6.
 Randomness: the reference sub-samples cross-attention keys with `torch.randperm` (mask3d.py:325);
 `self.randperm` can be replaced to inject fixed indices (parity tests do that).
 """
+import contextlib
 import os
 
 import torch
@@ -110,11 +111,24 @@ class Mask3D(nn.Module):
 
     # ------------------------------------------------------------------
     def _eager_pass(self, dec, i):
-        # the embedding MODULE, not a slice of its weight: the pass must own the parameter so that graph capture
-        # differentiates with respect to it and reads its live storage (a slice taken here would be a constant)
-        return _DecoderPass(self.lin_squeeze[dec][i], self.cross_attention[dec][i], self.self_attention[dec][i],
-                            self.ffn_attention[dec][i], self.level_embed if self.use_level_embed else None, i,
+        return _DecoderPass(self.cross_attention[dec][i], self.self_attention[dec][i], self.ffn_attention[dec][i],
                             self.num_heads)
+
+    def _key_prep(self, dec, i):
+        """The query-independent half of pass (dec, i): lin_squeeze (+ level embedding) and the key / value projections."""
+        # the embedding MODULE, not a slice of its weight: autograd differentiates with respect to the live parameter
+        return _KeyPrep(self.lin_squeeze[dec][i], self.cross_attention[dec][i],
+                        self.level_embed if self.use_level_embed else None, i)
+
+    def _side_stream(self, device):
+        """The HIP stream the query-independent key preparation of the decoder passes runs on (one per device)."""
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        pool = self.__dict__.setdefault("_usc_side_streams", {})
+        if key not in pool:
+            from .. import streams       # (measured to overlap with the compute and prefetch streams: streams.py)
+            pool[key] = streams.pick(device, "keys")
+            ops.SIDE_STREAMS.append(pool[key])
+        return pool[key]
 
     def _decoder_pass(self, decoder_counter, dec, i):
         """The callable for pass (decoder_counter, level i): a captured HIP graph when enabled, else eager."""
@@ -139,9 +153,9 @@ class Mask3D(nn.Module):
                 passes.append(self._eager_pass(dec, i))
                 samples.append((torch.zeros(B, Q, d, device=device, requires_grad=True),
                                 torch.zeros(Q, B, d, device=device, requires_grad=True),
-                                torch.zeros(B, K, sizes[hlevel], device=device, requires_grad=True),
-                                torch.zeros(B, K, Q, device=device, dtype=torch.bool),
-                                torch.zeros(B, K, d, device=device)))
+                                torch.zeros(K, B, d, device=device, requires_grad=True),       # keys   (ops.in_proj_kv,
+                                torch.zeros(K, B, d, device=device, requires_grad=True),       # values  outside the graph)
+                                torch.zeros(B, K, Q, device=device, dtype=torch.bool)))
         from ..graphs import capture_passes
         # query_pos (input 1) is one tensor for all passes of a step; the queries (input 0) are the previous pass's output
         graphed = capture_passes(passes, samples, shared_inputs=(1,), chain_input=0)
@@ -212,6 +226,8 @@ class Mask3D(nn.Module):
         # seeded run consumes the global generator in the reference's order.
         rng_queries = (not self.non_parametric_queries) and (self.random_queries or self.random_query_both)
         geo["key_samples"] = None if rng_queries else self._draw_key_samples(coords, is_eval)
+        if geo["key_samples"] is not None:
+            self._gather_pos_keys(geo["key_samples"], geo["pos_encodings_pcd"], geo)
         if self.train_on_segments and point2segment is not None and _FUSED_ATTN_MASK and len(point2segment) >= 1:
             # the mask module's child -> segment-row table (used by all 12 attention-mask chains of the step)
             if len(point2segment) == 1:
@@ -231,6 +247,27 @@ class Mask3D(nn.Module):
         # grew by 40 MB per step for 300 steps)
         x._usc_geometry = geo
         return geo
+
+    def _gather_pos_keys(self, samples, pos_encodings_pcd, geo):
+        """samples["pos_keys"][pass] = positional encodings of the pass's sampled voxels, f32[B, K, d] (reference :334-335):
+        geometry only, so the scene prefetcher issues these twelve gathers with the key samples."""
+        out = []
+        for pidx, plan in enumerate(samples["passes"]):
+            hlevel = self.hlevels[pidx % self.num_levels]
+            per_scene = pos_encodings_pcd[hlevel][0]
+            n_scenes, K = len(per_scene), plan["k"]
+            if plan["gidx"] is not None and per_scene[0].is_cuda:
+                if n_scenes == 1:
+                    pos_l = per_scene[0]
+                else:
+                    cat = geo.setdefault("pos_cat", {})
+                    if hlevel not in cat:
+                        cat[hlevel] = torch.cat(per_scene)
+                    pos_l = cat[hlevel]
+                out.append(ops.gather_rows(pos_l.contiguous(), plan["gidx"]).view(n_scenes, K, -1))
+            else:
+                out.append(_stack([per_scene[k][plan["rand_idx"][k], :] for k in range(n_scenes)]))
+        samples["pos_keys"] = out
 
     def _graph_key(self):
         g = getattr(self, "_graphed_passes", None)
@@ -252,7 +289,7 @@ class Mask3D(nn.Module):
                 if not (self.max_sample_size or is_eval):
                     curr = min(curr, self.sample_sizes[hlevel])
                 if graphed:
-                    want = self._graph_shapes[decoder_counter * self.num_levels + i][2][1]
+                    want = self._graph_shapes[decoder_counter * self.num_levels + i][2][0]
                     if curr < want:
                         # a level smaller than the captured key count: pad up to it (row 0, masked like the padding of
                         # a ragged batch) so the captured pass still applies.  Masked keys carry softmax weight 0: the
@@ -330,98 +367,111 @@ class Mask3D(nn.Module):
         samples = geo.pop("key_samples", None)         # drawn with the geometry (prefetch stream), used once
         if samples is None or samples["is_eval"] != bool(is_eval) or samples["graph_key"] != self._graph_key():
             samples = self._draw_key_samples(coords, is_eval)
+        if samples.get("pos_keys") is None:
+            self._gather_pos_keys(samples, pos_encodings_pcd, geo)
 
         predictions_class, predictions_mask = [], []
         p2s_arg = point2segment if self.train_on_segments else None
         sinks = {}      # one gradient buffer per backbone level for the num_decoders key samples taken from it
+        # The keys and values of a pass — sampled voxel rows -> lin_squeeze (+ level embedding) -> key / value projections
+        # (reference :306-354, :547-605) — depend on the backbone's output and the sampled indices, not on the queries:
+        # they are issued on a SIDE stream, pass by pass, and run beside the query chain (mask module -> attention mask ->
+        # pass), forward and backward (autograd runs a node's backward on the stream of its forward and orders the
+        # streams itself).  What stays on the chain per pass: the thresholded attention-mask rows.
+        use_side = _KV_SIDE_STREAM and x.F.is_cuda
+        main = torch.cuda.current_stream() if x.F.is_cuda else None
+        side = self._side_stream(x.device) if use_side else None
+        if use_side:
+            ready = torch.cuda.Event()
+            ready.record(main)                 # backbone features exist; the previous step's backward is behind this point too
+            side.wait_event(ready)
         for decoder_counter in range(self.num_decoders):
             dec = 0 if self.shared_decoder else decoder_counter
             for i, hlevel in enumerate(self.hlevels):
-                normed, queries = self._norm_queries(queries)
-                output_class, outputs_mask, attn_mask = self.mask_module(
-                    queries, mask_features, mask_segments, len(aux) - hlevel - 1, ret_attn_mask=True,
-                    point2segment=p2s_arg, coords=coords, defer_class=True, normed=normed)
-
+                pidx = decoder_counter * self.num_levels + i
+                plan = samples["passes"][pidx]
                 decomposed_aux = aux[hlevel].decomposed_features
-                decomposed_attn = attn_mask.decomposed_features
                 sizes = [f.shape[0] for f in decomposed_aux]
                 if min(sizes) == 1:
                     raise RuntimeError(SINGLE_POINT_ERROR)
-                plan = samples["passes"][decoder_counter * self.num_levels + i]
                 if plan["sizes"] != sizes:
                     raise RuntimeError(f"key samples were drawn for level sizes {plan['sizes']}, the backbone produced "
                                        f"{sizes}")
                 curr_sample_size, rand_idx, mask_idx = plan["k"], plan["rand_idx"], plan["mask_idx"]
-                graph_shapes = (self._graph_shapes[decoder_counter * self.num_levels + i]
-                                if getattr(self, "_graphed_passes", None) is not None else None)
-
+                n_valid = [min(n, curr_sample_size) for n in sizes]
+                graph_shapes = (self._graph_shapes[pidx] if getattr(self, "_graphed_passes", None) is not None else None)
                 step_fn = self._decoder_pass(decoder_counter, dec, i)
                 bufs = None
+                d_model = self.mask_dim
                 if graph_shapes is not None:
-                    want = graph_shapes
-                    have = (queries.shape, query_pos.shape, (n_scenes, curr_sample_size, decomposed_aux[0].shape[1]),
-                            (n_scenes, curr_sample_size, decomposed_attn[0].shape[1]),
-                            (n_scenes, curr_sample_size, pos_encodings_pcd[hlevel][0][0].shape[1]))
-                    if tuple(tuple(h) for h in have) != tuple(tuple(w) for w in want):
+                    have = (queries.shape, query_pos.shape, (curr_sample_size, n_scenes, d_model),
+                            (curr_sample_size, n_scenes, d_model), (n_scenes, curr_sample_size, self.num_queries))
+                    if tuple(tuple(h) for h in have) != tuple(tuple(w) for w in graph_shapes):
                         step_fn = self._eager_pass(dec, i)
                     elif _GATHER_INTO_GRAPH_INPUTS and plan["gidx"] is not None:
-                        bufs = step_fn.input_buffers    # gather straight into the captured pass's input buffers
+                        bufs = step_fn.input_buffers    # keys / values / mask written straight into the captured pass's inputs
                 feats_l = aux[hlevel].F
                 fused = (_FUSED_KEY_SAMPLING and plan["gidx"] is not None and feats_l.is_cuda
-                         and feats_l.dtype == torch.float32 and n_scenes <= 16 and attn_mask.F.dtype == torch.bool
-                         and attn_mask.F.shape[1] <= 128 and feats_l.shape[1] % 4 == 0
-                         and pos_encodings_pcd[hlevel][0][0].shape[1] % 4 == 0)
-                if fused:
-                    # two launches: the three row gathers (straight into the captured pass's input buffers when there
-                    # are any), the all-masked-query rule (reference :346) and the padding mask (:343)
-                    if n_scenes == 1:
-                        pos_l = pos_encodings_pcd[hlevel][0][0]
-                    else:
-                        cat = geo.setdefault("pos_cat", {})
-                        if hlevel not in cat:
-                            cat[hlevel] = torch.cat(pos_encodings_pcd[hlevel][0])
-                        pos_l = cat[hlevel]
-                    outs = None if bufs is None else (bufs[2], bufs[3], bufs[4])
-                    batched_aux, batched_attn, batched_pos_enc = ops.sample_keys(
-                        feats_l.contiguous(), attn_mask.F.contiguous(), pos_l.contiguous(), plan["gidx"], n_scenes,
-                        curr_sample_size, [min(n, curr_sample_size) for n in sizes], outs=outs,
-                        unique=plan["all_sampled"], valid_unique=True,     # (the plan's keys: distinct rows, then masked padding)
-                        sink=sinks.setdefault((hlevel, bool(plan["all_sampled"])), ops.GradSink()) if _GRAD_SINKS else None)
-                elif bufs is not None:
-                    # ONE gather for the whole batch: rows of the level's feature / mask tables addressed by
-                    # scene offset + sampled index, written into the [B, K, .] input buffers of the captured pass
-                    gidx = plan["gidx"]
-                    feats_l = feats_l.contiguous()
-                    batched_aux = ops.gather_rows(feats_l, gidx, out=bufs[2].view(-1, feats_l.shape[1]),
-                                                  unique=plan["all_sampled"]).view(bufs[2].shape)
-                    batched_attn = torch.index_select(attn_mask.F, 0, gidx,
-                                                      out=bufs[3].view(-1, bufs[3].shape[2])).view(bufs[3].shape)
-                    for k in range(n_scenes):
-                        torch.index_select(pos_encodings_pcd[hlevel][0][k], 0, rand_idx[k], out=bufs[4][k])
-                    batched_pos_enc = bufs[4]
-                else:
-                    batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k],
-                                                          unique=sizes[k] > curr_sample_size) for k in range(n_scenes)])
-                    batched_attn = _stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
-                    batched_pos_enc = _stack([pos_encodings_pcd[hlevel][0][k][rand_idx[k], :] for k in range(n_scenes)])
+                         and feats_l.dtype == torch.float32 and n_scenes <= 16 and feats_l.shape[1] % 4 == 0
+                         and self.num_queries <= 128)
 
-                if fused:
-                    pass
+                # ---- query-independent half (side stream): rows of the level's features -> keys, values
+                if use_side:
+                    # geometry tensors come from the prefetch stream's pool and are released as soon as the host has
+                    # ISSUED their last reader (autograd drops a node's saved tensors after running it): the allocator
+                    # must know that this stream reads them too, or the next scene's prefetch overwrites the indices
+                    # under a backward kernel still in flight here (seen as a memory access fault)
+                    for t in (plan["gidx"], samples["pos_keys"][pidx], feats_l):
+                        if t is not None and t.is_cuda:
+                            t.record_stream(side)
+                with (torch.cuda.stream(side) if use_side else contextlib.nullcontext()):
+                    if fused:
+                        batched_aux = ops.sample_keys(
+                            feats_l.contiguous(), None, None, plan["gidx"], n_scenes, curr_sample_size, n_valid,
+                            unique=plan["all_sampled"], valid_unique=True,       # (the plan's keys: distinct rows, then masked padding)
+                            sink=sinks.setdefault((hlevel, bool(plan["all_sampled"])), ops.GradSink()) if _GRAD_SINKS else None)
+                    else:
+                        if use_side:
+                            for t in rand_idx:
+                                t.record_stream(side)
+                        batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k],
+                                                              unique=sizes[k] > curr_sample_size) for k in range(n_scenes)])
+                    k_keys, v_keys = self._key_prep(dec, i)(batched_aux, samples["pos_keys"][pidx],
+                                                            outs=None if bufs is None else (bufs[2], bufs[3]))
+                    if use_side:
+                        kv_done = torch.cuda.Event()
+                        kv_done.record(side)
+                        if bufs is None:               # fresh tensors of the side stream's pool, read on the compute stream
+                            k_keys.record_stream(main)
+                            v_keys.record_stream(main)
+
+                # ---- the query chain (compute stream)
+                normed, queries = self._norm_queries(queries)
+                output_class, outputs_mask, attn_mask = self.mask_module(
+                    queries, mask_features, mask_segments, len(aux) - hlevel - 1, ret_attn_mask=True,
+                    point2segment=p2s_arg, coords=coords, defer_class=True, normed=normed)
+                decomposed_attn = attn_mask.decomposed_features
+                if fused and attn_mask.F.dtype == torch.bool and attn_mask.F.shape[1] <= 128:
+                    # the mask rows, the all-masked-query rule (reference :346) and the padding mask (:343): two launches
+                    batched_attn = ops.sample_keys(None, attn_mask.F.contiguous(), None, plan["gidx"], n_scenes,
+                                                   curr_sample_size, n_valid,
+                                                   outs=None if bufs is None else (None, bufs[4], None))
                 else:
+                    batched_attn = _stack([decomposed_attn[k][rand_idx[k], :] for k in range(n_scenes)])
                     # a query whose sampled keys are all masked attends to everything (reference :346)
                     batched_attn.permute(0, 2, 1)[batched_attn.sum(1) == curr_sample_size] = False
-                    if plan["all_sampled"]:
-                        pass                               # every scene was sampled: no padding rows to mask
-                    elif bufs is not None:
-                        torch.logical_or(batched_attn, _stack(mask_idx)[..., None], out=batched_attn)
-                    else:
+                    if not plan["all_sampled"]:        # (every scene sampled: no padding rows to mask)
                         batched_attn = torch.logical_or(batched_attn, _stack(mask_idx)[..., None])
+                    if bufs is not None:
+                        bufs[4].copy_(batched_attn)
+                        batched_attn = bufs[4]
 
                 rec = getattr(self, "attn_mask_record", None)
                 if rec is not None:          # parity tests: the thresholded masks are discrete decisions
                     rec.append(batched_attn.detach().clone())
-                queries = step_fn(queries, query_pos, batched_aux.contiguous(), batched_attn.contiguous(),
-                                  batched_pos_enc.contiguous())
+                if use_side:
+                    main.wait_event(kv_done)
+                queries = step_fn(queries, query_pos, k_keys, v_keys, batched_attn.contiguous())
 
                 predictions_class.append(output_class)
                 predictions_mask.append(outputs_mask)
@@ -704,28 +754,49 @@ class LayerNorm(nn.LayerNorm):
         return super().forward(x)
 
 
-class _DecoderPass(nn.Module):
-    """lin_squeeze -> masked cross attention -> self attention -> FFN of one (decoder, level) pass
-    (reference mask3d.py:351-373).  Pure tensor-in / tensor-out with static shapes whenever every scene
-    has at least `sample_sizes[hlevel]` voxels at that level, which makes it capturable as a HIP graph
-    (Mask3D.enable_decoder_graphs): ~45 forward and ~90 backward launches per pass become one graph launch
-    each, removing most of the host launch overhead of the 12 passes."""
+class _KeyPrep:
+    """lin_squeeze (+ level embedding) and the key / value thirds of the cross attention's input projection over the
+    sampled voxels of one (decoder, level) pass (reference mask3d.py:351-354 and the k / v part of :547-605): everything
+    of a pass that does not depend on the queries.  [B, K, C], [B, K, d] -> keys, values [K, B, d]."""
 
-    def __init__(self, squeeze, cross, self_attn, ffn, level_embed, level, num_heads):
-        super().__init__()
-        self.squeeze, self.cross, self.self_attn, self.ffn = squeeze, cross, self_attn, ffn
-        self.level_embed, self.level, self.num_heads = level_embed, level, num_heads   # nn.Embedding or None
+    def __init__(self, squeeze, cross, level_embed, level):
+        self.squeeze, self.cross, self.level_embed, self.level = squeeze, cross, level_embed, level
 
-    def forward(self, queries, query_pos, batched_aux, batched_attn, batched_pos_enc):
+    def __call__(self, batched_aux, batched_pos, outs=None):
         src = self.squeeze(batched_aux.permute(1, 0, 2))
         if self.level_embed is not None:
             src = src + self.level_embed.weight[self.level]          # reference mask3d.py:353-354
-        out = self.cross(queries.permute(1, 0, 2), src, memory_mask=None, memory_mask_bsl=batched_attn,
-                         memory_key_padding_mask=None, pos=batched_pos_enc.permute(1, 0, 2), query_pos=query_pos)
+        mha = self.cross.multihead_attn
+        pos = batched_pos.permute(1, 0, 2)
+        if src.is_cuda and src.dtype == torch.float32:
+            return ops.in_proj_kv(src, mha.in_proj_weight, mha.in_proj_bias, pos=pos.contiguous(), outs=outs)
+        E = src.shape[-1]
+        W, b = mha.in_proj_weight, mha.in_proj_bias
+        k, v = F.linear(src + pos, W[E:2 * E], b[E:2 * E]), F.linear(src, W[2 * E:], b[2 * E:])
+        if outs is not None:
+            outs[0].copy_(k), outs[1].copy_(v)
+            k, v = outs
+        return k, v
+
+
+class _DecoderPass(nn.Module):
+    """masked cross attention (on prepared keys / values) -> self attention -> FFN of one (decoder, level) pass
+    (reference mask3d.py:355-373).  Pure tensor-in / tensor-out with static shapes whenever every scene
+    has at least `sample_sizes[hlevel]` voxels at that level, which makes it capturable as a HIP graph
+    (Mask3D.enable_decoder_graphs): ~16 forward and ~25 backward launches per pass become one graph launch
+    each, removing most of the host launch overhead of the 12 passes.  The keys and values come from _KeyPrep."""
+
+    def __init__(self, cross, self_attn, ffn, num_heads):
+        super().__init__()
+        self.cross, self.self_attn, self.ffn, self.num_heads = cross, self_attn, ffn, num_heads
+
+    def forward(self, queries, query_pos, k, v, batched_attn):
+        out = self.cross.forward_kv(queries.permute(1, 0, 2), k, v, batched_attn, query_pos)
         out = self.self_attn(out, tgt_mask=None, tgt_key_padding_mask=None, query_pos=query_pos)
         return self.ffn(out).permute(1, 0, 2)
 
 
+_KV_SIDE_STREAM = os.environ.get("USC3D_KV_SIDE_STREAM", "1") != "0"
 _FUSED_ATTN_MASK = os.environ.get("USC3D_FUSED_ATTN_MASK", "1") != "0"
 _CHAIN_SEGMENT_GRADS = os.environ.get("USC3D_CHAIN_SEGMENT_GRADS", "1") != "0"
 
@@ -868,6 +939,45 @@ class CrossAttentionLayer(nn.Module):
         return _residual_norm(self, tgt, upd)
 
 
+def _attention_on_projected(q, k, v, mask_bsl, H, dropout_p, training):
+    """softmax(q k^T / sqrt(hd) + mask) v on already projected q [L,B,E], k / v [S,B,E] (sequence-first), mask bool[B,S,L]
+    (True = masked): the fused HIP kernels for head dim 16 and <= 128 queries, else plain tensor ops."""
+    L, B, E = q.shape
+    S = k.shape[0]
+    hd = E // H
+    if q.is_cuda and q.dtype == torch.float32 and hd == 16 and L <= 128 and mask_bsl is not None and dropout_p == 0.0:
+        return ops.masked_cross_attention(q, k.contiguous(), v.contiguous(), mask_bsl, H)
+    qh = q.reshape(L, B * H, hd).transpose(0, 1).reshape(B, H, L, hd)
+    kh = k.reshape(S, B * H, hd).transpose(0, 1).reshape(B, H, S, hd)
+    vh = v.reshape(S, B * H, hd).transpose(0, 1).reshape(B, H, S, hd)
+    scores = (qh @ kh.transpose(-1, -2)) / (hd ** 0.5)
+    if mask_bsl is not None:
+        scores = scores.masked_fill(mask_bsl.permute(0, 2, 1)[:, None], float("-inf"))
+    att = F.dropout(torch.softmax(scores, dim=-1), dropout_p, training)
+    return (att @ vh).permute(2, 0, 1, 3).reshape(L, B, E)
+
+
+def _cross_forward_kv(self, tgt, k, v, mask_bsl, query_pos):
+    """CrossAttentionLayer on PREPARED keys / values (ops.in_proj_kv over the sampled voxels, computed apart from the
+    query chain): query projection, masked attention, output projection, residual + post-norm (reference :547-605)."""
+    mha = self.multihead_attn
+    src = self.norm(tgt) if self.normalize_before else tgt
+    W, b = mha.in_proj_weight, mha.in_proj_bias
+    E = src.shape[-1]
+    if src.is_cuda and src.dtype == torch.float32:
+        if not self.normalize_before and _RESIDUAL_IN_PROJECTION and (mha.dropout == 0.0 or not self.training):
+            q, tgt = ops.in_proj_q(src, W, b, pos=query_pos, residual=True)
+        else:
+            q = ops.in_proj_q(src, W, b, pos=query_pos)
+        out = _attention_on_projected(q, k, v, mask_bsl, mha.num_heads, mha.dropout if self.training else 0.0, self.training)
+        upd = ops.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    else:
+        q = F.linear(_with_pos(src, query_pos), W[:E], b[:E])
+        out = _attention_on_projected(q, k, v, mask_bsl, mha.num_heads, mha.dropout if self.training else 0.0, self.training)
+        upd = F.linear(out, mha.out_proj.weight, mha.out_proj.bias)
+    return _residual_norm(self, tgt, upd)
+
+
 class FFNLayer(nn.Module):
     """Feed-forward block (reference :607-651)."""
 
@@ -894,6 +1004,9 @@ class FFNLayer(nn.Module):
         else:
             hidden = self.dropout(self.activation(self.linear1(src)))
         return _residual_norm(self, tgt, self.linear2(hidden))
+
+
+CrossAttentionLayer.forward_kv = _cross_forward_kv
 
 
 def _get_activation_fn(activation):

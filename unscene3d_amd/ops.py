@@ -310,6 +310,26 @@ def pairs_gemm(feats, W, rows_in, rows_out, koff, P, n_out):
 GRAD_IN_PLACE = os.environ.get("USC3D_GRAD_IN_PLACE", "1") == "1"
 
 
+# streams other than the compute stream that backward kernels of this package write parameter gradients on (the decoder's
+# key-preparation stream, models/mask3d.py): whoever reads p.grad outside autograd's own stream bookkeeping — a gradient
+# reducer starting a collective in the middle of backward — lets the current stream wait for them first
+SIDE_STREAMS = []
+
+
+def on_side_stream():
+    if not SIDE_STREAMS:
+        return False
+    raw = _stream()
+    return any(st.cuda_stream == raw for st in SIDE_STREAMS)
+
+
+def join_side_streams():
+    cur = torch.cuda.current_stream()
+    for st in SIDE_STREAMS:
+        if st.device == cur.device:
+            cur.wait_stream(st)
+
+
 GRAD_WRITTEN_HOOK = None   # callable(param), set by ddp.BucketedGradReducer: "the kernels that add into p.grad are queued"
 
 
@@ -325,7 +345,30 @@ def _grad_target(param):
     return None
 
 
+_JOIN_QUEUED = False
+
+
+def _join_after_backward():
+    """Called by backward kernels that may be running on one of SIDE_STREAMS.  The engine makes the caller's stream wait
+    for the streams of the AccumulateGrad nodes it ran, not for a stream on which a backward wrote p.grad in place: one
+    end-of-backward callback lets the caller's stream wait for the side streams, so that `loss.backward();
+    optimizer.step()` stays correct without the caller knowing about them."""
+    global _JOIN_QUEUED
+    if _JOIN_QUEUED or not SIDE_STREAMS:
+        return
+    if not on_side_stream():
+        return
+    _JOIN_QUEUED = True
+
+    def done():
+        global _JOIN_QUEUED
+        _JOIN_QUEUED = False
+        join_side_streams()
+    torch.autograd.Variable._execution_engine.queue_callback(done)
+
+
 def _grad_written(*params):
+    _join_after_backward()
     if GRAD_WRITTEN_HOOK is not None:
         for p in params:
             if p is not None:
@@ -690,44 +733,45 @@ class GradSink:
 class _SampleKeys(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, mask, pos, idx, n_scenes, K, n_valid, outs, unique, sink=None, valid_unique=False):
-        c, q = feats.shape[1], mask.shape[1]
+        # feats None: the mask rows only; mask None: the feature (+ positional) rows only (usc_sample_keys' partial calls)
+        c = 0 if feats is None else feats.shape[1]
+        q = 0 if mask is None else mask.shape[1]
         p = 0 if pos is None else pos.shape[1]
-        dev = feats.device
+        dev = idx.device
         if outs is None:
-            of = torch.empty((n_scenes, K, c), dtype=torch.float32, device=dev)
-            om = torch.empty((n_scenes, K, q), dtype=torch.bool, device=dev)
+            of = None if feats is None else torch.empty((n_scenes, K, c), dtype=torch.float32, device=dev)
+            om = None if mask is None else torch.empty((n_scenes, K, q), dtype=torch.bool, device=dev)
             op = None if pos is None else torch.empty((n_scenes, K, p), dtype=torch.float32, device=dev)
         else:
             # fresh tensor objects over the caller's storage: the objects returned from here get autograd metadata
             of, om, op = (None if o is None else o.detach() for o in outs)
-            want = ((n_scenes, K, c), (n_scenes, K, q)) + (() if pos is None else ((n_scenes, K, p),))
-            have = (tuple(of.shape), tuple(om.shape)) + (() if pos is None else (tuple(op.shape),))
-            if have != want or of.dtype != torch.float32 or om.dtype != torch.bool or not of.is_contiguous() \
-                    or not om.is_contiguous() or (op is not None and (
-                        op.dtype != torch.float32 or not op.is_contiguous())):
-                raise RuntimeError(f"sample_keys: output buffers {have} do not fit {want} (contiguous f32 / bool / f32): "
-                                   f"dtypes {of.dtype}, {om.dtype}, {None if op is None else op.dtype}; "
-                                   f"strides {of.stride()}, {om.stride()}")
+            for name, t, want, dt in (("features", of, (n_scenes, K, c), torch.float32), ("mask", om, (n_scenes, K, q), torch.bool),
+                                      ("positions", op, (n_scenes, K, p), torch.float32)):
+                if (t is None) != (want[2] == 0):
+                    raise RuntimeError(f"sample_keys: an output buffer for the {name} is {'missing' if t is None else 'not wanted'}")
+                if t is not None and (tuple(t.shape) != want or t.dtype != dt or not t.is_contiguous()):
+                    raise RuntimeError(f"sample_keys: the {name} buffer {tuple(t.shape)} {t.dtype} (strides {t.stride()}) "
+                                       f"does not fit {want} contiguous {dt}")
         nv = (ctypes.c_int32 * n_scenes)(*[int(v) for v in n_valid])
-        wsb = lib.usc_sample_keys_ws_bytes(n_scenes, K, q)
-        ws = _ws(wsb, dev)
+        wsb = lib.usc_sample_keys_ws_bytes(n_scenes, K, q) if q else 0
+        ws = _ws(wsb, dev) if q else None
         check(lib.usc_sample_keys(_ptr(feats), c, _ptr(mask), q, _ptr(pos), p, _ptr(idx), n_scenes, K, nv, _ptr(of),
-                                  _ptr(om), _ptr(op), _ptr(ws), ws.numel(), _stream()), "usc_sample_keys")
+                                  _ptr(om), _ptr(op), _ptr(ws), 0 if ws is None else ws.numel(), _stream()), "usc_sample_keys")
         ctx.save_for_backward(idx)
         # the mask and positional outputs never carry a gradient: without this the engine hands backward() zero-filled
         # [B, K, Q] / [B, K, p] tensors for them (two stock fills per decoder pass, up to 26 us for the bool one)
         ctx.set_materialize_grads(False)
-        ctx.n_src, ctx.unique = feats.shape[0], bool(unique)
+        ctx.n_src, ctx.unique = (0 if feats is None else feats.shape[0]), bool(unique)
         ctx.valid_unique = bool(valid_unique)
         ctx.K, ctx.n_valid = int(K), [min(int(v), int(K)) for v in n_valid]
         ctx.sink = sink if (sink is not None and ctx.needs_input_grad[0]) else None     # (forward runs under no_grad)
         if ctx.sink is not None:
             ctx.sink.pending += 1
-        ctx.mark_non_differentiable(om)
-        if op is not None:
-            ctx.mark_non_differentiable(op)
-            return of, om, op
-        return of, om
+        outs_ = tuple(t for t in (of, om, op) if t is not None)
+        for t in (om, op):
+            if t is not None:
+                ctx.mark_non_differentiable(t)
+        return outs_ if len(outs_) > 1 else outs_[0]
 
     @staticmethod
     def backward(ctx, dfeats, *_):
@@ -784,20 +828,24 @@ class _SampleKeys(torch.autograd.Function):
 def sample_keys(feats, mask, pos, idx, n_scenes, K, n_valid, outs=None, unique=False, sink=None, valid_unique=False):
     """The cross-attention keys of one decoder pass (reference models/mask3d.py:306-346) in two launches:
     rows `idx` (i64[n_scenes*K], batch-wide row numbers) of the level's features f32[n,c], thresholded attention
-    masks bool[n,Q] and positional encodings f32[n,p] (or None) -> ([B,K,c], bool[B,K,Q], [B,K,p]); a query column
+    masks bool[n,Q] and positional encodings f32[n,p] (or None) -> ([B,K,c], bool[B,K,Q], [B,K,p]) — feats None: the
+    masks only (-> bool[B,K,Q]); mask None: the features (and positions) only, in one launch; a query column
     masked in all K rows of its scene is cleared; rows k >= n_valid[b] (padding) are fully masked.
     outs: the caller's three buffers (e.g. the inputs of a captured pass).  Gradient: features only (scatter;
     `unique` as in gather_rows; valid_unique: only the first n_valid[b] keys of every scene are distinct and the padding
     behind them carries no gradient).  sink: a GradSink shared by every call that samples the SAME `feats` in this forward
     pass — their gradients are then accumulated into one buffer."""
-    _chk(feats, torch.float32, "feats")
-    _chk(mask, torch.bool, "mask")
+    if feats is None and mask is None:
+        raise RuntimeError("sample_keys: nothing to gather")
+    rows = None
+    for t, dt, name in ((feats, torch.float32, "feats"), (mask, torch.bool, "mask"), (pos, torch.float32, "pos")):
+        if t is not None:
+            _chk(t, dt, name)
+            if rows is not None and t.shape[0] != rows:
+                raise RuntimeError("sample_keys: feats, mask and pos must have the same rows")
+            rows = t.shape[0]
     _chk(idx, torch.int64, "idx")
-    if pos is not None:
-        _chk(pos, torch.float32, "pos")
-        if pos.shape[0] != feats.shape[0]:
-            raise RuntimeError("sample_keys: pos and feats must have the same rows")
-    if mask.shape[0] != feats.shape[0] or idx.shape[0] != n_scenes * K or len(n_valid) != n_scenes:
+    if idx.shape[0] != n_scenes * K or len(n_valid) != n_scenes:
         raise RuntimeError("sample_keys: inconsistent sizes")
     return _SampleKeys.apply(feats, mask, pos, idx, int(n_scenes), int(K), list(n_valid), outs, unique, sink,
                              valid_unique)
@@ -1035,7 +1083,7 @@ def _rows_gemm_ok(rows, n_in, n_out):
     return rows > SMALL_ROWS and n_in % 32 == 0 and n_out % 32 == 0
 
 
-def _lin_fwd(x2, W, b, add=None, relu=False, pad_rows_to=None):
+def _lin_fwd(x2, W, b, add=None, relu=False, pad_rows_to=None, out=None):
     """y = (x2 [+ add]) W^T + b [then ReLU] for contiguous f32 x2 [M,K], W [N,K] (a contiguous row block is fine);
     `add` / `relu` are folded into the launch on the few-row kernels and applied separately elsewhere.
     pad_rows_to: y gets that many rows, the extra ones zero (few-row kernels only)."""
@@ -1043,7 +1091,9 @@ def _lin_fwd(x2, W, b, add=None, relu=False, pad_rows_to=None):
     N = W.shape[0]
     if _small_linear_ok(M, K, N):
         Mp = M if pad_rows_to is None else int(pad_rows_to)
-        y = torch.empty((Mp, N), dtype=torch.float32, device=x2.device)
+        y = torch.empty((Mp, N), dtype=torch.float32, device=x2.device) if out is None else out
+        if tuple(y.shape) != (Mp, N) or y.dtype != torch.float32 or not y.is_contiguous():
+            raise RuntimeError(f"linear: `out` must be a contiguous f32 [{Mp}, {N}] tensor")
         check(lib.usc_linear_fwd_pad(_ptr(x2), _ptr(add), _ptr(W), _ptr(b), M, N, K, int(relu), _ptr(y), Mp, _stream()),
               "usc_linear_fwd")
         return y
@@ -1052,12 +1102,13 @@ def _lin_fwd(x2, W, b, add=None, relu=False, pad_rows_to=None):
     if add is not None:
         x2 = x2 + add
     if relu:
-        return torch.relu_(_lin_fwd(x2, W, b))
+        return torch.relu_(_lin_fwd(x2, W, b, out=out))
     if _rows_gemm_ok(M, K, N) and W.is_contiguous():
         # W [N, K] is the product's [cout][cin]: read in place by the row-order kernel (was: a transpose launch per call,
         # 36 per training step inside the captured decoder passes)
-        return gather_gemm(x2, W.view(1, N, K), None, M, bias=b, w_transposed=True)
-    return torch.addmm(b, x2, W.t()) if b is not None else x2 @ W.t()
+        return gather_gemm(x2, W.view(1, N, K), None, M, bias=b, out=out, w_transposed=True)
+    y = torch.addmm(b, x2, W.t()) if b is not None else x2 @ W.t()
+    return y if out is None else out.copy_(y)
 
 
 def col_sum(x2, out, accumulate=False):
@@ -1312,6 +1363,109 @@ class _InProj(torch.autograd.Function):
             out_x = (gq, gv, None) if chain_v else (gq, gk, gv)
             out_p = (gq if need_pq else None, gk if need_pk else None)
         return out_x, out_p
+
+
+def _packed_grad_targets(W, b):
+    """(dW [3E,E], db [3E], in_place) for one part of a packed in-projection: the parameters' gradient buffers when they
+    exist (the part's rows are added into), else fresh zero tensors (returned to autograd whole)."""
+    tw, tb = _grad_target(W), _grad_target(b)
+    if tw is not None and tb is not None:
+        return tw, tb, True
+    return torch.zeros_like(W), torch.zeros_like(b), False
+
+
+class _InProjQ(torch.autograd.Function):
+    """q = (x + pos) Wq^T + bq, Wq = in_proj_weight[:E] — the QUERY third of nn.MultiheadAttention's packed input
+    projection on its own (reference models/mask3d.py:547-605 CrossAttentionLayer, :517 with_pos_embed), so that the key /
+    value thirds can be computed elsewhere (ops.in_proj_kv: they do not depend on the queries).  residual: x comes back
+    as a second output and its gradient (the block's residual path) is summed inside the input-gradient launch."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, pos, residual=False):
+        E = W.shape[1]
+        x2 = x.contiguous().view(-1, E)
+        p2 = None if pos is None else pos.contiguous().view(-1, E)
+        if p2 is not None and not _small_linear_ok(x2.shape[0], E, E):
+            x2, p2 = x2 + p2, None
+        y = _lin_fwd(x2, W[:E], b[:E], add=p2)
+        ctx.save_for_backward(x2, W, p2)
+        ctx.shape, ctx.pos_shape = x.shape, None if pos is None else pos.shape
+        ctx.w_param, ctx.b_param = W, b
+        y = y.view(*x.shape[:-1], E)
+        return (y, x) if residual else y
+
+    @staticmethod
+    def backward(ctx, dq, dres=None):
+        x2, W, p2 = ctx.saved_tensors
+        E = W.shape[1]
+        dW, db, in_place = _packed_grad_targets(ctx.w_param, ctx.b_param)
+        dq2 = dq.contiguous().view(-1, E)
+        dres2 = None if dres is None else dres.contiguous().view(-1, E)
+        need_pos = ctx.pos_shape is not None and ctx.needs_input_grad[3]
+        if dres2 is not None and need_pos:
+            gx, gpos = _lin_bwd(dq2, x2, W[:E], dW[:E], db[:E], need_dx=True, accumulate=in_place, add=p2, dx_add2=dres2,
+                                want_dx_b=True)
+        else:
+            gx = _lin_bwd(dq2, x2, W[:E], dW[:E], db[:E], need_dx=True, accumulate=in_place, add=p2, dx_add=dres2)
+            gpos = gx if need_pos else None
+        if in_place:
+            dW = db = None
+            _grad_written(ctx.w_param, ctx.b_param)
+        return (gx.view(ctx.shape), dW, db, None if gpos is None or ctx.pos_shape is None else gpos.view(ctx.pos_shape), None)
+
+
+class _InProjKV(torch.autograd.Function):
+    """k = (x + pos) Wk^T + bk, v = x Wv^T + bv with Wk, Wv = in_proj_weight[E:2E], [2E:3E]: the key / value thirds of the
+    packed input projection over the sampled voxels of a decoder pass.  `outs` (optional): (k, v) buffers to write into
+    (the static inputs of a captured pass).  One summed gradient for x (k's part chained into v's launch)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, pos, outs=None):
+        E = W.shape[1]
+        x2 = x.contiguous().view(-1, E)
+        p2 = None if pos is None else pos.contiguous().view(-1, E)
+        xk, pk = x2, p2
+        if pk is not None and not _small_linear_ok(x2.shape[0], E, E):
+            xk, pk = x2 + pk, None                  # (many rows: no fused add on those kernels)
+        ok, ov = (None, None) if outs is None else (outs[0].detach().view(-1, E), outs[1].detach().view(-1, E))
+        k = _lin_fwd(xk, W[E:2 * E], b[E:2 * E], add=pk, out=ok)
+        v = _lin_fwd(x2, W[2 * E:], b[2 * E:], out=ov)
+        ctx.save_for_backward(xk, x2, W, pk)
+        ctx.shape = x.shape
+        ctx.w_param, ctx.b_param = W, b
+        shp = (*x.shape[:-1], E)
+        return k.view(shp), v.view(shp)
+
+    @staticmethod
+    def backward(ctx, dk, dv):
+        xk, x2, W, pk = ctx.saved_tensors
+        E = W.shape[1]
+        dW, db, in_place = _packed_grad_targets(ctx.w_param, ctx.b_param)
+        need = ctx.needs_input_grad[0]
+        gk = _lin_bwd(dk.contiguous().view(-1, E), xk, W[E:2 * E], dW[E:2 * E], db[E:2 * E], need_dx=need,
+                      accumulate=in_place, add=pk)
+        gx = _lin_bwd(dv.contiguous().view(-1, E), x2, W[2 * E:], dW[2 * E:], db[2 * E:], need_dx=need,
+                      accumulate=in_place, dx_add=gk)
+        if in_place:
+            dW = db = None
+            _grad_written(ctx.w_param, ctx.b_param)
+        return (None if gx is None else gx.view(ctx.shape)), dW, db, None, None
+
+
+def in_proj_q(x, W, b, pos=None, residual=False):
+    _chk(W, torch.float32, "in_proj_weight")
+    _chk(b, torch.float32, "in_proj_bias")
+    if pos is not None and pos.shape != x.shape:
+        raise RuntimeError(f"in_proj_q: pos {tuple(pos.shape)} must have the shape of the input {tuple(x.shape)}")
+    return _InProjQ.apply(x, W, b, pos, residual)
+
+
+def in_proj_kv(x, W, b, pos=None, outs=None):
+    _chk(W, torch.float32, "in_proj_weight")
+    _chk(b, torch.float32, "in_proj_bias")
+    if pos is not None and pos.shape != x.shape:
+        raise RuntimeError(f"in_proj_kv: pos {tuple(pos.shape)} must have the shape of the input {tuple(x.shape)}")
+    return _InProjKV.apply(x, W, b, pos, outs)
 
 
 def in_proj(xq, xk, xv, W, b, pos_q=None, pos_k=None, residual=False):

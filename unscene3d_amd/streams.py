@@ -1,0 +1,77 @@
+"""HIP streams that really run beside each other.
+
+HIP multiplexes its streams onto a few hardware queues — GPU_MAX_HW_QUEUES, 4 by default, per priority — and hands a new
+stream the least-used queue.  torch draws its streams from a pool of 32 per priority, so which queue a
+`torch.cuda.Stream()` lands on depends on how many streams the process created before; two streams on one queue execute
+strictly one kernel after the other, however independent their work (measured here: a key-preparation stream that happened
+to share the compute stream's queue made the step 0.35 ms SLOWER — all of the cross-stream waits, none of the overlap).
+`pick()` therefore measures: it times pairs of spinning launches (usc_spin) on a candidate and on every stream the
+candidate has to run beside, and returns the first candidate that overlaps with all of them.  High-priority candidates
+come first: their queues are a separate set, which the null stream (torch's default compute stream) never shares.
+
+No reference counterpart (the reference is single-stream PyTorch); used by datasets/prefetch.py and models/mask3d.py.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import torch
+
+from ._lib import check, lib
+
+SPIN_US = 40
+SPIN_N = 8
+_PICKED = {}          # (device index, role) -> stream
+REPORT = []           # one dict per pick(): what was measured (tools/stream_queue_probe.py prints it)
+
+
+def overlap_ratio(a: torch.cuda.Stream, b: torch.cuda.Stream, us: int = SPIN_US, n: int = SPIN_N) -> float:
+    """wall time of n spins on a AND n on b (issued alternately) / n spins on a alone: ~1 when the two streams run
+    beside each other, ~2 when they share a hardware queue.  Synchronises the device."""
+    def run(second):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            check(lib.usc_spin(us, 1, a.cuda_stream), "usc_spin")
+            if second is not None:
+                check(lib.usc_spin(us, 1, second.cuda_stream), "usc_spin")
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    run(b)                                   # first use of a stream binds its queue: not timed
+    one = min(run(None) for _ in range(2))
+    two = min(run(b) for _ in range(2))
+    return two / one
+
+
+def pick(device, role: str, beside=(), high_priority_first: bool = True, max_candidates: int = 6) -> torch.cuda.Stream:
+    """A stream for `role` on `device` that overlaps with the device's default stream and with every stream in `beside`
+    (cached per (device, role)).  Falls back to the best candidate seen, noted in REPORT, when none overlaps with all."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, role)
+    if key in _PICKED:
+        return _PICKED[key]
+    if os.environ.get("USC3D_STREAM_PROBE", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        st = torch.cuda.Stream(device=device)
+        _PICKED[key] = st
+        return st
+    with torch.cuda.device(idx):
+        others = [torch.cuda.default_stream(idx)] + [s for s in beside if s is not None] \
+            + [s for (d, r), s in _PICKED.items() if d == idx and r != role]
+        prios = ([-1] if high_priority_first else []) + [0] * max_candidates + ([] if high_priority_first else [-1])
+        best, best_worst, tried = None, 1e9, []
+        for pr in prios:
+            cand = torch.cuda.Stream(device=device, priority=pr)
+            if any(cand.cuda_stream == o.cuda_stream for o in others):
+                continue
+            ratios = [overlap_ratio(o, cand) for o in others]
+            worst = max(ratios)
+            tried.append({"priority": pr, "ratios": [round(r, 2) for r in ratios]})
+            if worst < best_worst:
+                best, best_worst = cand, worst
+            if worst < 1.35:
+                break
+    REPORT.append({"role": role, "device": idx, "shared_queue": best_worst >= 1.35, "tried": tried})
+    _PICKED[key] = best
+    return best
