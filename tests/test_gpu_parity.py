@@ -1722,7 +1722,8 @@ def test_deferred_weight_gradients_equal_the_immediate_ones(device, monkeypatch)
     """Res16UNet34C on a 20 k-voxel scene, gradient buffers allocated (the trainer's configuration): with the
     weight gradients of the coarse levels queued and issued as grouped launches (units.GROUP_WGRAD) every parameter
     gradient equals the immediate path's to rounding, nothing is left in the queue after backward, and a second
-    backward pass gives the same bits (no stale queue state)."""
+    backward pass gives the same bits (no stale queue state).  The same for the weight-gradient LANE (a second stream,
+    joined once at the end of the backward pass), which is what runs by default."""
     from types import SimpleNamespace
 
     from unscene3d_amd import MinkowskiEngine as ME
@@ -1747,8 +1748,14 @@ def test_deferred_weight_gradients_equal_the_immediate_ones(device, monkeypatch)
         return real(R_, *a)
 
     res = {}
-    for mode in (False, True, "again"):
-        monkeypatch.setattr(units, "GROUP_WGRAD", bool(mode))
+    lane_rows = units.LANE_MAX_ROWS
+    units.set_lane_max_rows(0)             # (the lane, on by default, takes the weight gradients before the queue sees them)
+    request_lane = []
+    for mode in (False, True, "again", "lane", "lane again"):
+        if mode == "lane":
+            units.set_lane_max_rows(1 << 40)
+            request_lane.append(True)
+        monkeypatch.setattr(units, "GROUP_WGRAD", mode in (True, "again"))
         monkeypatch.setattr(units.lib, "usc_spconv_wgrad_group", counting)
         model.load_state_dict(state)
         for p in model.parameters():
@@ -1758,11 +1765,15 @@ def test_deferred_weight_gradients_equal_the_immediate_ones(device, monkeypatch)
         (out.F.square().mean() + sum(f.F.square().mean() for f in fmaps[:-1])).backward()
         assert all(not q.items for q in units._WGQ.values())
         res[mode] = {n: p.grad.clone() for n, p in model.named_parameters() if not n.startswith("final.")}
+    units.set_lane_max_rows(lane_rows)
     assert len(calls) >= 4 and max(calls) >= 5, calls                 # grouped launches really happened
-    worst = max((rel_err(res[True][n], res[False][n]), n) for n in res[False])
-    assert worst[0] < 1e-5, worst
+    for mode in (True, "lane"):
+        worst = max((rel_err(res[mode][n], res[False][n]), n) for n in res[False])
+        assert worst[0] < 1e-5, (mode, worst)
     for n in res[True]:
         assert torch.equal(res[True][n], res["again"][n]), n
+        # weight gradients queued on the lane stream (units.py: joined at the end of the backward pass): same bits twice
+        assert torch.equal(res["lane"][n], res["lane again"][n]), n
 
 
 @pytest.mark.parametrize("unique", [True, False])

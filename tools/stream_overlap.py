@@ -67,7 +67,7 @@ for q, rs in sorted(byq.items(), key=lambda kv: -len(kv[1])):
     ov = overlap(u, main_u) if q != main_q else 0
     print(f"queue {q}: {len(rs) / n_steps:7.1f} launches/step, busy {busy / 1e6 / n_steps:6.3f} ms/step, "
           f"of which beside a compute-queue kernel {ov / 1e6 / n_steps:6.3f} ms")
-    if q != main_q:
+    if True:
         c, t = Counter(), Counter()
         for s, e, name, _ in rs:
             c[name[:70]] += 1

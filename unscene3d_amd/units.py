@@ -30,11 +30,14 @@ ENABLED = os.environ.get("USC3D_NATIVE_UNITS", "1") == "1"
 FORK_WGRAD = os.environ.get("USC3D_FORK_WGRAD", "0") == "1"
 # The weight-gradient lane (usc_set_wgrad_lane): weight gradients of maps up to LANE_MAX_ROWS rows are queued on a second
 # stream and joined ONCE, at the end of the backward pass (and before a gradient bucket goes to a collective) — the
-# input-gradient chain is not held up by them.  0 rows = off, the default: measured on the bench scene (same box,
-# alternating runs) 26.28 ms per step without the lane, 26.73 / 26.91 / 26.95 / 27.13 / 27.22 ms with the bound at
-# 3 000 / 10 000 / 24 576 / 50 000 / all rows — the step is bound by the device's one chain of dependent launches, and
-# a second queue competing for the CUs (plus one event record per convolution on the chain) lengthens it.
-LANE_MAX_ROWS = int(os.environ.get("USC3D_WGRAD_LANE_MAX_ROWS", "0"))
+# input-gradient chain is not held up by them.  On for every map since round 5 (USC3D_WGRAD_LANE_MAX_ROWS=0 switches it
+# off).  History worth keeping: rounds 3-4 measured the lane 0.4-0.9 ms per step SLOWER at every row bound and concluded
+# that a second queue only competes with the chain; the lane's stream was a plain torch.cuda.Stream() then, and HIP had
+# put it on the compute stream's hardware queue (streams.py) — all of the event traffic, none of the overlap.  On a stream
+# measured to run beside the compute stream: 25.2 ms per step without the lane, 25.35 / 24.97 / 24.40 / 24.2 ms with the
+# bound at 3 000 / 10 000 / 50 000 / all rows (bench scene, same box, alternating runs; loss bits equal up to 50 000 rows,
+# above that the finest level's three 96 -> 96 gradients are no longer one grouped grid and sum in another order).
+LANE_MAX_ROWS = int(os.environ.get("USC3D_WGRAD_LANE_MAX_ROWS", str(1 << 40)))
 LANE_WS_BYTES = 192 << 20
 SAME, DOWN, UP = 0, 1, 2
 # Grouped weight gradients (usc_spconv_wgrad_group): the stride-1 convolutions of one level's residual blocks have the
@@ -64,7 +67,10 @@ def _lane_stream(device):
             raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
         return torch.cuda.ExternalStream(raw.value, device=device)
     pr = os.environ.get("USC3D_LANE_PRIORITY")
-    return torch.cuda.Stream(device=device, priority=int(pr)) if pr is not None else torch.cuda.Stream(device=device)
+    if pr is not None:
+        return torch.cuda.Stream(device=device, priority=int(pr))
+    from . import streams           # a stream measured to run beside the compute stream (streams.py)
+    return streams.pick(device, "wgrad-lane", high_priority_first=False)
 
 
 def _lane(device):
@@ -79,6 +85,20 @@ def _lane(device):
         else:
             _LANE[key] = None
     return _LANE[key]
+
+
+def set_lane_max_rows(max_rows: int):
+    """Switch the lane's row bound at run time (0 = off): tests and A/B runs.  Joins and drops the current lanes; the
+    next backward builds them again."""
+    global LANE_MAX_ROWS
+    for key, ent in list(_LANE.items()):
+        if ent is not None:
+            with torch.cuda.device(key):
+                join_lane()
+                torch.cuda.synchronize()
+                check(lib.usc_set_wgrad_lane(None, None, 0, 0), "usc_set_wgrad_lane")
+    _LANE.clear()
+    LANE_MAX_ROWS = int(max_rows)
 
 
 def join_lane(device=None):
