@@ -1,8 +1,8 @@
 """Bit-reproducibility of the training step under load (round-2 verdict: two-rank runs with captured graphs once ended
 5-6 ulp apart on a shared device and the multirank test's tolerance was loosened instead of root-caused).
 
-Harness: tests/stress/step_probe.py (forward + criterion + backward of one fixed batch, every gradient word compared)
-and tests/stress/trajectory_probe.py (two ranks, every trial = four full steps from one restored initial state:
+Harness: tools/stress/step_probe.py (forward + criterion + backward of one fixed batch, every gradient word compared)
+and tools/stress/trajectory_probe.py (two ranks, every trial = four full steps from one restored initial state:
 loss bits and reduced-gradient checksums of every step compared), both optionally next to extra training processes on
 the same device.  What they established: 5 configurations x 119 single-process iterations and
 5 x 59 x 2 two-rank trajectories — graphs, prefetch stream, bucketed and single all-reduce, 0-2 competing processes —
@@ -40,7 +40,7 @@ def _torchrun(script_args, port, env_extra=None, timeout=900):
 def test_single_process_step_is_bit_reproducible_under_load():
     """40 repetitions of forward + criterion + backward (captured decoder passes, prefetch stream) while a second
     training process hammers the same device: every gradient word equal to the first repetition's."""
-    cmd = [sys.executable, os.path.join(ROOT, "tests", "stress", "step_probe.py"), "--iters", "40", "--graphs",
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "stress", "step_probe.py"), "--iters", "40", "--graphs",
            "--prefetch", "--load", "1"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
@@ -52,7 +52,7 @@ def test_single_process_step_is_bit_reproducible_under_load():
 def test_two_rank_trajectories_are_bit_reproducible_under_load(overlap):
     """Two ranks (RCCL on a multi-GPU box, else gloo on the shared device), 16 trials of four full steps each from one
     restored state, next to a third training process: loss bits and the reduced gradients of every step identical."""
-    out = _torchrun([os.path.join(ROOT, "tests", "stress", "trajectory_probe.py"), "--trials", "16", "--load", "1"],
+    out = _torchrun([os.path.join(ROOT, "tools", "stress", "trajectory_probe.py"), "--trials", "16", "--load", "1"],
                     _free_port(), {"USC3D_OVERLAP_ALLREDUCE": overlap})
     res = re.findall(r"RESULT rank (\d) .*: (\d+) of (\d+) trials differ", out)
     assert sorted(r[0] for r in res) == ["0", "1"], out[-2000:]

@@ -62,6 +62,19 @@ orig_backward = torch.Tensor.backward
 
 def backward(self, *a, **k):
     mark("bwd0")
+    # the end-of-backward callbacks (lane join, side-stream join) run inside orig_backward: note where the lane is BEFORE
+    # the compute stream waits for it — an engine callback queued first runs first
+    from unscene3d_amd import units
+
+    def note():
+        for key, ent in units._LANE.items():
+            if ent is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(ent[0])
+                marks[-1]["lane_done"] = ev
+        mark("chain_done")
+    torch.autograd.Variable._execution_engine.queue_callback  # (only callable during backward: registered by a hook below)
+    self.register_hook(lambda g: (torch.autograd.Variable._execution_engine.queue_callback(note), None)[1])
     r = orig_backward(self, *a, **k)
     mark("bwd1")
     return r
@@ -78,6 +91,7 @@ torch.cuda.synchronize()
 rows = [("backbone forward", "bb0", "bb1"), ("decoder forward", "bb1", "dec_fwd_done"), ("criterion", "dec_fwd_done", "bwd0"),
         ("criterion + decoder backward", "bwd0", "dec_bwd_done"), ("backbone backward", "dec_bwd_done", "bwd1"),
         ("reduce + optimizer", "bwd1", "t1"), ("step", "t0", "t1"),
+        ("weight-gradient lane done AFTER the compute stream's last backward kernel by", "chain_done", "lane_done"),
         ("key-preparation stream done AFTER the compute stream's decoder backward by", "dec_bwd_done", "side_done")]
 use = marks[args.warmup:]
 for name, a, b in rows:

@@ -40,7 +40,7 @@ def main():
     if a.load and rank == 0:
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
         for _ in range(a.load):
-            kids.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "stress", "step_probe.py"), "--child", "--graphs",
+            kids.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "stress", "step_probe.py"), "--child", "--graphs",
                                           "--prefetch", "--iters", "1000000", "--seconds", "100000", "--voxels", "40000"],
                                          env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL))
     args = bench.parse(["--gpus", str(world), "--voxels", str(a.voxels), "--no-cpu-baseline", "--dist-backend", backend,
