@@ -67,6 +67,16 @@ def _lane_stream(device):
             raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
         return torch.cuda.ExternalStream(raw.value, device=device)
     pr = os.environ.get("USC3D_LANE_PRIORITY")
+    if pr == "low":
+        # HIP's lowest priority (torch offers normal and high only): the chain's kernels win every race for a free CU
+        hip = C.CDLL("libamdhip64.so")
+        lo, hi = C.c_int(), C.c_int()
+        hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi))
+        raw = C.c_void_p()
+        rc = hip.hipStreamCreateWithPriority(C.byref(raw), 1, lo.value)          # 1 = hipStreamNonBlocking
+        if rc != 0 or not raw.value:
+            raise RuntimeError(f"hipStreamCreateWithPriority failed ({rc})")
+        return torch.cuda.ExternalStream(raw.value, device=device)
     if pr is not None:
         return torch.cuda.Stream(device=device, priority=int(pr))
     from . import streams           # a stream measured to run beside the compute stream (streams.py)
