@@ -50,6 +50,8 @@ def parse(argv=None):
     ap.add_argument("--no-prefetch", action="store_true",
                     help="voxelise and build the coordinate maps at the start of the step on the compute stream "
                          "instead of ahead of time on a side stream")
+    ap.add_argument("--prefetch-depth", type=int, default=2, metavar="D",
+                    help="batches the scene prefetcher keeps in flight (the reference's DataLoader: prefetch_factor = 2)")
     ap.add_argument("--prefetch-ahead", type=int, default=0, metavar="N",
                     help="DIAGNOSTIC (not the metric: the collate leaves the timed region): prepare N batches before the "
                          "timed loop and consume them without issuing new ones — the step without the prefetch stream's "
@@ -142,6 +144,17 @@ WORKLOADS = {
 }
 
 
+def _gil_switch_interval():
+    """Two Python threads issue device work here: the step (main thread) and the next scenes' voxelisation + maps (the
+    prefetcher's worker).  CPython hands the interpreter lock over every 5 ms by default — a fifth of the step: the main
+    thread, whose launches the device is waiting for, then sits out whole slices of the worker's bookkeeping.
+    USC3D_GIL_SWITCH_MS (default 0.5) shortens the slice."""
+    import sys
+    ms = float(os.environ.get("USC3D_GIL_SWITCH_MS", "0.5"))
+    if ms > 0:
+        sys.setswitchinterval(ms / 1e3)
+
+
 def make_mask3d_step(args, dev, rank, world):
     """Full self-training step (reference trainer/trainer.py:99-163 + :953-966) on one scene per rank."""
     from unscene3d_amd.config import apply_overrides, default_config
@@ -222,12 +235,19 @@ def make_mask3d_step(args, dev, rank, world):
         prefetch = ScenePrefetcher(collate, add_raw_coordinates=cfg.data.add_raw_coordinates, device=dev,
                                    precompute=module.model.precompute_geometry,
                                    threaded=os.environ.get("USC3D_PREFETCH_THREAD", "1") == "1")
-        prefetch.submit(sets[0])       # the first batch, outside the timed region like the resident raw arrays
+        # the first batches, outside the timed region like the resident raw arrays.  Two in flight (the reference's
+        # DataLoader default, prefetch_factor = 2): with one, every step began by waiting ~8 ms for the worker thread to
+        # finish issuing the batch submitted a moment earlier — host time the 24 ms device step no longer hides
+        depth = max(1, getattr(args, "prefetch_depth", 2))
+        for j in range(depth):
+            prefetch.submit(sets[j % n_sets])
+    _gil_switch_interval()
     state = {"k": 0, "marks": None}
     ahead = []
     if prefetch is not None and getattr(args, "prefetch_ahead", 0) > 0:
         from unscene3d_amd.datasets.prefetch import _record_streams
-        prefetch.take()
+        while prefetch.in_flight:
+            prefetch.take()
         ahead = [prefetch._issue(sets[k % n_sets]) for k in range(args.prefetch_ahead)]
         torch.cuda.synchronize()
 
@@ -262,7 +282,8 @@ def make_mask3d_step(args, dev, rank, world):
         opt.step()
         state["sched"].step()
         if prefetch is not None and not ahead and not getattr(args, "prefetch_ahead", 0):
-            prefetch.submit(sets[state["k"] % n_sets])      # the next step's voxelisation + coordinate maps, on a side stream under backward
+            # the voxelisation + coordinate maps of the step after the next (depth 2), on the prefetch stream
+            prefetch.submit(sets[(state["k"] + max(1, getattr(args, "prefetch_depth", 2)) - 1) % n_sets])
         return total.detach(), batch[0].coordinates.shape[0]
 
     state["sched"] = sched
@@ -271,11 +292,14 @@ def make_mask3d_step(args, dev, rank, world):
         re-issue the prefetched batch in the new order."""
         collate.spatial_sort = int(shift) if shift else False
         if prefetch is not None:
-            prefetch.take()
-            prefetch.submit(sets[state["k"] % n_sets])
+            while prefetch.in_flight:
+                prefetch.take()
+            for j in range(max(1, getattr(args, "prefetch_depth", 2))):
+                prefetch.submit(sets[(state["k"] + j) % n_sets])
 
     step.set_spatial_sort = set_spatial_sort
     step.close = (lambda: prefetch.close()) if prefetch is not None else (lambda: None)
+    step.prefetch = prefetch
     step.scenes_per_rank = B
     step.skew_info = skew_info
     step.state = state
@@ -315,6 +339,17 @@ def _committed_traffic(kernel):
         if shas.get(fn) != have:
             return {"traffic": None, "traffic_source": f"stale: {fn} changed since profiles/pmc_traffic.json was measured"}
     return {"traffic": ent["bytes_per_launch"], "traffic_source": "profiles/pmc_traffic.json (source hashes match)"}
+
+
+def _stream_report():
+    """What unscene3d_amd/streams.py measured when it picked the prefetch / lane / key-preparation streams (two HIP streams
+    may share a hardware queue; `shared_queue: true` = no candidate overlapped with the compute stream)."""
+    try:
+        from unscene3d_amd import streams
+        return [{"role": r["role"], "shared_queue": r["shared_queue"], "tried": len(r["tried"]),
+                 "ratios": r["tried"][-1]["ratios"] if r["tried"] else None} for r in streams.REPORT]
+    except Exception as err:      # noqa: BLE001 — a report, never a reason to lose the bench line
+        return str(err)
 
 
 def _allreduce_note(step, world):
@@ -809,10 +844,12 @@ def main():
     spr = getattr(step, "scenes_per_rank", 1)
     rot = None
     if marks:
-        per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+        per_in_order = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)]
+        per = sorted(per_in_order)
         q = lambda f: per[min(len(per) - 1, int(round(f * (len(per) - 1))))]
         rot = {"rotated_scene_sets": args.rotate, "rotate_spread": args.rotate_spread, "step_ms_p10": q(0.1), "step_ms_p50": q(0.5), "step_ms_p90": q(0.9),
-               "step_ms_min": per[0], "step_ms_max": per[-1]}
+               "step_ms_min": per[0], "step_ms_max": per[-1],
+               "step_ms_max_at": int(max(range(args.steps), key=lambda k: per_in_order[k]))}
     skew = None
     if own_marks is not None and len(own_marks) == args.steps:
         # per-rank step-time skew: how long each rank's OWN work of a step took (step start -> backward queued, device
@@ -839,6 +876,7 @@ def main():
                                                                    (f"; z-order cells of {2 ** args.zorder_shift}^3 voxels (value_zorder)"
                                                                     if ref_order else "")), **(rot or {}), **({"rank_skew": skew} if skew else {}),
                        "loss": float(loss), "grad_allreduce": _allreduce_note(step, world),
+                       "streams": _stream_report(),
                        **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),

@@ -82,19 +82,53 @@ def backward(self, *a, **k):
 
 torch.Tensor.backward = backward
 n = args.steps + args.warmup
+import time  # noqa: E402
+htimes = []          # per step: {call name: host ms}
+
+
+def timed_call(obj, name, label):
+    orig = getattr(obj, name)
+
+    def wrapper(*a, **k):
+        t = time.perf_counter()
+        try:
+            return orig(*a, **k)
+        finally:
+            htimes[-1][label] = htimes[-1].get(label, 0.0) + (time.perf_counter() - t) * 1e3
+    setattr(obj, name, wrapper)
+
+
+timed_call(step.module, "training_step", "training_step (forward + criterion)")
+timed_call(torch.Tensor, "backward", "backward")
+timed_call(step.opt, "step", "optimizer")
+if step.prefetch is not None:
+    timed_call(step.prefetch, "take", "prefetch.take (waits for the worker thread to have issued the batch)")
+    timed_call(step.prefetch, "submit", "prefetch.submit")
+    timed_call(step.prefetch, "_issue", "worker thread: issuing the next batch (overlaps the main thread)")
+host = []
 for i in range(n):
+    if i == args.warmup:
+        torch.cuda.synchronize()      # like bench.py in front of its timed loop: the first step after it starts on an idle device
     marks.append({})
+    htimes.append({})
     mark("t0")
+    h0 = time.perf_counter()
     step(1)
+    host.append((time.perf_counter() - h0) * 1e3)
     mark("t1")
 torch.cuda.synchronize()
+print(f"host time to issue a step: first after the synchronize {host[args.warmup]:.2f} ms, others {sum(host[args.warmup + 1:]) / max(1, n - args.warmup - 1):.2f} ms")
 rows = [("backbone forward", "bb0", "bb1"), ("decoder forward", "bb1", "dec_fwd_done"), ("criterion", "dec_fwd_done", "bwd0"),
         ("criterion + decoder backward", "bwd0", "dec_bwd_done"), ("backbone backward", "dec_bwd_done", "bwd1"),
         ("reduce + optimizer", "bwd1", "t1"), ("step", "t0", "t1"),
         ("weight-gradient lane done AFTER the compute stream's last backward kernel by", "chain_done", "lane_done"),
         ("key-preparation stream done AFTER the compute stream's decoder backward by", "dec_bwd_done", "side_done")]
-use = marks[args.warmup:]
+for label in htimes[args.warmup]:
+    rest = [h.get(label, 0.0) for h in htimes[args.warmup + 1:]]
+    print(f"   host: {label}: first {htimes[args.warmup][label]:.2f} ms, others {sum(rest) / max(1, len(rest)):.2f} ms")
+first, use = marks[args.warmup], marks[args.warmup + 1:]
 for name, a, b in rows:
     v = [m[a].elapsed_time(m[b]) for m in use if a in m and b in m]
-    print(f"{sum(v) / max(1, len(v)):8.3f} ms  {name}")
+    f = first[a].elapsed_time(first[b]) if a in first and b in first else float("nan")
+    print(f"{sum(v) / max(1, len(v)):8.3f} ms  {name}   (first step after the synchronize: {f:.3f})")
 step.close()

@@ -20,7 +20,7 @@ print("high-priority pool stream i vs the null: ", [round(streams.overlap_ratio(
 print("normal 0 vs normal i:                     ", [round(streams.overlap_ratio(normal[0], s), 2) for s in normal[1:]])
 print("high 0 vs high i:                         ", [round(streams.overlap_ratio(high[0], s), 2) for s in high[1:]])
 print("normal 0 vs high i:                       ", [round(streams.overlap_ratio(normal[0], s), 2) for s in high])
-a = streams.pick(dev, "prefetch", high_priority_first=False)
+a = streams.pick(dev, "prefetch")
 b = streams.pick(dev, "keys")
 for r in streams.REPORT:
     print(r)

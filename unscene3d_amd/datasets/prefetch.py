@@ -54,7 +54,8 @@ def _record_streams(obj, stream, seen):
 
 class ScenePrefetcher:
     """prefetch = ScenePrefetcher(collate, add_raw_coordinates, n_down);  prefetch.submit(samples) issues the work for
-    the next batch; prefetch.take() -> (data, target, names) with `data.sparse_tensor` (maps prepared) and
+    the next batch (several may be in flight: take() returns them in submission order — the reference's DataLoader
+    keeps prefetch_factor = 2 batches per worker ahead); prefetch.take() -> (data, target, names) with `data.sparse_tensor` (maps prepared) and
     `data.raw_coordinates` attached, ready for `InstanceSegmentation.training_step`."""
 
     def __init__(self, collate, add_raw_coordinates: bool = True, n_down: int = 4, ksize: int = 3, device="cuda",
@@ -75,8 +76,8 @@ class ScenePrefetcher:
         self.device = torch.device(device)
         # a stream measured to run beside the compute stream (streams.py: two HIP streams may share a hardware queue)
         from .. import streams
-        self.side = streams.pick(self.device, "prefetch", high_priority_first=False)
-        self._pending = None
+        self.side = streams.pick(self.device, "prefetch")
+        self._pending = collections.deque()        # batches submitted and not yet taken, oldest first
         self._keep = collections.deque(maxlen=2)
         self._jobs = self._worker = None
         if threaded:
@@ -119,9 +120,13 @@ class ScenePrefetcher:
         if self._worker is not None:
             box = {"done": threading.Event()}
             self._jobs.put((samples, box, gate))
-            self._pending = box
+            self._pending.append(box)
             return
-        self._pending = self._issue(samples, gate)
+        self._pending.append(self._issue(samples, gate))
+
+    @property
+    def in_flight(self) -> int:
+        return len(self._pending)
 
     def _issue(self, samples, gate=None):
         with torch.cuda.stream(self.side):
@@ -144,9 +149,9 @@ class ScenePrefetcher:
         return (data, target, names), done
 
     def take(self):
-        if self._pending is None:
+        if not self._pending:
             raise RuntimeError("ScenePrefetcher.take() without a submit()")
-        pending, self._pending = self._pending, None
+        pending = self._pending.popleft()
         if isinstance(pending, dict):                        # issued by the worker thread
             pending["done"].wait()
             if "error" in pending:

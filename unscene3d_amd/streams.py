@@ -6,8 +6,13 @@ stream the least-used queue.  torch draws its streams from a pool of 32 per prio
 strictly one kernel after the other, however independent their work (measured here: a key-preparation stream that happened
 to share the compute stream's queue made the step 0.35 ms SLOWER — all of the cross-stream waits, none of the overlap).
 `pick()` therefore measures: it times pairs of spinning launches (usc_spin) on a candidate and on every stream the
-candidate has to run beside, and returns the first candidate that overlaps with all of them.  High-priority candidates
-come first: their queues are a separate set, which the null stream (torch's default compute stream) never shares.
+candidate has to run beside, and returns the first candidate that overlaps with all of them.
+
+NEVER a high-priority stream.  Their queues are a separate set that the null stream cannot share, which made them the
+obvious first candidates — and with ONE high-priority stream in use (the decoder's key preparation, a few small launches
+per pass) every kernel on the normal-priority queues ran 2-5x slower: 63.8 ms per step instead of 24.3, backbone forward
+14.9 instead of 6.4 ms, decoder forward 11.7 instead of 2.3 (tools/ab_r05j.sh; `profiles/r05_stream_priority.txt`).  The
+first version of this probe only escaped it because first-use noise made it reject the high-priority candidate.
 
 No reference counterpart (the reference is single-stream PyTorch); used by datasets/prefetch.py and models/mask3d.py.
 """
@@ -20,33 +25,39 @@ import torch
 
 from ._lib import check, lib
 
-SPIN_US = 40
+SPIN_US = 60
 SPIN_N = 8
+_REPS = 4
 _PICKED = {}          # (device index, role) -> stream
 REPORT = []           # one dict per pick(): what was measured (tools/stream_queue_probe.py prints it)
 
 
-def overlap_ratio(a: torch.cuda.Stream, b: torch.cuda.Stream, us: int = SPIN_US, n: int = SPIN_N) -> float:
-    """wall time of n spins on a AND n on b (issued alternately) / n spins on a alone: ~1 when the two streams run
-    beside each other, ~2 when they share a hardware queue.  Synchronises the device."""
+def overlap_ratio(a: torch.cuda.Stream, b: torch.cuda.Stream, us: int = SPIN_US, n: int = SPIN_N, reps: int = _REPS) -> float:
+    """device time of n spins on stream a while n more are issued on b (alternately) / n spins on a alone: ~1 when the
+    two streams run beside each other, ~2 when they share a hardware queue.  Timed with events on a (host jitter cannot
+    shorten it) and the MINIMUM of `reps` repetitions of each form is used: a repetition can only be measured too long (a
+    preempted host thread, a busy device), never too short.  Synchronises the device."""
     def run(second):
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(a)
         for _ in range(n):
             check(lib.usc_spin(us, 1, a.cuda_stream), "usc_spin")
             if second is not None:
                 check(lib.usc_spin(us, 1, second.cuda_stream), "usc_spin")
+        e1.record(a)
         torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        return e0.elapsed_time(e1)
     run(b)                                   # first use of a stream binds its queue: not timed
-    one = min(run(None) for _ in range(2))
-    two = min(run(b) for _ in range(2))
+    one = min(run(None) for _ in range(reps))
+    two = min(run(b) for _ in range(reps))
     return two / one
 
 
-def pick(device, role: str, beside=(), high_priority_first: bool = True, max_candidates: int = 6) -> torch.cuda.Stream:
-    """A stream for `role` on `device` that overlaps with the device's default stream and with every stream in `beside`
-    (cached per (device, role)).  Falls back to the best candidate seen, noted in REPORT, when none overlaps with all."""
+def pick(device, role: str, beside=(), max_candidates: int = 8) -> torch.cuda.Stream:
+    """A stream for `role` on `device` that overlaps with the device's default stream, with every stream in `beside` and
+    with the streams picked for other roles (cached per (device, role)).  Falls back to the best candidate seen, noted in
+    REPORT, when none overlaps with all.  Candidates are NORMAL-priority streams only (see the module docstring)."""
     device = torch.device(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, role)
@@ -59,15 +70,14 @@ def pick(device, role: str, beside=(), high_priority_first: bool = True, max_can
     with torch.cuda.device(idx):
         others = [torch.cuda.default_stream(idx)] + [s for s in beside if s is not None] \
             + [s for (d, r), s in _PICKED.items() if d == idx and r != role]
-        prios = ([-1] if high_priority_first else []) + [0] * max_candidates + ([] if high_priority_first else [-1])
         best, best_worst, tried = None, 1e9, []
-        for pr in prios:
-            cand = torch.cuda.Stream(device=device, priority=pr)
+        for _ in range(max_candidates):
+            cand = torch.cuda.Stream(device=device)
             if any(cand.cuda_stream == o.cuda_stream for o in others):
                 continue
             ratios = [overlap_ratio(o, cand) for o in others]
             worst = max(ratios)
-            tried.append({"priority": pr, "ratios": [round(r, 2) for r in ratios]})
+            tried.append({"ratios": [round(r, 2) for r in ratios]})
             if worst < best_worst:
                 best, best_worst = cand, worst
             if worst < 1.35:

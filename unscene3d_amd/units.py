@@ -80,7 +80,7 @@ def _lane_stream(device):
     if pr is not None:
         return torch.cuda.Stream(device=device, priority=int(pr))
     from . import streams           # a stream measured to run beside the compute stream (streams.py)
-    return streams.pick(device, "wgrad-lane", high_priority_first=False)
+    return streams.pick(device, "wgrad-lane")
 
 
 def _lane(device):
