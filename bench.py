@@ -727,6 +727,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.dist_backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
+        if world > torch.cuda.device_count():
+            # ranks SHARE a device (a code-path check on a one-GPU box, never a deployment): two processes with four
+            # streams each on one device degenerate — 1.5-6 s per step, 100 ms with the lane or the key-preparation
+            # stream off (tools/ab_r05k.sh; the queues of different processes are time-sliced) — so the shared-device run
+            # keeps the second streams off unless the caller set the switches
+            os.environ.setdefault("USC3D_WGRAD_LANE_MAX_ROWS", "0")
+            os.environ.setdefault("USC3D_KV_SIDE_STREAM", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

@@ -22,8 +22,9 @@ def _backend():
     return "nccl" if torch.cuda.device_count() >= 2 else "gloo"
 
 
-def _run(overlap, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", USC3D_OVERLAP_ALLREDUCE=overlap)
+def _run(overlap, port, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", USC3D_OVERLAP_ALLREDUCE=overlap,
+               **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--voxels", "40000", "--dist-backend", _backend(), "--no-cpu-baseline", "--rotate", "0"]
@@ -46,6 +47,18 @@ def test_overlapped_gradient_allreduce_equals_the_single_one():
     note = a["config"]["grad_allreduce"]
     assert "buckets" in note and int(note.split(", ")[1].split()[0]) >= 1, note
     assert b["config"]["grad_allreduce"] == "one flat buffer after backward"
+
+
+def test_second_streams_under_the_gradient_exchange():
+    """The weight-gradient lane and the decoder's key-preparation stream write parameter gradients on streams of their
+    own; a bucket's collective must start behind them (ddp.BucketedGradReducer._launch: lane join, side-stream join, and a
+    report that arrives ON the side stream only counts).  With both streams on, overlapped buckets and one all-reduce
+    after backward give the same loss to the bit.  (On a one-GPU box bench.py keeps the second streams off for ranks that
+    share a device — two processes with four streams each on one device take seconds per step; forced on here.)"""
+    on = {"USC3D_WGRAD_LANE_MAX_ROWS": str(1 << 40), "USC3D_KV_SIDE_STREAM": "1"}
+    a, b = _run("1", _free_port(), **on), _run("0", _free_port(), **on)
+    assert a["config"]["loss"] == b["config"]["loss"], (a["config"]["loss"], b["config"]["loss"])
+    assert {r["role"] for r in a["config"]["streams"]} >= {"wgrad-lane", "keys"}, a["config"]["streams"]
 
 
 def test_bench_two_ranks():

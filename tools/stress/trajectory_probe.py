@@ -31,6 +31,9 @@ def main():
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    if backend == "gloo":      # ranks share a device: keep the second streams off like bench.py does (see there)
+        os.environ.setdefault("USC3D_WGRAD_LANE_MAX_ROWS", "0")
+        os.environ.setdefault("USC3D_KV_SIDE_STREAM", "0")
     local = rank % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
