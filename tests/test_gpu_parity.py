@@ -1661,6 +1661,125 @@ def test_sample_keys_equals_the_reference_steps(device, n_scenes, K, sizes):
         assert not m[b, :n_valid[b], 3].any() and m[b, n_valid[b]:, 3].all()
 
 
+def test_sample_keys_partial_calls_equal_the_full_call(device):
+    """usc_sample_keys with only the feature rows (one launch, what the decoder's key-preparation stream issues) and with
+    only the mask rows (what stays on the query chain) == the corresponding outputs of the full call, bit for bit,
+    incl. the all-masked-query rule, the padding mask and the feature gradient."""
+    from unscene3d_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    n_scenes, K, sizes, Q, C, P = 2, 200, [150, 900], 100, 96, 128
+    n = sum(sizes)
+    feats, pos = torch.randn(n, C, generator=g), torch.randn(n, P, generator=g)
+    mask = torch.rand(n, Q, generator=g) < 0.5
+    mask[:, 7] = True
+    idx = [torch.cat([torch.arange(150), torch.zeros(50, dtype=torch.int64)]), torch.randperm(900, generator=g)[:K] + 150]
+    gidx, n_valid = _dev(torch.cat(idx), device), [150, 200]
+    fd = _dev(feats, device).requires_grad_()
+    a, m, p_ = ops.sample_keys(fd, _dev(mask, device), _dev(pos, device), gidx, n_scenes, K, n_valid, valid_unique=True)
+    dy = _dev(torch.randn(n_scenes, K, C, generator=g), device)
+    a.backward(dy)
+    g_full, fd.grad = fd.grad.clone(), None
+    a2 = ops.sample_keys(fd, None, None, gidx, n_scenes, K, n_valid, valid_unique=True)
+    assert isinstance(a2, torch.Tensor) and torch.equal(a2, a)
+    a2.backward(dy)
+    assert torch.equal(fd.grad, g_full)
+    buf = torch.empty(n_scenes, K, Q, dtype=torch.bool, device=device)
+    m2 = ops.sample_keys(None, _dev(mask, device), None, gidx, n_scenes, K, n_valid, outs=(None, buf, None))
+    assert torch.equal(m2, m) and m2.data_ptr() == buf.data_ptr() and not m2.requires_grad
+    ap, pp = ops.sample_keys(fd, None, _dev(pos, device), gidx, n_scenes, K, n_valid, valid_unique=True)
+    assert torch.equal(ap, a) and torch.equal(pp, p_)
+    with pytest.raises(RuntimeError, match="nothing to gather"):
+        ops.sample_keys(None, None, None, gidx, n_scenes, K, n_valid)
+
+
+@pytest.mark.parametrize("rows_kv", [200, 3200])
+def test_split_input_projection_equals_the_packed_one(device, rows_kv):
+    """ops.in_proj_q + ops.in_proj_kv (the query third on the query chain, the key / value thirds over the sampled voxels
+    on the key-preparation stream; reference models/mask3d.py:547-605 through nn.MultiheadAttention's packed in_proj)
+    == F.linear on the row blocks of the SAME packed parameters: outputs, input gradients, the residual pass-through,
+    and ONE [3E, E] weight gradient / [3E] bias gradient — returned through autograd and written in place into p.grad.
+    200 rows: the few-row kernels with the positional add folded in; 3 200: the many-row kernels."""
+    from unscene3d_amd import ops
+
+    E, L, B = 128, 100, 1
+    g = torch.Generator().manual_seed(rows_kv)
+    W, b = torch.randn(3 * E, E, generator=g) * 0.05, torch.randn(3 * E, generator=g) * 0.1
+    xq, pq = torch.randn(L, B, E, generator=g), torch.randn(L, B, E, generator=g)
+    xk, pk = torch.randn(rows_kv, B, E, generator=g), torch.randn(rows_kv, B, E, generator=g)
+    dq, dk, dv = torch.randn(L, B, E, generator=g), torch.randn(rows_kv, B, E, generator=g), torch.randn(rows_kv, B, E, generator=g)
+    dres = torch.randn(L, B, E, generator=g)
+    # reference on the CPU in f64
+    Wr, br = W.double().requires_grad_(), b.double().requires_grad_()
+    xqr, xkr = xq.double().requires_grad_(), xk.double().requires_grad_()
+    F = torch.nn.functional
+    q = F.linear(xqr + pq.double(), Wr[:E], br[:E])
+    k = F.linear(xkr + pk.double(), Wr[E:2 * E], br[E:2 * E])
+    v = F.linear(xkr, Wr[2 * E:], br[2 * E:])
+    ((q * dq.double()).sum() + (xqr * dres.double()).sum() + (k * dk.double()).sum() + (v * dv.double()).sum()).backward()
+    for in_place in (False, True):
+        Wd, bd = torch.nn.Parameter(_dev(W, device)), torch.nn.Parameter(_dev(b, device))
+        if in_place:
+            Wd.grad, bd.grad = torch.zeros_like(Wd), torch.zeros_like(bd)
+        xqd, xkd = _dev(xq, device).requires_grad_(), _dev(xk, device).requires_grad_()
+        kbuf, vbuf = torch.empty(rows_kv, B, E, device=device), torch.empty(rows_kv, B, E, device=device)
+        qd, res = ops.in_proj_q(xqd, Wd, bd, pos=_dev(pq, device), residual=True)
+        kd, vd = ops.in_proj_kv(xkd, Wd, bd, pos=_dev(pk, device), outs=(kbuf, vbuf) if in_place else None)
+        if in_place:
+            assert kd.data_ptr() == kbuf.data_ptr() and vd.data_ptr() == vbuf.data_ptr()
+        assert rel_err(qd, q) < 1e-5 and rel_err(kd, k) < 1e-5 and rel_err(vd, v) < 1e-5
+        ((qd * _dev(dq, device)).sum() + (res * _dev(dres, device)).sum() + (kd * _dev(dk, device)).sum()
+         + (vd * _dev(dv, device)).sum()).backward()
+        assert rel_err(xqd.grad, xqr.grad) < 1e-5 and rel_err(xkd.grad, xkr.grad) < 1e-5
+        assert Wd.grad.shape == (3 * E, E) and rel_err(Wd.grad, Wr.grad) < 1e-5 and rel_err(bd.grad, br.grad) < 1e-5
+    with pytest.raises(RuntimeError, match="must have the shape"):
+        ops.in_proj_kv(xkd, Wd, bd, pos=_dev(pk[:, :, :64], device))
+
+
+def test_picked_streams_run_beside_the_compute_stream(device):
+    """unscene3d_amd.streams: two HIP streams may share a hardware queue (then they execute one kernel after the other).
+    overlap_ratio measures it with usc_spin launches; pick() returns a NORMAL-priority stream whose ratio against the
+    default stream and against every stream picked for another role is ~1, caches it per role, and reports what it
+    measured.  A stream against itself is the one case that must read ~2."""
+    from unscene3d_amd import streams
+
+    dev = torch.device(device)
+    a = streams.pick(dev, "test-role-a")
+    b = streams.pick(dev, "test-role-b")
+    assert streams.pick(dev, "test-role-a") is a and a.cuda_stream != b.cuda_stream
+    assert a.priority == 0 and b.priority == 0                      # never a high-priority stream (DESIGN.md §3.13)
+    default = torch.cuda.default_stream(dev)
+    assert streams.overlap_ratio(default, a) < 1.35 and streams.overlap_ratio(a, b) < 1.35
+    assert streams.overlap_ratio(a, a) > 1.7
+    rep = [r for r in streams.REPORT if r["role"] in ("test-role-a", "test-role-b")]
+    assert len(rep) == 2 and not any(r["shared_queue"] for r in rep) and all(r["tried"] for r in rep)
+    for role in ("test-role-a", "test-role-b"):
+        streams._PICKED.pop((dev.index if dev.index is not None else torch.cuda.current_device(), role), None)
+
+
+def test_scene_prefetcher_keeps_batches_in_submission_order(device):
+    """ScenePrefetcher with two batches in flight (the reference's DataLoader: prefetch_factor = 2): take() hands them
+    back in submission order, from the worker thread and inline, and a take() without a submit() raises."""
+    from unscene3d_amd.datasets.prefetch import ScenePrefetcher
+    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+
+    ds = SyntheticFreeMaskDataset(n_scenes=3, target_voxels=6000, seed=77)
+    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=str(device))
+    for threaded in (True, False):
+        pf = ScenePrefetcher(collate, device=device, threaded=threaded)
+        want = []
+        for i in range(3):
+            pf.submit([ds[i]])
+            want.append(collate([ds[i]])[0].coordinates.shape[0])
+        assert pf.in_flight == 3
+        got = [pf.take()[0].coordinates.shape[0] for _ in range(3)]
+        assert got == want and len(set(want)) == 3, (got, want)
+        with pytest.raises(RuntimeError, match="without a submit"):
+            pf.take()
+        pf.close()
+
+
 @pytest.mark.parametrize("c", [96, 128, 19])
 def test_gather_rows_backward_unique_and_atomic_paths_agree(device, c):
     """The backward of a row gather: plain stores for an index set without duplicates (`unique=True`: the decoder's
