@@ -254,7 +254,7 @@ def make_mask3d_step(args, dev, rank, world):
     def step(w):
         state["k"] += 1
         if ahead:
-            batch, done = ahead.pop(0)
+            batch, done, _ = ahead.pop(0)
             torch.cuda.current_stream().wait_event(done)
             _record_streams(batch, torch.cuda.current_stream(), set())
         elif prefetch is not None:

@@ -77,6 +77,7 @@ class ScenePrefetcher:
         # a stream measured to run beside the compute stream (streams.py: two HIP streams may share a hardware queue)
         from .. import streams
         self.side = streams.pick(self.device, "prefetch")
+        self.consumer = torch.cuda.default_stream(self.device)      # the stream take() is normally called on
         self._pending = collections.deque()        # batches submitted and not yet taken, oldest first
         self._keep = collections.deque(maxlen=2)
         self._jobs = self._worker = None
@@ -146,7 +147,12 @@ class ScenePrefetcher:
             data.sparse_tensor, data.raw_coordinates = x, raw
             done = torch.cuda.Event()
             done.record(self.side)
-        return (data, target, names), done
+        batch = (data, target, names)
+        # the allocator must know that the consumer's stream reads these tensors too; done HERE (on the worker thread when
+        # there is one: the walk over ~1 800 objects is 1 ms of the step's host time) for the stream the consumer normally
+        # is; take() repeats it only for another stream
+        _record_streams(batch, self.consumer, set())
+        return batch, done, self.consumer.cuda_stream
 
     def take(self):
         if not self._pending:
@@ -157,9 +163,10 @@ class ScenePrefetcher:
             if "error" in pending:
                 raise pending["error"]
             pending = pending["result"]
-        batch, done = pending
+        batch, done, recorded = pending
         main = torch.cuda.current_stream(self.device)
         main.wait_event(done)
-        _record_streams(batch, main, set())
+        if main.cuda_stream != recorded:
+            _record_streams(batch, main, set())
         self._keep.append(batch)
         return batch
