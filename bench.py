@@ -606,9 +606,14 @@ def run_ncut(args, dev):
         "config": {"workload": "BASELINE.json configs[4]: iterative masked NCut (affinity + generalized Fiedler vector, "
                                f"20 iterations) on one synthetic {S}-segment scene, DINO-like 384-d + CSC-like 96-d "
                                "segment features", "segments": S, "masks": int(masks.shape[0])},
+        # a chain of S-1 dependent Householder steps, one grid-wide exchange each: neither HBM nor the matrix cores bound it.
+        # What it is priced against is the exchange: the guide's ~4 us for one all-workgroup hand-over (MI355X_MICROARCH.md,
+        # grid barrier 4-7 us) — `frac` = that floor / the measured time per step of the solve (1 = nothing but exchanges)
         "roofline": {"bound": "latency", "kernel": "usc_ncut_fiedler (tridiagonalisation + bisection + inverse iteration)",
-                     "achieved": flops / (eig_ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                     "frac": flops / (eig_ms * 1e-3) / 1e12 / 78.6, "traffic": None, "avg_call_ms": eig_ms},
+                     "chain_steps": S - 1, "us_per_chain_step": 1e3 * eig_ms / max(1, S - 1), "exchange_floor_us": 4.0,
+                     "achieved": 1e3 * eig_ms / max(1, S - 1), "peak": 4.0, "unit": "us per dependent step (lower is better)",
+                     "frac": 4.0 / (1e3 * eig_ms / max(1, S - 1)), "traffic": None, "avg_call_ms": eig_ms,
+                     "f64_gflop_per_call": flops / 1e9},
         "cpu_baseline": cpu,
     }))
 

@@ -38,6 +38,9 @@ enum usc_status {
 const char* usc_last_error(void);
 /* Library/ABI version (bumped on any signature change). */
 int usc_abi_version(void);
+/* What the loaded library was built from: "arch=gfx950; HIP version: ...; built <UTC time>; sources sha256 <16 hex>" (the
+ * hash covers every .hip / .cpp / .h the objects were compiled from).  __graft_entry__.build() and smoke() print it. */
+const char* usc_build_info(void);
 /* Number of visible HIP devices, or a negative usc_status. */
 int usc_device_count(void);
 

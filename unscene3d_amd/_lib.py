@@ -59,6 +59,7 @@ STEP_UNIT_FWD, STEP_UNIT_BWD, STEP_CAT, STEP_SPLIT, STEP_ADD = 0, 1, 2, 3, 4
 SIGNATURES = {
     "usc_last_error": (C.c_char_p, []),
     "usc_abi_version": (C.c_int, []),
+    "usc_build_info": (C.c_char_p, []),
     "usc_device_count": (C.c_int, []),
     "usc_voxel_floor_f64": (C.c_int, [_p, _i64, _f64, _p, _p]),
     "usc_voxel_floor_f64_host": (C.c_int, [_p, _i64, C.c_double, _p]),
