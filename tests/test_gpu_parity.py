@@ -1736,7 +1736,7 @@ def test_split_input_projection_equals_the_packed_one(device, rows_kv):
         ops.in_proj_kv(xkd, Wd, bd, pos=_dev(pk[:, :, :64], device))
 
 
-def test_picked_streams_run_beside_the_compute_stream(device):
+def test_picked_streams_run_beside_the_compute_stream(device, monkeypatch):
     """unscene3d_amd.streams: two HIP streams may share a hardware queue (then they execute one kernel after the other).
     overlap_ratio measures it with usc_spin launches; pick() returns a NORMAL-priority stream whose ratio against the
     default stream and against every stream picked for another role is ~1, caches it per role, and reports what it
@@ -1744,6 +1744,9 @@ def test_picked_streams_run_beside_the_compute_stream(device):
     from unscene3d_amd import streams
 
     dev = torch.device(device)
+    # (a fresh table: the roles other tests of this process picked — prefetch, keys, lane — would have to be avoided too,
+    # and a process has only a handful of hardware queues)
+    monkeypatch.setattr(streams, "_PICKED", {})
     a = streams.pick(dev, "test-role-a")
     b = streams.pick(dev, "test-role-b")
     assert streams.pick(dev, "test-role-a") is a and a.cuda_stream != b.cuda_stream
@@ -1753,8 +1756,6 @@ def test_picked_streams_run_beside_the_compute_stream(device):
     assert streams.overlap_ratio(a, a) > 1.7
     rep = [r for r in streams.REPORT if r["role"] in ("test-role-a", "test-role-b")]
     assert len(rep) == 2 and not any(r["shared_queue"] for r in rep) and all(r["tried"] for r in rep)
-    for role in ("test-role-a", "test-role-b"):
-        streams._PICKED.pop((dev.index if dev.index is not None else torch.cuda.current_device(), role), None)
 
 
 def test_scene_prefetcher_keeps_batches_in_submission_order(device):
