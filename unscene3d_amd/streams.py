@@ -14,6 +14,9 @@ per pass) every kernel on the normal-priority queues ran 2-5x slower: 63.8 ms pe
 14.9 instead of 6.4 ms, decoder forward 11.7 instead of 2.3 (tools/ab_r05j.sh; `profiles/r05_stream_priority.txt`).  The
 first version of this probe only escaped it because first-use noise made it reject the high-priority candidate.
 
+(The same slow mode appears with GPU_MAX_HW_QUEUES=8: 55.8 ms per step.  The default four queues per process are what this
+module works with.)
+
 No reference counterpart (the reference is single-stream PyTorch); used by datasets/prefetch.py and models/mask3d.py.
 """
 from __future__ import annotations
