@@ -343,6 +343,30 @@ int usc_set_side_stream(usc_stream_t side);
  * gradient buffer). */
 int usc_set_wgrad_lane(usc_stream_t lane, void* lane_ws, int64_t lane_ws_bytes, int64_t max_rows);
 int usc_wgrad_lane_join(usc_stream_t s);
+/* Scheduling of the lane against the caller's chain (step program of the backbone's backward pass, which visits the
+ * U-Net stages fine -> coarse -> fine, models/res16unet.py:224-297 in reverse).  mode 1: from now on the weight gradient
+ * of a map with >= hold_min_rows rows is only NOTED; the first backward call on a map with <= release_max_rows rows —
+ * a stage whose launches cannot fill 256 CUs — puts everything noted on the lane behind one event of `s` and ends the
+ * hold (later calls queue at once, as without a hold).  The throughput-bound fine-level weight gradients then run
+ * beside the latency-bound coarse-level chain instead of beside the fine-level input gradients they compete with for
+ * matrix-core issue slots.  mode 0: release what is still noted and end the hold (also done by usc_wgrad_lane_join).
+ * mode -1: forget what was noted (the caller's pass failed; the noted pointers are stale).  The caller keeps every
+ * noted x / dy / dW alive until the join, as for a queued one.  Results are unchanged. */
+int usc_wgrad_lane_hold(int32_t mode, int64_t hold_min_rows, int64_t release_max_rows, usc_stream_t s);
+/* 1 while a hold is in force on the current device (nothing released yet), else 0. */
+int32_t usc_wgrad_lane_holding(void);
+/* Launch statistics of the tile-compacted kernel (the dominant kernel of the step, models/modules/common.py:125-188),
+ * taken by the kernel itself while a real step runs — every stream, graph and lane as they are — so that the bench can
+ * report the kernel's rate inside the step it times (`roofline.frac_in_step`) next to its rate alone.  Between begin and
+ * end every such launch gets the next slot of `ring_dev` (device memory, slots x 4 x u64, initialised on `s` by begin):
+ * {earliest workgroup start, latest workgroup end (wall-clock ticks, usc_wall_clock_khz), real (in, out) pairs of the
+ * launch, 0}; launches beyond `slots` are not recorded.  usc_launch_stats_end stops the recording and copies the shapes
+ * of the recorded launches, in launch order, into host_out (<= max_out entries); it returns their number.  The caller
+ * synchronises before reading the ring.  Cost while recording: two atomics per workgroup. */
+typedef struct usc_launch_stat { int64_t n_out; int32_t cin, cout, K, nb; } usc_launch_stat;
+int usc_launch_stats_begin(void* ring_dev, int64_t slots, usc_stream_t s);
+int64_t usc_launch_stats_end(usc_launch_stat* host_out, int64_t max_out);
+int64_t usc_wall_clock_khz(void);
 /* Scratch bytes covering forward AND backward of one convolution / one unit. */
 int64_t usc_conv_ws_bytes(const usc_kmap* m, int32_t kind, int32_t cin,
                           int32_t cout);

@@ -108,3 +108,101 @@ def test_step_program_in_eval_mode_and_fallbacks(device, monkeypatch):
     out, fmaps, loss = _run(model, coords4, feats, device, (1, 1, 1, 1, 1))
     loss.backward()
     assert model.block4[0].conv1.kernel.grad is not None and bool(torch.isfinite(model.block4[0].conv1.kernel.grad).all())
+
+
+def _fresh_model(device, seed=7):
+    from unscene3d_amd.models.res16unet import Res16UNet34C
+    torch.manual_seed(seed)
+    cfg = SimpleNamespace(bn_momentum=0.02, conv1_kernel_size=3, dilations=[1, 1, 1, 1])
+    model = Res16UNet34C(3, 20, cfg, out_fpn=True).to(device).train()
+    for p in model.parameters():
+        p.grad = torch.zeros_like(p)
+    return model
+
+
+def test_lane_schedule_holds_the_fine_weight_gradients_and_changes_no_bit(device, monkeypatch):
+    """usc_wgrad_lane_hold (round 6): the fine decoder stages' weight gradients are noted and only put on the lane when
+    the backward walk reaches a coarse map.  Same kernels on the same operands: every gradient is bit-equal to the
+    un-held schedule, nothing stays noted after the pass, wherever the release point lies."""
+    from unscene3d_amd import program, units
+    from unscene3d_amd._lib import lib
+
+    coords4, feats = _scene(30_000, 2317)
+    model = _fresh_model(device)
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    monkeypatch.setattr(program, "ENABLED", True)
+    assert units._lane(torch.device(device)) is not None, "the weight-gradient lane is on by default"
+    res = {}
+    coarsest = int(np.unique(coords4[:, 1:] // 16, axis=0).shape[0])       # rows of the stride-16 map
+    assert 0 < coarsest < 5_000
+    for name, hold_min, release in (("plain", 1 << 40, 0), ("held", 20_000, 5_000), ("coarsest-only", 20_000, coarsest)):
+        monkeypatch.setattr(units, "LANE_HOLD_MIN_ROWS", hold_min)
+        monkeypatch.setattr(units, "LANE_RELEASE_ROWS", release)
+        model.load_state_dict(state)
+        for p in model.parameters():
+            p.grad.zero_()
+        held_seen = []
+        real_run = lib.usc_program_run
+
+        def run(*a, _real=real_run, _seen=held_seen):
+            rc = _real(*a)
+            _seen.append(int(lib.usc_wgrad_lane_holding()))
+            return rc
+        monkeypatch.setattr(lib, "usc_program_run", run)
+        _run(model, coords4, feats, device, (0.5, 1.0, 1.5, 2.0, 0.25))[2].backward()
+        monkeypatch.setattr(lib, "usc_program_run", real_run)
+        torch.cuda.synchronize()
+        assert lib.usc_wgrad_lane_holding() == 0
+        if name == "held":      # the forward call, then: held over the first (fine) stage calls, released by a coarse one
+            assert held_seen[1] == 1 and held_seen[-1] == 0, held_seen
+        res[name] = {n: p.grad.clone() for n, p in model.named_parameters() if not n.startswith("final.")}
+    for name in ("held", "coarsest-only"):
+        for n, g in res["plain"].items():
+            assert torch.equal(g, res[name][n]), (name, n)
+    assert float(res["plain"]["block8.0.conv1.kernel"].abs().sum()) > 0
+
+
+def test_joins_are_queued_again_after_a_failed_backward(device, monkeypatch):
+    """A backward node that raises makes the engine drop its end-of-backward callbacks.  The queued-once marks of the
+    lane join / grouped weight gradients are keyed on the graph task, so the next pass queues its own join and its
+    gradients are complete (a sticky flag left every later pass un-joined)."""
+    from unscene3d_amd import program, units
+
+    class Poison(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w):
+            return w * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("poisoned backward node")
+
+    coords4, feats = _scene(12_000, 2323)
+    model = _fresh_model(device, seed=8)
+    monkeypatch.setattr(program, "ENABLED", True)
+    joins = []
+    real_join = units.join_lane
+    monkeypatch.setattr(units, "join_lane", lambda *a, **k: (joins.append(1), real_join(*a, **k))[1])
+    _run(model, coords4, feats, device, (1, 1, 1, 1, 1))[2].backward()
+    torch.cuda.synchronize()
+    assert joins, "the lane join runs at the end of a backward pass"
+    want = {n: p.grad.clone() for n, p in model.named_parameters() if not n.startswith("final.")}
+    for p in model.parameters():
+        p.grad.zero_()
+    # created BEFORE the forward pass -> lower sequence number -> its backward runs after the trunk's
+    w = torch.ones(4, device=device, requires_grad=True)
+    z = Poison.apply(w)
+    loss = _run(model, coords4, feats, device, (1, 1, 1, 1, 1))[2] + z.sum()
+    with pytest.raises(RuntimeError, match="poisoned"):
+        loss.backward()
+    torch.cuda.synchronize()
+    for p in model.parameters():
+        p.grad.zero_()
+    model.load_state_dict({k: v for k, v in model.state_dict().items()})
+    n0 = len(joins)
+    # the batch-norm running statistics moved twice; the gradients depend on the batch statistics only
+    _run(model, coords4, feats, device, (1, 1, 1, 1, 1))[2].backward()
+    assert len(joins) > n0, "the pass after a failed one queued no lane join"
+    torch.cuda.synchronize()
+    for n, g in want.items():
+        assert torch.equal(g, dict(model.named_parameters())[n].grad), n

@@ -105,6 +105,11 @@ SIGNATURES = {
     "usc_set_side_stream": (C.c_int, [_p]),
     "usc_set_wgrad_lane": (C.c_int, [_p, _p, _i64, _i64]),
     "usc_wgrad_lane_join": (C.c_int, [_p]),
+    "usc_wgrad_lane_hold": (C.c_int, [_i32, _i64, _i64, _p]),
+    "usc_wgrad_lane_holding": (_i32, []),
+    "usc_launch_stats_begin": (C.c_int, [_p, _i64, _p]),
+    "usc_launch_stats_end": (_i64, [_p, _i64]),
+    "usc_wall_clock_khz": (_i64, []),
     "usc_conv_ws_bytes": (_i64, [_kp, _i32, _i32, _i32]),
     "usc_unit_ws_bytes": (_i64, [_kp, _i32, _i32, _i32]),
     "usc_conv_forward": (C.c_int, [_kp, _i32, _p, _i32, _p, _i32, _p, _p, _p, _i64, _p]),
@@ -197,6 +202,11 @@ SIGNATURES = {
     "usc_furthest_point_sampling": (C.c_int, [_p, _i32, _i32, _i32, _p, _p, _p]),
     "usc_fourier_posenc": (C.c_int, [_p, _i64, _p, _p, _p, _i32, _p, _p]),
 }
+
+
+class LaunchStat(C.Structure):
+    """Mirror of usc_launch_stat (include/usc3d.h)."""
+    _fields_ = [("n_out", _i64), ("cin", _i32), ("cout", _i32), ("K", _i32), ("nb", _i32)]
 
 
 def _load():

@@ -21,6 +21,8 @@
 
 #include <stdlib.h>
 
+#include <vector>
+
 namespace usc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,6 +45,8 @@ struct GemmParams {
   const int32_t* rows_in;
   const int32_t* rows_out;
   const int64_t* koff;
+  // launch statistics (usc_launch_stats_begin): {min start, max end (wall clock ticks), real pairs, -} of this launch, or NULL
+  unsigned long long* stats;
 };
 
 // MFMA C/D layout (32x32): col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   const int64_t r0 = tile * TM;
+  if (p.stats && threadIdx.x == 0) atomicMin(p.stats, (unsigned long long)wall_clock64());
 
   // ---- prologue: zero accumulators, compact the neighbour table of this tile per offset
   for (int e = threadIdx.x; e < TM * BN / 4; e += NT) reinterpret_cast<float4*>(accT)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -529,6 +534,15 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
       v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
     *reinterpret_cast<float4*>(dst) = v;
+  }
+  if (p.stats && threadIdx.x == 0) {
+    if (blockIdx.y == 0) {
+      int pairs = 0;
+      for (int k = 0; k < K; ++k) pairs += cnt[k];
+      atomicAdd(p.stats + 2, (unsigned long long)pairs);
+    }
+    __builtin_amdgcn_s_waitcnt(0);      // (the tile's stores have been issued; the end mark is taken after them)
+    atomicMax(p.stats + 1, (unsigned long long)wall_clock64());
   }
 }
 
@@ -1304,6 +1318,45 @@ int64_t usc_spconv_gather_gemm_ws_bytes(int64_t n_out, int32_t cin, int32_t cout
   return pl.G > 1 ? (int64_t)pl.G * n_out * cout * 4 : 0;
 }
 
+// ---- launch statistics of the tile-compacted kernel, taken by the kernel itself inside whatever step is running ----
+namespace {
+struct LaunchStats { unsigned long long* ring = nullptr; int64_t slots = 0, count = 0; std::vector<usc_launch_stat> meta; };
+LaunchStats g_lstats;
+__global__ void launch_stats_init_kernel(unsigned long long* ring, int64_t slots) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < slots) { ring[4 * i] = ~0ull; ring[4 * i + 1] = 0; ring[4 * i + 2] = 0; ring[4 * i + 3] = 0; }
+}
+}  // namespace
+
+int usc_launch_stats_begin(void* ring_dev, int64_t slots, usc_stream_t s) {
+  USC_REQUIRE(ring_dev && slots > 0, "usc_launch_stats_begin: needs a device ring of slots x 4 x u64");
+  hipLaunchKernelGGL(launch_stats_init_kernel, dim3((unsigned)ceil_div(slots, 256)), dim3(256), 0, as_stream(s),
+                     (unsigned long long*)ring_dev, slots);
+  USC_CHECK_LAUNCH("usc_launch_stats_begin");
+  g_lstats.ring = (unsigned long long*)ring_dev;
+  g_lstats.slots = slots;
+  g_lstats.count = 0;
+  g_lstats.meta.clear();
+  g_lstats.meta.reserve((size_t)slots);
+  return USC_OK;
+}
+
+int64_t usc_launch_stats_end(usc_launch_stat* host_out, int64_t max_out) {
+  const int64_t n = g_lstats.count;
+  if (host_out)
+    for (int64_t i = 0; i < n && i < max_out; ++i) host_out[i] = g_lstats.meta[(size_t)i];
+  g_lstats.ring = nullptr;
+  g_lstats.slots = g_lstats.count = 0;
+  g_lstats.meta.clear();
+  return n;
+}
+
+int64_t usc_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return khz;
+}
+
 int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
                            const int32_t* nbr, int64_t n_out, const float* bias, float* out, int32_t accumulate,
                            int32_t w_transposed, void* ws, int64_t ws_bytes, usc_stream_t s) {
@@ -1341,6 +1394,10 @@ int usc_spconv_gather_gemm(const float* in, int64_t n_in, int32_t cin, const flo
     p.W = (const float*)ws;
     dim3 cgrid((unsigned)ceil_div(n_out, pl.TM), (unsigned)(cout / (pl.NB * 32)));
     const size_t lds = compact_lds_bytes(pl.NB, pl.TM);
+    if (g_lstats.ring && g_lstats.count < g_lstats.slots) {
+      p.stats = g_lstats.ring + 4 * g_lstats.count++;
+      g_lstats.meta.push_back(usc_launch_stat{n_out, cin, cout, K, pl.NB});
+    }
 #define USC_CG(NBv)                                                                                        \
     {                                                                                                      \
       static bool attr_set = false;                                                                        \

@@ -12,6 +12,8 @@
 // models/res16unet.py:231-297 (conv{0..4} / convtr{4..7} + bn + relu), models/modules/common.py:125-188.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.h"
 
 using namespace usc;
@@ -101,13 +103,39 @@ constexpr int64_t kForkMaxRows = 24576;   // larger maps fill the chip on their 
 // returns; the input-gradient chain — the critical path of the backward pass — carries on, and the latency-bound
 // weight-gradient launches of the coarse levels fill the CUs it leaves idle.  The caller joins once, when the
 // gradients are needed (usc_wgrad_lane_join), keeps x / dy / dW alive until then, and gives the lane its own scratch.
+// One weight gradient that has been handed to the lane but not launched yet (usc_wgrad_lane_hold).
+struct HeldWgrad { const float* x; const float* dy; float* dW; const int32_t* a_idx; const int32_t* b_idx; const int64_t* koff;
+                   int64_t rows, ws_bytes; int cin, cout, K; };
 struct Lane { hipStream_t st = nullptr; hipEvent_t fork = nullptr, join = nullptr; void* ws = nullptr; int64_t ws_bytes = 0;
-              int64_t max_rows = 0; bool dirty = false; };
+              int64_t max_rows = 0; bool dirty = false;
+              // hold: weight gradients of maps with >= hold_min_rows rows are only NOTED until the caller's chain reaches a map
+              // with <= release_max_rows rows (or the hold is lifted); from then on everything goes to the lane at once
+              bool hold = false; int64_t hold_min_rows = 0, release_max_rows = 0; std::vector<HeldWgrad> held; };
 Lane g_lane[16];
 Lane* lane_for_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   return g_lane[dev].st ? &g_lane[dev] : nullptr;
+}
+
+// the held weight gradients go to the lane, in the order they were noted, behind one event of the caller's stream
+int lane_release(Lane* lane, usc_stream_t s) {
+  lane->hold = false;
+  if (lane->held.empty()) return USC_OK;
+  if (hipEventRecord(lane->fork, as_stream(s)) != hipSuccess || hipStreamWaitEvent(lane->st, lane->fork, 0) != hipSuccess) {
+    lane->held.clear();
+    set_error("usc wgrad lane: releasing the held weight gradients failed (event)");
+    return USC_ERR_LAUNCH;
+  }
+  int rc = USC_OK;
+  lane->dirty = true;
+  for (const HeldWgrad& h : lane->held) {
+    rc = usc_spconv_wgrad(h.x, h.cin, h.dy, h.cout, h.K, h.a_idx, h.b_idx, h.koff, h.rows, h.dW, 1, lane->ws, h.ws_bytes,
+                          (usc_stream_t)lane->st);
+    if (rc) break;
+  }
+  lane->held.clear();
+  return rc;
 }
 
 SideStream* side_for_current_device() {
@@ -232,6 +260,8 @@ int usc_set_wgrad_lane(usc_stream_t lane, void* lane_ws, int64_t lane_ws_bytes, 
   Lane& e = g_lane[dev];
   if (!lane) {
     e.st = nullptr;
+    e.held.clear();
+    e.hold = false;
     return USC_OK;
   }
   USC_REQUIRE(lane_ws && lane_ws_bytes > 0 && max_rows > 0, "usc_set_wgrad_lane: the lane needs its own scratch and a row bound");
@@ -250,8 +280,33 @@ int usc_set_wgrad_lane(usc_stream_t lane, void* lane_ws, int64_t lane_ws_bytes, 
   return USC_OK;
 }
 
+int usc_wgrad_lane_hold(int32_t mode, int64_t hold_min_rows, int64_t release_max_rows, usc_stream_t s) {
+  Lane* lane = lane_for_current_device();
+  if (!lane) return USC_OK;
+  if (mode > 0) {
+    USC_REQUIRE(hold_min_rows > release_max_rows && release_max_rows >= 0, "usc_wgrad_lane_hold: hold_min_rows must exceed release_max_rows");
+    if (!lane->held.empty()) { const int rc = lane_release(lane, s); if (rc) return rc; }
+    lane->hold = true;
+    lane->hold_min_rows = hold_min_rows;
+    lane->release_max_rows = release_max_rows;
+    return USC_OK;
+  }
+  if (mode < 0) {            // the caller's pass failed: what was noted points into buffers that are gone
+    lane->held.clear();
+    lane->hold = false;
+    return USC_OK;
+  }
+  return lane_release(lane, s);
+}
+
+int32_t usc_wgrad_lane_holding(void) {
+  Lane* lane = lane_for_current_device();
+  return lane && lane->hold ? 1 : 0;
+}
+
 int usc_wgrad_lane_join(usc_stream_t s) {
   Lane* lane = lane_for_current_device();
+  if (lane && !lane->held.empty()) { const int rc = lane_release(lane, s); if (rc) return rc; }
   if (!lane || !lane->dirty) return USC_OK;
   if (hipEventRecord(lane->join, lane->st) != hipSuccess || hipStreamWaitEvent(as_stream(s), lane->join, 0) != hipSuccess) {
     set_error("usc_wgrad_lane_join: joining the lane failed");
@@ -365,8 +420,21 @@ static int conv_backward_impl(const usc_kmap* m, int32_t kind, const float* x, i
     // USC3D_WGRAD_LANE_MIN_ROWS (experiment knob): only maps with at least that many rows go to the lane — the
     // throughput-bound weight gradients of the fine levels, queued to run beside the latency-bound coarse-level chain
     static const int64_t lane_min_rows = getenv("USC3D_WGRAD_LANE_MIN_ROWS") ? atoll(getenv("USC3D_WGRAD_LANE_MIN_ROWS")) : 0;
-    if (lane && sh.n_in > 0 && sh.n_in >= lane_min_rows && sh.n_in <= lane->max_rows && sh.n_out <= lane->max_rows && b <= lane->ws_bytes &&
-        (!m->nbr || (m->pair_in && m->pair_out && m->koff)) &&
+    const bool lane_ok = lane && sh.n_in > 0 && sh.n_in >= lane_min_rows && sh.n_in <= lane->max_rows && sh.n_out <= lane->max_rows &&
+                         b <= lane->ws_bytes && (!m->nbr || (m->pair_in && m->pair_out && m->koff));
+    const int64_t big = sh.n_in > sh.n_out ? sh.n_in : sh.n_out;
+    // the chain has reached a map too small to fill the chip: what was held runs beside it from here on
+    if (lane && lane->hold && big <= lane->release_max_rows) { rc = lane_release(lane, s); if (rc) return rc; }
+    if (lane_ok && lane->hold && big >= lane->hold_min_rows) {
+      HeldWgrad h{x, dy, dW, nullptr, nullptr, nullptr, m->nbr ? rows : sh.n_in, b, cin, cout, m->nbr ? K : 1};
+      if (m->nbr) {
+        h.a_idx = kind == USC_CONV_UP ? m->pair_out : m->pair_in;
+        h.b_idx = kind == USC_CONV_UP ? m->pair_in : m->pair_out;
+        h.koff = m->koff;
+      }
+      lane->held.push_back(h);
+      dW = nullptr;          // noted; launched by lane_release
+    } else if (lane_ok &&
         hipEventRecord(lane->fork, as_stream(s)) == hipSuccess && hipStreamWaitEvent(lane->st, lane->fork, 0) == hipSuccess) {
       usc_stream_t ls = (usc_stream_t)lane->st;
       lane->dirty = true;

@@ -345,7 +345,14 @@ def _grad_target(param):
     return None
 
 
-_JOIN_QUEUED = False
+_JOIN_QUEUED_TASK = None        # id of the autograd graph task whose end-of-backward join has been queued
+
+
+def _graph_task():
+    """Id of the running backward pass (-1 outside one).  The queued-once marks of the end-of-backward joins are keyed
+    on it: the engine drops its callbacks when a backward node raises, and a sticky flag would then keep every later
+    pass from queueing its join (tests/test_gpu_program.py::test_joins_are_queued_again_after_a_failed_backward)."""
+    return torch._C._current_graph_task_id()
 
 
 def _join_after_backward():
@@ -353,16 +360,17 @@ def _join_after_backward():
     for the streams of the AccumulateGrad nodes it ran, not for a stream on which a backward wrote p.grad in place: one
     end-of-backward callback lets the caller's stream wait for the side streams, so that `loss.backward();
     optimizer.step()` stays correct without the caller knowing about them."""
-    global _JOIN_QUEUED
-    if _JOIN_QUEUED or not SIDE_STREAMS:
+    global _JOIN_QUEUED_TASK
+    if not SIDE_STREAMS or not on_side_stream():
         return
-    if not on_side_stream():
+    task = _graph_task()
+    if task < 0 or task == _JOIN_QUEUED_TASK:
         return
-    _JOIN_QUEUED = True
+    _JOIN_QUEUED_TASK = task
 
     def done():
-        global _JOIN_QUEUED
-        _JOIN_QUEUED = False
+        global _JOIN_QUEUED_TASK
+        _JOIN_QUEUED_TASK = None
         join_side_streams()
     torch.autograd.Variable._execution_engine.queue_callback(done)
 

@@ -291,8 +291,8 @@ class _Trunk(torch.autograd.Function):
         model, pl, cm, ts, feats, car, ptr, stats_ptr, kmaps, bnrefs, rows = ctx.state
         dev = feats.device
         gar = _Pool(dev, max(rows[0] * 256, 1 << 20))
-        lane = units._lane(dev)                  # weight-gradient lane (experiment, off by default): its launches read x
-        if lane is not None:                     # and dy after this function has moved on -> nothing they read is re-used
+        lane = units._lane(dev)                  # weight-gradient lane (on by default): its launches read x and dy after
+        if lane is not None:                     # this function has moved on -> nothing they read is re-used
             gar.release = lambda p_, n_: None
             car.arena.record_stream(lane[0])
         keep = [g.contiguous() if g is not None else None for g in gouts]
@@ -411,19 +411,36 @@ class _Trunk(torch.autograd.Function):
         ws = units.workspace(wsb, dev)
         stream = ops._stream()
         begin = 0
-        for end, plist in segments:
-            if end > begin:
-                check(lib.usc_program_run(steps, begin, end, ws.data_ptr(), ws.numel(), stream), "usc_program_run")
-            if plist:
-                ops._grad_written(*plist)         # finished stages are reported while the earlier ones are still issued
-            begin = end
+        # the lane's schedule (usc_wgrad_lane_hold): the fine decoder stages' weight gradients are noted, not launched,
+        # until the walk reaches a stage whose maps cannot fill the chip; their parameters are reported then
+        holding = lane is not None and units.LANE_HOLD_MIN_ROWS > units.LANE_RELEASE_ROWS > 0 and \
+            any(min(rows[o["lin"]], rows[o["lout"]]) <= units.LANE_RELEASE_ROWS for o in pl.ops if o["t"] == "unit")
+        unreported = []
+        if holding:
+            check(lib.usc_wgrad_lane_hold(1, units.LANE_HOLD_MIN_ROWS, units.LANE_RELEASE_ROWS, stream), "usc_wgrad_lane_hold")
+        try:
+            for end, plist in segments:
+                if end > begin:
+                    check(lib.usc_program_run(steps, begin, end, ws.data_ptr(), ws.numel(), stream), "usc_program_run")
+                if holding and lib.usc_wgrad_lane_holding():
+                    unreported.extend(plist)
+                elif plist or unreported:
+                    ops._grad_written(*unreported, *plist)   # finished stages are reported while the earlier ones are still issued
+                    unreported = []
+                begin = end
+            if holding:
+                check(lib.usc_wgrad_lane_hold(0, 0, 0, stream), "usc_wgrad_lane_hold")
+                if unreported:
+                    ops._grad_written(*unreported)
+        except BaseException:
+            if holding:
+                lib.usc_wgrad_lane_hold(-1, 0, 0, None)
+            raise
         if lane is not None:
             for t in gar.chunks:
                 t.record_stream(lane[0])
             key = dev.index if dev.index is not None else torch.cuda.current_device()
-            if key not in units._LANE_JOIN_QUEUED:
-                units._LANE_JOIN_QUEUED.add(key)
-                torch.autograd.Variable._execution_engine.queue_callback(lambda: units._join_lane_after_backward(key))
+            units.queue_lane_join(key)
         ctx.state = None
         return (None, None, None, None, None) + (None,) * len(pl.params)
 

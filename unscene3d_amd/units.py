@@ -39,6 +39,12 @@ FORK_WGRAD = os.environ.get("USC3D_FORK_WGRAD", "0") == "1"
 # above that the finest level's three 96 -> 96 gradients are no longer one grouped grid and sum in another order).
 LANE_MAX_ROWS = int(os.environ.get("USC3D_WGRAD_LANE_MAX_ROWS", str(1 << 40)))
 LANE_WS_BYTES = 192 << 20
+# The lane's schedule inside the step program's backward pass (usc_wgrad_lane_hold, round 6): weight gradients of maps
+# with >= LANE_HOLD_MIN_ROWS rows (the levels whose input gradients run on the tile-compacted kernel) are noted until
+# the walk reaches a map with <= LANE_RELEASE_ROWS rows and run beside the coarse levels' latency-bound chain instead
+# of beside the fine levels' input gradients.  USC3D_LANE_RELEASE_ROWS=0 switches the schedule off.
+LANE_HOLD_MIN_ROWS = int(os.environ.get("USC3D_LANE_HOLD_MIN_ROWS", "24576"))
+LANE_RELEASE_ROWS = int(os.environ.get("USC3D_LANE_RELEASE_ROWS", "12000"))
 SAME, DOWN, UP = 0, 1, 2
 # Grouped weight gradients (usc_spconv_wgrad_group): the stride-1 convolutions of one level's residual blocks have the
 # same shape on the same kernel map; their weight gradients are off the backward pass's critical chain (nothing reads
@@ -50,7 +56,7 @@ SAME, DOWN, UP = 0, 1, 2
 GROUP_WGRAD = os.environ.get("USC3D_GROUP_WGRAD", "1") == "1"
 _SIDE = {}     # device index -> torch.cuda.Stream handed to usc_set_side_stream
 _LANE = {}     # device index -> (stream, scratch tensor) handed to usc_set_wgrad_lane, or None
-_LANE_JOIN_QUEUED = set()
+_LANE_JOIN_QUEUED = {}     # device index -> id of the graph task whose end-of-backward lane join has been queued
 
 
 def _lane_stream(device):
@@ -119,9 +125,22 @@ def join_lane(device=None):
 
 
 def _join_lane_after_backward(key):
-    _LANE_JOIN_QUEUED.discard(key)
+    _LANE_JOIN_QUEUED.pop(key, None)
     with torch.cuda.device(key):
         join_lane()
+
+
+def queue_lane_join(key):
+    """Queue ONE lane join at the end of the running backward pass.  Keyed on the graph task (ops._graph_task): after a
+    backward pass that raised — the engine drops its callbacks then — the next pass queues its own join again."""
+    task = ops._graph_task()
+    if task < 0:                       # not inside a backward pass (a direct call of a backward function): join now
+        with torch.cuda.device(key):
+            join_lane()
+        return
+    if _LANE_JOIN_QUEUED.get(key) != task:
+        _LANE_JOIN_QUEUED[key] = task
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_lane_after_backward(key))
 
 
 def _lane_hold(device, n_in, n_out, in_place_dW, *tensors):
@@ -134,9 +153,7 @@ def _lane_hold(device, n_in, n_out, in_place_dW, *tensors):
     for t in tensors:
         t.record_stream(lane[0])
     key = device.index if device.index is not None else torch.cuda.current_device()
-    if key not in _LANE_JOIN_QUEUED:
-        _LANE_JOIN_QUEUED.add(key)
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_lane_after_backward(key))
+    queue_lane_join(key)
     return True
 
 
@@ -186,21 +203,26 @@ class _WgradQueue:
     """Deferred same-shape weight gradients of the running backward pass (one queue per device)."""
 
     def __init__(self):
-        self.key, self.items, self.callback_queued = None, [], False
+        self.key, self.items, self.task = None, [], None
 
     def push(self, key, kmap, x, dy, W_param, dW):
+        task = ops._graph_task()
+        if self.task is not None and task != self.task:
+            # left behind by a backward pass that raised (the engine drops its callbacks then): those gradients belong
+            # to a pass that never finished
+            self.items, self.key, self.task = [], None, None
         if self.key is not None and key != self.key:
             self.flush()
         self.key = key
         self.items.append((kmap, x, dy, W_param, dW))
-        if len(self.items) >= _group_max():
+        if len(self.items) >= _group_max() or task < 0:
             self.flush()
-        elif not self.callback_queued:
-            self.callback_queued = True
+        elif self.task is None:
+            self.task = task
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def _end_of_backward(self):
-        self.callback_queued = False
+        self.task = None
         self.flush()
 
     def flush(self):
