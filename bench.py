@@ -91,6 +91,9 @@ def parse(argv=None):
                          "device-bound; the collectives must line up all the same); default: --voxels on every rank")
     ap.add_argument("--eager-ranks", default="", metavar="R0,R1,...",
                     help="ranks that do NOT capture the decoder passes as HIP graphs (mixed eager / graphed ranks)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still create a (one-rank) process group and run the bucketed gradient reducer and "
+                         "the criterion's all-reduce through it — what RCCL's own streams cost next to the step's four")
     ap.add_argument("--dry-collectives", action="store_true",
                     help="N ranks: run ONLY the collectives of a training step — the criterion's 13 scalar `num_masks` "
                          "all-reduces (models/criterion.py:258-260) and the gradient exchange in the reducer's bucket "
@@ -225,7 +228,7 @@ def make_mask3d_step(args, dev, rank, world):
                                       spatial_sort=args.spatial_sort)
 
     reducer = None
-    if world > 1 and os.environ.get("USC3D_OVERLAP_ALLREDUCE", "1") == "1":
+    if (world > 1 or getattr(args, "force_dist", False)) and os.environ.get("USC3D_OVERLAP_ALLREDUCE", "1") == "1":
         from unscene3d_amd.ddp import BucketedGradReducer
         reducer = BucketedGradReducer(params, flat, world).install()     # ~24 MB buckets, started during backward
 
@@ -353,9 +356,9 @@ def _stream_report():
 
 
 def _allreduce_note(step, world):
-    if world == 1:
-        return None
     red = getattr(step, "reducer", None)
+    if world == 1 and red is None:
+        return None
     if red is None:
         return "one flat buffer after backward"
     return (f"{len(red.bounds)} buckets of the flat buffer, {red.started_during_backward} started during backward "
@@ -741,13 +744,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # --force-dist: a ONE-rank process group (RCCL with world_size 1 works on one device): the bucketed gradient reducer,
+    # the criterion's num_masks all-reduce and RCCL's own streams run exactly as on N ranks, minus the wire
+    multi = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch exactly one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     if args.dist_backend == "nccl" and world > torch.cuda.device_count():
         raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} devices, this node shows "
                          f"{torch.cuda.device_count()} (--dist-backend gloo shares devices; smoke test only)")
-    if world > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.dist_backend != "nccl":
@@ -755,13 +765,13 @@ def main():
         if world > torch.cuda.device_count():
             # ranks SHARE a device (a code-path check on a one-GPU box, never a deployment): two processes with four
             # streams each on one device degenerate — 1.5-6 s per step, 100 ms with the lane or the key-preparation
-            # stream off (tools/ab_r05k.sh; the queues of different processes are time-sliced) — so the shared-device run
+            # stream off (tools/ab.sh, round 5; the queues of different processes are time-sliced) — so the shared-device run
             # keeps the second streams off unless the caller set the switches
             os.environ.setdefault("USC3D_WGRAD_LANE_MAX_ROWS", "0")
             os.environ.setdefault("USC3D_KV_SIDE_STREAM", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world,
                                 **({"device_id": dev} if args.dist_backend == "nccl" else {}))
         assert dist.get_world_size() == args.gpus
@@ -803,7 +813,7 @@ def main():
         check(lib.usc_launch_stats_begin(lstat_ring.data_ptr(), lstat_slots, torch.cuda.current_stream().cuda_stream),
               "usc_launch_stats_begin")
         torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -821,7 +831,7 @@ def main():
             marks[k + 1].record()          # device-side step boundaries (no host wait inside the timed loop)
     nvox = nvox_sum / max(1, args.steps)   # mean voxels per step over the timed loop (the rotated scenes differ)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -834,7 +844,7 @@ def main():
     own_marks = None
     if own is not None:                    # freeze the timed loop's marks (later steps must not append to them)
         own_marks, own["marks"] = own["marks"], None
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -851,18 +861,18 @@ def main():
         for _ in range(max(2, args.warmup)):
             step(world)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         r0 = time.perf_counter()
         for k in range(args.steps):
             step(world)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         rdt = time.perf_counter() - r0
-        if world > 1:
+        if multi:
             t = torch.tensor([rdt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             rdt = float(t.item())
@@ -901,7 +911,7 @@ def main():
                              "in_step_all": in_step})
 
     ranks_seen = None
-    if world > 1:
+    if multi:
         ranks_seen = _ranks_seen(dev, rank, world, args.dist_backend, getattr(step, "params", None))
 
     spr = getattr(step, "scenes_per_rank", 1)
@@ -947,7 +957,7 @@ def main():
         print(json.dumps(line))
     if hasattr(step, "close"):
         step.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

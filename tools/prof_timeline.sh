@@ -10,5 +10,6 @@ O=gpurun_out/$T; mkdir -p "$O"
 python tools/prof_summary.py "$O/prof" 90 > "$O/kernel_stats_summary.txt"
 python tools/stream_timeline.py "$O/prof" > "$O/timeline_last_step.txt"
 cp "$(ls $O/prof/*/*kernel_stats.csv | head -1)" "$O/kernel_stats.csv"
+gzip -c "$(ls $O/prof/*/*kernel_trace.csv | head -1)" > "$O/kernel_trace.csv.gz"
 rm -rf "$O/prof"
 tail -1 "$O/prof.log"

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Merged kernel timeline (all queues) of the LAST step in a rocprofv3 --kernel-trace CSV, for reading cross-stream
 stalls: one line per kernel — start (us from the step's first kernel), duration, gap to the previous kernel of the same
-queue, queue, name.  Usage: python tools/stream_timeline.py <dir> [from_us] [to_us]"""
+queue, queue, name.  Usage: python tools/stream_timeline.py <dir> [from_us] [to_us] [step_from_end]
+step_from_end: 1 = the span between the last two AdamW launches (bench.py: the instrumented per-operator step that
+follows the timed loop), 2 (default) = the one before it = the LAST TIMED step."""
 import csv
 import glob
 import sys
@@ -15,7 +17,8 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
 rows.sort()
 ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
-rows = rows[ad[-2] + 1:ad[-1] + 1]
+back = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+rows = rows[ad[-back - 1] + 1:ad[-back] + 1]
 t0 = rows[0][0]
 last_end = {}
 for s, e, name, q in rows:

@@ -797,6 +797,15 @@ class _DecoderPass(nn.Module):
 
 
 _KV_SIDE_STREAM = os.environ.get("USC3D_KV_SIDE_STREAM", "1") != "0"
+
+
+def set_kv_side_stream(on: bool):
+    """Switch the key-preparation stream at run time (streams.recheck_under_collective, tests).  Captured decoder passes
+    do not depend on it: the key / value side is issued eagerly, pass by pass, on whichever stream."""
+    global _KV_SIDE_STREAM
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    _KV_SIDE_STREAM = bool(on)
 _FUSED_ATTN_MASK = os.environ.get("USC3D_FUSED_ATTN_MASK", "1") != "0"
 _CHAIN_SEGMENT_GRADS = os.environ.get("USC3D_CHAIN_SEGMENT_GRADS", "1") != "0"
 
