@@ -350,7 +350,8 @@ def _stream_report():
     try:
         from unscene3d_amd import streams
         return [{"role": r["role"], "shared_queue": r["shared_queue"], "tried": len(r["tried"]),
-                 "ratios": r["tried"][-1]["ratios"] if r["tried"] else None} for r in streams.REPORT]
+                 "ratios": r["tried"][-1]["ratios"] if r["tried"] else None,
+                 **({"switched_off": r["switched_off"]} if "switched_off" in r else {})} for r in streams.REPORT]
     except Exception as err:      # noqa: BLE001 — a report, never a reason to lose the bench line
         return str(err)
 
@@ -801,6 +802,14 @@ def main():
     for _ in range(args.warmup):
         loss, nvox = step(world)
     torch.cuda.synchronize()
+    if multi and args.dist_backend == "nccl" and args.mode == "mask3d" and os.environ.get("USC3D_STREAM_RECHECK", "1") == "1":
+        # RCCL's stream exists now (first collective done): do the lane and the key stream still run beside the compute
+        # stream with an all-reduce in flight?  A stream that does not is switched off (config.streams says so).
+        from unscene3d_amd import streams
+        if any(r.get("switched_off") for r in streams.recheck_under_collective(dev)):
+            for _ in range(2):
+                loss, nvox = step(world)
+            torch.cuda.synchronize()
     # the dominant kernel marks its own start / end (device wall clock) and counts its real pairs during the TIMED steps
     # (usc_launch_stats_begin: two atomics per workgroup) -> roofline.frac_in_step describes the configuration `value`
     # is measured in — lane, step program, captured decoder passes and all

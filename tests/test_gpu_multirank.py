@@ -165,3 +165,25 @@ def test_prefetched_batches_give_the_same_training_trajectory():
     a, b = _run_single([]), _run_single(["--no-prefetch"])
     assert a["config"]["loss"] == b["config"]["loss"], (a["config"]["loss"], b["config"]["loss"])
     assert a["config"]["voxels_per_scene"] == b["config"]["voxels_per_scene"]
+
+
+def test_one_rank_rccl_reducer_runs_the_real_exchange_and_changes_no_bit():
+    """bench.py --force-dist: a ONE-rank RCCL process group on the one device this box has — the bucketed reducer (buckets
+    started during backward, issued in the weight-gradient lane's order), the criterion's num_masks all-reduce and RCCL's
+    own stream next to the step's four, exactly as on N ranks minus the wire (reference: DDP's bucket all-reduce,
+    main_instance_segmentation.py:86-92; models/criterion.py:258-260).  Averaging over one rank is the identity: the
+    loss after the steps has the bits of the plain run; the line says what was measured about the streams."""
+    def run(*extra):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--voxels", "40000",
+               "--no-cpu-baseline", "--rotate", "0", "--no-zorder", *extra]
+        out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    plain, forced = run(), run("--force-dist")
+    assert forced["n_gpus"] == 1 and forced["config"]["loss"] == plain["config"]["loss"], (forced["config"]["loss"], plain["config"]["loss"])
+    note = forced["config"]["grad_allreduce"]
+    assert note and "buckets" in note and plain["config"]["grad_allreduce"] is None, note
+    roles = {r["role"] for r in forced["config"]["streams"]}
+    assert "wgrad-lane under an all-reduce" in roles, roles
+    assert forced["config"]["rccl_ranks_seen"] == 1

@@ -225,6 +225,10 @@ constexpr int kZeroRowFloats = 4096;
 // (a select on a loaded register makes the compiler wait for the load — and everything older — first)
 __device__ float g_zero_row[kZeroRowFloats + 8];
 
+#ifdef USC_PHASE_STATS   /* developer build (tools/build_ablate.sh phase "-DUSC_PHASE_STATS"): where a tile's cycles go */
+__device__ unsigned long long g_phase[16];
+#define USC_PH(idx, val) atomicAdd(&g_phase[idx], (unsigned long long)(val))
+#endif
 #ifndef USC_COMPACT_WAVES
 #define USC_COMPACT_WAVES 8          /* developer builds: 16 = one 1024-thread workgroup per CU (tools/build_ablate.sh) */
 #endif
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
   const int TM = p.TM;   // rows per tile (multiple of 4, <= 256), chosen so that tiles fill whole CU rounds
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* accT = reinterpret_cast<float*>(smem);                        // [TM][BN]
-  int32_t* pl_in = reinterpret_cast<int32_t*>(accT + TM * BN);         // [K][TM]
+  int32_t* pl_in = reinterpret_cast<int32_t*>(accT + (TM + 1) * BN);   // [K][TM]   (accT[TM] = the dummy row of padding pairs)
   int32_t* cnt = pl_in + kMaxK * TM;                                   // [32]
   int32_t* item_start = cnt + 32;                                      // [32]
   volatile int32_t* ticket = item_start + 32;                          // [1] (+3 pad)
@@ -261,26 +265,50 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
   }
   const int64_t r0 = tile * TM;
   if (p.stats && threadIdx.x == 0) atomicMin(p.stats, (unsigned long long)wall_clock64());
+#ifdef USC_PHASE_STATS
+  const long long ph_t0 = clock64();
+  long long ph_wait = 0, ph_flush = 0;
+#endif
 
   // ---- prologue: zero accumulators, compact the neighbour table of this tile per offset
-  for (int e = threadIdx.x; e < TM * BN / 4; e += NT) reinterpret_cast<float4*>(accT)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int e = threadIdx.x; e < (TM + 1) * BN / 4; e += NT) reinterpret_cast<float4*>(accT)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (threadIdx.x == 0) *ticket = 0;
-  for (int k = wave; k < K; k += kCompactWaves) {
-    int base = 0;
-    for (int c = 0; c * 64 < TM; ++c) {
-      const int lr = c * 64 + lane;
-      const int64_t row = r0 + lr;
-      const int v = (lr < TM && row < p.n_out) ? (p.nbr ? p.nbr[(int64_t)k * p.n_out + row] : (int)row) : -1;
-      const bool f = v >= 0;
-      const unsigned long long m = __ballot(f);
-      if (f) {
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        pl_in[k * TM + pos] = v;
-        pl_loc[k * TM + pos] = (uint8_t)(c * 64 + lane);
+  {
+    // every neighbour-table word this wave compacts (<= 4 offsets x 4 chunks of 64 rows) is requested before the first one
+    // is used: the ballot passes below depend on each other only through `base`, but one load per pass, each waited
+    // for, put ~10 dependent HBM round trips in front of every tile (round 6: tools/compact_phase.py, 6 % of a tile)
+    constexpr int kOffPerWave = (kMaxK + kCompactWaves - 1) / kCompactWaves;
+    int nv[kOffPerWave][4];
+#pragma unroll
+    for (int j = 0; j < kOffPerWave; ++j) {
+      const int k = wave + j * kCompactWaves;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int lr = c * 64 + lane;
+        const int64_t row = r0 + lr;
+        nv[j][c] = (k < K && lr < TM && row < p.n_out) ? (p.nbr ? p.nbr[(int64_t)k * p.n_out + row] : (int)row) : -1;
       }
-      base += __popcll(m);
     }
-    if (lane == 0) cnt[k] = base;
+#pragma unroll
+    for (int j = 0; j < kOffPerWave; ++j) {
+      const int k = wave + j * kCompactWaves;
+      if (k >= K) break;
+      int base = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c * 64 >= TM) break;
+        const int v = nv[j][c];
+        const bool f = v >= 0;
+        const unsigned long long m = __ballot(f);
+        if (f) {
+          const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+          pl_in[k * TM + pos] = v;
+          pl_loc[k * TM + pos] = (uint8_t)(c * 64 + lane);
+        }
+        base += __popcll(m);
+      }
+      if (lane == 0) cnt[k] = base;
+    }
   }
   __syncthreads();
   if (wave == 0) {
@@ -297,6 +325,9 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
   }
   __syncthreads();
   const int total_items = item_start[K < 32 ? K : 31] + (K >= 32 ? 0 : 0);
+#ifdef USC_PHASE_STATS
+  const long long ph_t1 = clock64();
+#endif
 
   // ---- main loop.  A wave walks its items (item = wave, wave + 8, ...); one item = 32 real pairs of one
   // offset k, reduced over Cin in "quads" of 8 input channels (one 16-byte load of the gathered row per lane
@@ -390,6 +421,17 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     // s_waitcnt vmcnt(0), draining the prefetch rings at every poll).  LDS executes one wave's instructions in
     // issue order, so the hand-off needs no memory fence — which would also wait for vmcnt(0) — only the
     // compiler barriers and lgkmcnt waits below.
+#ifdef USC_PHASE_STATS
+    const long long ph_f0 = clock64();
+#endif
+    // The local output rows of this lane's 16 accumulator rows, read BEFORE the ticket (the pair lists do not change after
+    // the prologue): accumulator row r = 4g + q belongs to pair 8g + q + 4h of the item, so a lane's rows are four runs of
+    // four consecutive bytes — four aligned word reads, all in flight while lane 0 polls.  (Round 6: the first version read
+    // one byte per row inside the ordered section, each behind an `s_waitcnt lgkmcnt(0)` — sixteen dependent LDS round
+    // trips under the ticket; tools/compact_phase.py put the section at a fifth of a wave's time.)
+    uint32_t loc4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) loc4[g] = *reinterpret_cast<const uint32_t*>(pl_loc + st.pbase + 8 * g);
 #ifndef USC_ABLATE_TICKET
     if (lane == 0) {
 #ifndef USC_POLL_SLEEP
@@ -403,17 +445,21 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     }
     __builtin_amdgcn_wave_barrier();
 #endif
+#ifdef USC_PHASE_STATS
+    const long long ph_f1 = clock64();
+#endif
 #ifndef USC_NO_SETPRIO
-    // the ticket holder is the workgroup's critical path: without priority its ~300 LDS/VALU instructions queue
+    // the ticket holder is the workgroup's critical path: without priority its LDS/VALU instructions queue
     // behind the other waves' MFMAs (issue is arbitrated by priority, then age) and the serialised section
     // stretched to ~10k cycles per item — measured: ticket alone +3 %, RMW alone +8 %, both together +77 %.
     __builtin_amdgcn_s_setprio(3);
 #endif
     asm volatile("" ::: "memory");
     // Plain LDS read-add-write; the ticket gives this wave exclusive, ordered access (ds_add_f32
-    // atomics measured 2x slower for the whole kernel).  The reads of a batch of rows are issued
-    // before the first dependent add so the row updates pipeline instead of paying one LDS round
-    // trip each — the serialised flush is the critical section of the workgroup.
+    // atomics measured 2x slower for the whole kernel).  No branches: a padding pair's rows go to the dummy row
+    // accT[TM] (its accumulators are exact zeros — the pair gathered the all-zero row — but -0 + 0 would flip a sign
+    // bit in a real row).  The reads of a batch of rows are issued before the first dependent add so the row updates
+    // pipeline instead of paying one LDS round trip each.
 #ifndef USC_KFB
 #define USC_KFB 4
 #endif
@@ -425,30 +471,27 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sink += acc[nb][r];
-      if (sink == 1.2345e-30f) accT[lane] = sink;
+      if (sink == 1.2345e-30f + (float)loc4[0]) accT[lane] = sink;
     }
 #else
 #pragma unroll
     for (int part = 0; part < 16 / kFB; ++part) {
-      int lrs[kFB];
+      float* dsts[kFB];
       float old[kFB][NB];
 #pragma unroll
       for (int q = 0; q < kFB; ++q) {
         const int r = part * kFB + q;
         const int prow = (r & 3) + 8 * (r >> 2);   // pair index inside the item is prow + 4h (MFMA C layout)
-        lrs[q] = (prow + 4 * h < st.npairs) ? (int)pl_loc[st.pbase + prow] : -1;
-        const float* src = accT + (lrs[q] >= 0 ? lrs[q] : 0) * BN + NB * i;
+        const int lr = (prow + 4 * h < st.npairs) ? (int)((loc4[r >> 2] >> (8 * (r & 3))) & 0xffu) : TM;
+        dsts[q] = accT + lr * BN + NB * i;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) old[q][nb] = src[nb];
+        for (int nb = 0; nb < NB; ++nb) old[q][nb] = dsts[q][nb];
       }
 #pragma unroll
       for (int q = 0; q < kFB; ++q) {
         const int r = part * kFB + q;
-        if (lrs[q] >= 0) {
-          float* dst = accT + lrs[q] * BN + NB * i;
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) dst[nb] = old[q][nb] + acc[nb][r];
-        }
+        for (int nb = 0; nb < NB; ++nb) dsts[q][nb] = old[q][nb] + acc[nb][r];
       }
     }
 #endif
@@ -460,6 +503,9 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
 #endif
 #ifndef USC_NO_SETPRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
+#ifdef USC_PHASE_STATS
+    { const long long ph_f2 = clock64(); ph_wait += ph_f1 - ph_f0; ph_flush += ph_f2 - ph_f1; }
 #endif
     zero_acc();
   };
@@ -516,7 +562,14 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
       }
     }
   }
+#ifdef USC_PHASE_STATS
+  const long long ph_tw = clock64();
+#endif
   __syncthreads();
+#ifdef USC_PHASE_STATS
+  const long long ph_t3 = clock64();
+  if (lane == 0) { USC_PH(3, ph_t3 - ph_tw); USC_PH(4, ph_wait); USC_PH(5, ph_flush); USC_PH(8, ph_tw - ph_t1); }
+#endif
 
   // ---- epilogue: coalesced copy of the tile to HBM
   for (int e = threadIdx.x; e < TM * BN / 4; e += NT) {
@@ -535,6 +588,12 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     }
     *reinterpret_cast<float4*>(dst) = v;
   }
+#ifdef USC_PHASE_STATS
+  if (threadIdx.x == 0) {
+    const long long ph_t4 = clock64();
+    USC_PH(0, ph_t1 - ph_t0); USC_PH(1, ph_t3 - ph_t1); USC_PH(2, ph_t4 - ph_t3); USC_PH(6, 1); USC_PH(7, total_items);
+  }
+#endif
   if (p.stats && threadIdx.x == 0) {
     if (blockIdx.y == 0) {
       int pairs = 0;
@@ -547,7 +606,7 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
 }
 
 static size_t compact_lds_bytes(int NB, int TM) {
-  return (size_t)TM * NB * 32 * 4 + (size_t)kMaxK * TM * 4 + (32 + 32 + 4) * 4 + (size_t)kMaxK * TM + kMaxItems * 4;
+  return (size_t)(TM + 1) * NB * 32 * 4 + (size_t)kMaxK * TM * 4 + (32 + 32 + 4) * 4 + (size_t)kMaxK * TM + kMaxItems * 4;
 }
 
 // out = (accumulate ? out : 0) + bias + sum_g partial[g]   (fixed order)
@@ -1350,6 +1409,15 @@ int64_t usc_launch_stats_end(usc_launch_stat* host_out, int64_t max_out) {
   g_lstats.meta.clear();
   return n;
 }
+
+#ifdef USC_PHASE_STATS
+// developer build only: read (and clear) the phase counters of gather_gemm_compact_kernel
+extern "C" int usc_phase_stats_read(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 16) != hipSuccess) return USC_ERR_LAUNCH;
+  unsigned long long z[16] = {0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) == hipSuccess ? USC_OK : USC_ERR_LAUNCH;
+}
+#endif
 
 int64_t usc_wall_clock_khz(void) {
   int dev = 0, khz = 0;

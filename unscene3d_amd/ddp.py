@@ -7,6 +7,8 @@ while the backbone's backward is still running (`BucketedGradReducer`).  xGMI ri
 per-link bound: few, large collectives."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 
@@ -30,6 +32,10 @@ def all_reduce_mean_(flat, world_size: int):
         dist.all_reduce(flat)
         flat.div_(world_size)
     return flat
+
+
+# USC3D_LANE_ORDERED_COLLECTIVES=0: the round-5 behaviour (the compute stream waits for the lane before every bucket)
+LANE_ORDERED_COLLECTIVES = os.environ.get("USC3D_LANE_ORDERED_COLLECTIVES", "1") == "1"
 
 
 class BucketedGradReducer:
@@ -115,11 +121,20 @@ class BucketedGradReducer:
         import torch.distributed as dist
         s, e = self.bounds[b]
         if self.flat.is_cuda:
-            # weight gradients queued on the lane stream (units.py) are not in this stream's order yet: the collective
-            # reads the bucket in the order of the current stream
+            # weight gradients queued on the lane stream (units.py) are not in this stream's order: the collective has to
+            # start behind BOTH.  Round 5 made the compute stream wait for the lane here — every bucket started during
+            # backward then serialised the lane's work into the input-gradient chain (a one-rank process group, bench.py
+            # --force-dist: 26.1-27.5 ms per step against 23.9).  Now the LANE waits for the compute stream (one event) and
+            # the collective is issued in the lane's order: RCCL's stream waits for the lane, the chain waits for nobody.
             from . import ops, units
-            units.join_lane(self.flat.device)
             ops.join_side_streams()          # (the decoder's key-preparation stream writes lin_squeeze / in_proj gradients)
+            lane = units.lane_stream_behind_current(self.flat.device) if LANE_ORDERED_COLLECTIVES else None
+            if lane is not None:
+                with torch.cuda.stream(lane):
+                    self.handles.append(dist.all_reduce(self.flat[s:e], async_op=True))
+                self.launched[b] = True
+                return
+            units.join_lane(self.flat.device)
         self.handles.append(dist.all_reduce(self.flat[s:e], async_op=True))
         self.launched[b] = True
 

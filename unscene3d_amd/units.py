@@ -124,6 +124,23 @@ def join_lane(device=None):
         check(lib.usc_wgrad_lane_join(ops._stream()), "usc_wgrad_lane_join")
 
 
+def lane_stream_behind_current(device=None):
+    """The lane's stream after it has been made to wait for everything queued on the current stream so far (one event), or
+    None without a lane.  Work issued on it from here on — a gradient bucket's collective (ddp.BucketedGradReducer) — is
+    ordered behind the lane's weight gradients AND the current stream's, and the current stream waits for neither.
+    Weight gradients still held by the lane's schedule (usc_wgrad_lane_hold) are released first."""
+    key = torch.cuda.current_device() if device is None or device.index is None else device.index
+    ent = _LANE.get(key)
+    if ent is None:
+        return None
+    if lib.usc_wgrad_lane_holding():
+        check(lib.usc_wgrad_lane_hold(0, 0, 0, ops._stream()), "usc_wgrad_lane_hold")
+    ev = torch.cuda.Event()
+    ev.record()
+    ent[0].wait_event(ev)
+    return ent[0]
+
+
 def _join_lane_after_backward(key):
     _LANE_JOIN_QUEUED.pop(key, None)
     with torch.cuda.device(key):
