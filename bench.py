@@ -23,6 +23,12 @@ from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The caching allocator in expandable segments (set before torch's allocator reads its configuration; the caller's own
+# setting wins): with four streams and scenes of changing size the fixed-size segments fragmented — a 383 ms step among
+# 131 ms ones at 8 scenes per GPU, 55.1 -> 60.2 scenes/s with this setting (round 6, same box).  config.allocator in the
+# line says what was in force; unscene3d_amd.trainer documents the same setting for training runs.
+for _k in ("PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF"):
+    os.environ.setdefault(_k, "expandable_segments:True")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -959,6 +965,7 @@ def main():
                                                                     if ref_order else "")), **(rot or {}), **({"rank_skew": skew} if skew else {}),
                        "loss": float(loss), "grad_allreduce": _allreduce_note(step, world),
                        "streams": _stream_report(),
+                       "allocator": os.environ.get("PYTORCH_HIP_ALLOC_CONF", ""),
                        **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),

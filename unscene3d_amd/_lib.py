@@ -17,7 +17,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("USC3D_LIB", os.path.join(_HERE, "libusc3d_hip.so"))   # override: developer ablation builds
+LIB_PATH = os.environ.get("USC3D_LIB") or os.path.join(_HERE, "libusc3d_hip.so")   # override: developer ablation builds
 
 _p = C.c_void_p
 _i32 = C.c_int32

@@ -537,8 +537,19 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
     while (true) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
+#ifndef USC_LOAD_B_FIRST
         load_a(ra[(u + kDA) % kRA], pa); advance_a();
         load_bq(rb[(u + kDB) % kRB], pb); advance_b();
+#else
+        // Developer switch, measured in round 6 and NOT kept: vector loads return in order, and the next quad's first MFMA
+        // waits for this quad's weight loads — with the gather issued in front of them it also waits for a row requested
+        // only one quad earlier, whatever the ring's nominal distance of kDA quads.  Weights first doubles that distance
+        // (the ISA shows vmcnt(7) instead of vmcnt(6)): 0.511 / 0.478 ms against 0.509 / 0.466 (96 -> 96, 148 564 rows,
+        // forward / input gradient), 24.1 against 23.9 ms per step, and kDA = 2 is as fast as 3 — the gathered rows'
+        // latency is not what this loop waits for.
+        load_bq(rb[(u + kDB) % kRB], pb); advance_b();
+        load_a(ra[(u + kDA) % kRA], pa); advance_a();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const float4 a4 = ra[u % kRA];
         const float av[4] = {a4.x, a4.y, a4.z, a4.w};

@@ -13,6 +13,10 @@ from torch import nn
 
 from .misc import get_world_size, is_dist_avail_and_initialized
 
+# diagnostic switch (tools/ab.sh): USC3D_NUM_MASKS_ALLREDUCE=0 leaves the reference's num_masks collective out of the device
+# criterion — its result is unused there — to price what ONE small collective per step costs next to the step's streams
+_NUM_MASKS_ALLREDUCE = __import__("os").environ.get("USC3D_NUM_MASKS_ALLREDUCE", "1") == "1"
+
 
 def dice_loss(inputs, targets, num_masks: float, weights):
     p = inputs.sigmoid().flatten(1)
@@ -410,9 +414,12 @@ class SetCriterion(nn.Module):
             warnings.warn("SetCriterion: the device criterion (csrc/criterion.hip) does not apply to these inputs; "
                           "using the torch-operator path (see SetCriterion._fused_tables for the conditions)")
         if tables is not None:
-            if is_dist_avail_and_initialized():     # the reference's collective (criterion.py:258-260); its result is
+            if is_dist_avail_and_initialized() and _NUM_MASKS_ALLREDUCE:   # the reference's collective (criterion.py:258-260); its result is
                 # never used by the losses (loss_masks overwrites num_masks, :189), so nobody waits for it here
-                nm = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float, device=tables[0].device)
+                # (a fill launch, not torch.as_tensor(list, device=...): that is a copy from pageable host memory, which
+                #  makes the HOST wait for everything queued on the stream — in the middle of the step.  Measured with a
+                #  one-rank RCCL group, bench.py --force-dist: 26.3-26.6 ms per step with it, 23.8 without, round 6)
+                nm = torch.full((1,), float(sum(len(t["labels"]) for t in targets)), dtype=torch.float, device=tables[0].device)
                 torch.distributed.all_reduce(nm)
             logits = torch.stack([lv["pred_logits"] for lv in levels])                       # [L,B,Q,C]
             flat = _FusedCriterion.apply(self, targets, mask_type, logits, *tables)

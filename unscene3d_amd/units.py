@@ -44,7 +44,7 @@ LANE_WS_BYTES = 192 << 20
 # the walk reaches a map with <= LANE_RELEASE_ROWS rows and run beside the coarse levels' latency-bound chain instead
 # of beside the fine levels' input gradients.  USC3D_LANE_RELEASE_ROWS=0 switches the schedule off.
 LANE_HOLD_MIN_ROWS = int(os.environ.get("USC3D_LANE_HOLD_MIN_ROWS", "24576"))
-LANE_RELEASE_ROWS = int(os.environ.get("USC3D_LANE_RELEASE_ROWS", "12000"))
+LANE_RELEASE_ROWS = int(os.environ.get("USC3D_LANE_RELEASE_ROWS", "3000"))
 SAME, DOWN, UP = 0, 1, 2
 # Grouped weight gradients (usc_spconv_wgrad_group): the stride-1 convolutions of one level's residual blocks have the
 # same shape on the same kernel map; their weight gradients are off the backward pass's critical chain (nothing reads
