@@ -407,36 +407,9 @@ def test_avgpool_gather_segment_mean(device):
     assert rel_err(m.detach(), mr.detach()) < 1e-5 and rel_err(fd.grad, fr.grad) < 1e-6
 
 
-def _fps_ref(xyz, m):
-    """numpy restatement of sampling_gpu.cu:73-176 incl. the tie-break (block size 512)."""
-    n = xyz.shape[0]
-    bs = 1
-    while bs * 2 <= n and bs < 512:
-        bs *= 2
-    tmp = np.full(n, 1e10, np.float32)
-    idx = np.zeros(m, np.int32)
-    mag = (xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1] + xyz[:, 2] * xyz[:, 2]).astype(np.float32)
-    ok = ~(mag <= np.float32(1e-3))
-    ks = np.arange(n)
-    old = 0
-    for j in range(1, m):
-        d = ((xyz - xyz[old]) ** 2).astype(np.float32)
-        d = (d[:, 0] + d[:, 1] + d[:, 2]).astype(np.float32)
-        d2 = np.minimum(d, tmp)
-        tmp = np.where(ok, d2, tmp)
-        cand = np.where(ok, d2, -np.inf)
-        best = cand.max()
-        if not np.isfinite(best):
-            old = 0
-        else:
-            tied = ks[cand == best]
-            old = int(tied[np.lexsort((tied, tied % bs))][0])
-        idx[j] = old
-    return idx
-
-
 @pytest.mark.parametrize("n,m", [(700, 20), (20000, 100), (300, 50)])
 def test_fps_bit_exact_with_ties(device, n, m):
+    from oracle import fps_ref
     from unscene3d_amd import ops
 
     rng = np.random.default_rng(n)
@@ -444,7 +417,7 @@ def test_fps_bit_exact_with_ties(device, n, m):
     xyz[0, 5] = 0.0                                                   # |p|^2 <= 1e-3 is skipped
     got = ops.furthest_point_sample(_dev(xyz, device), m).cpu().numpy()
     for b in range(2):
-        assert np.array_equal(got[b], _fps_ref(xyz[b], m))
+        assert np.array_equal(got[b], fps_ref.furthest_point_sample(xyz[b], m))
 
 
 def test_fourier_posenc(device):
