@@ -23,13 +23,6 @@ from types import SimpleNamespace
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# The caching allocator in expandable segments (set before torch's allocator reads its configuration; the caller's own
-# setting wins): with four streams and scenes of changing size the fixed-size segments fragmented — a 383 ms step among
-# 131 ms ones at 8 scenes per GPU, 55.1 -> 60.2 scenes/s with this setting (round 6, same box).  config.allocator in the
-# line says what was in force; unscene3d_amd.trainer documents the same setting for training runs.
-for _k in ("PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF"):
-    os.environ.setdefault(_k, "expandable_segments:True")
-
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -260,8 +253,12 @@ def make_mask3d_step(args, dev, rank, world):
         ahead = [prefetch._issue(sets[k % n_sets]) for k in range(args.prefetch_ahead)]
         torch.cuda.synchronize()
 
+    from unscene3d_amd.trainer.trainer import StepsInFlight
+    in_flight = StepsInFlight(int(os.environ.get("USC3D_STEPS_IN_FLIGHT", "2")))
+
     def step(w):
         state["k"] += 1
+        in_flight.begin()              # at most two steps queued on the device (trainer.StepsInFlight)
         if ahead:
             batch, done, _ = ahead.pop(0)
             torch.cuda.current_stream().wait_event(done)
@@ -290,6 +287,7 @@ def make_mask3d_step(args, dev, rank, world):
             flat.div_(w)
         opt.step()
         state["sched"].step()
+        in_flight.end()
         if prefetch is not None and not ahead and not getattr(args, "prefetch_ahead", 0):
             # the voxelisation + coordinate maps of the step after the next (depth 2), on the prefetch stream
             prefetch.submit(sets[(state["k"] + max(1, getattr(args, "prefetch_depth", 2)) - 1) % n_sets])
@@ -805,8 +803,14 @@ def main():
     else:
         step = make_mask3d_step(args, dev, rank, world)
 
-    for _ in range(args.warmup):
+    steady = None
+    for w in range(args.warmup):
         loss, nvox = step(world)
+        if w == max(0, args.warmup - 2) and args.mode == "mask3d" and os.environ.get("USC3D_STEADY", "1") == "1":
+            # the trainer's one-time preparation of the steady state (stream pools pre-sized from the high-water mark,
+            # interpreter heap frozen): before the LAST warm-up step, which refills the small-block pools
+            from unscene3d_amd.trainer.trainer import prepare_steady_state
+            steady = prepare_steady_state(dev)
     torch.cuda.synchronize()
     if multi and args.dist_backend == "nccl" and args.mode == "mask3d" and os.environ.get("USC3D_STREAM_RECHECK", "1") == "1":
         # RCCL's stream exists now (first collective done): do the lane and the key stream still run beside the compute
@@ -965,7 +969,7 @@ def main():
                                                                     if ref_order else "")), **(rot or {}), **({"rank_skew": skew} if skew else {}),
                        "loss": float(loss), "grad_allreduce": _allreduce_note(step, world),
                        "streams": _stream_report(),
-                       "allocator": os.environ.get("PYTORCH_HIP_ALLOC_CONF", ""),
+                       "steady_state": steady,
                        **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),

@@ -36,3 +36,39 @@ def test_training_steps_free_their_batch_without_the_cycle_collector(device, mon
         assert m1 - m0 < 4 * 2**20, f"allocated memory grew by {(m1 - m0) / 2**20:.1f} MB over 6 steps without gc"
     finally:
         step.close()
+
+
+def test_steady_state_preparation_keeps_the_step_bit_identical_and_out_of_the_driver_allocator(device, monkeypatch):
+    """trainer.prepare_steady_state: the pools are pre-sized and the interpreter heap frozen between two steps — the
+    trajectory must not change by a bit (same seeds, same scenes: compared with a run that never calls it), and the
+    steps after it must not grow the reserved memory (no hipMalloc in the steady state)."""
+    import bench
+    from unscene3d_amd.trainer.trainer import prepare_steady_state
+
+    monkeypatch.setenv("USC3D_PREFETCH_THREAD", "0")
+
+    def run(prepare):
+        torch.manual_seed(7)
+        args = bench.parse(["--no-cpu-baseline", "--voxels", "20000", "--rotate", "0"])
+        step = bench.make_mask3d_step(args, device, 0, 1)
+        losses, info, reserved = [], None, None
+        try:
+            for k in range(6):
+                if k == 2 and prepare:
+                    info = prepare_steady_state(device)
+                losses.append(step(1)[0])
+                if k == 3:
+                    torch.cuda.synchronize()
+                    reserved = torch.cuda.memory_reserved()
+            torch.cuda.synchronize()
+            return torch.stack(losses).cpu(), info, reserved, torch.cuda.memory_reserved()
+        finally:
+            step.close()
+            gc.unfreeze()
+
+    with_prep, info, r3, r5 = run(True)
+    without, _, _, _ = run(False)
+    assert torch.equal(with_prep, without), (with_prep, without)
+    assert info["streams"] >= 2 and info["frozen_objects"] > 1000
+    assert info["reserved_after"] >= info["main_bytes"] + (info["streams"] - 1) * info["side_bytes"]
+    assert r5 == r3, f"reserved memory grew from {r3} to {r5} bytes after the pools had been pre-sized"

@@ -66,3 +66,19 @@ def test_attention_and_layernorm_workspaces():
     assert lib.usc_attn_ws_bytes(100, 12800, 1, 8) >= lib.usc_attn_ws_bytes(100, 200, 1, 8)
     assert lib.usc_layernorm_bwd_ws_bytes(100, 128) == 0                # one workgroup: no partials
     assert lib.usc_layernorm_bwd_ws_bytes(5000, 128) == 5 * 2 * 128 * 4
+
+
+def test_steady_state_preparation_on_a_host_device_only_freezes_the_heap():
+    """trainer.prepare_steady_state(cpu): no stream pools to size; the interpreter heap is frozen (and thawed here)."""
+    import gc
+
+    import torch
+
+    from unscene3d_amd.trainer.trainer import prepare_steady_state
+    before = gc.get_freeze_count()
+    try:
+        out = prepare_steady_state(torch.device("cpu"))
+        assert "main_bytes" not in out and out["frozen_objects"] > before
+        assert prepare_steady_state(torch.device("cpu"), freeze_heap=False) == {}
+    finally:
+        gc.unfreeze()

@@ -23,8 +23,11 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     step = bench.make_mask3d_step(args, dev, 0, 1)
-    for _ in range(8):
+    for w in range(8):
         step(1)
+        if w == 1 and os.environ.get("USC3D_STEADY", "1") == "1":
+            from unscene3d_amd.trainer.trainer import prepare_steady_state
+            print("steady state:", prepare_steady_state(dev), file=sys.stderr)
     torch.cuda.synchronize()
     torch.cuda.reset_peak_memory_stats()
     marks, losses, mem = [], [], []

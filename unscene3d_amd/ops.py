@@ -180,6 +180,13 @@ def _conv_cost(P, n_in, n_out, K, cin, cout):
     return 2.0 * P * cin * cout, 4.0 * (n_in * cin + n_out * cout + K * cin * cout) + 8.0 * P
 
 
+def _sorted_symbol(cout):
+    """The mask-sorted kernel's template instance for this output width (plan_sorted, csrc/spconv_sorted.hip)."""
+    cb = cout // 32
+    nb = 4 if cb % 4 == 0 else 3 if cb % 3 == 0 else 2 if cb % 2 == 0 else 1
+    return f"usc::gather_gemm_sorted_kernel<{nb}, {4 if nb == 4 else 8}>"
+
+
 def _kernel_symbol(kind, n, cin, cout, K):
     """rocprof-style symbol of the kernel a launch will use (usc_spconv_plan)."""
     code = lib.usc_spconv_plan(kind, int(n), cin, cout, K)
@@ -271,7 +278,9 @@ def gather_gemm(feats, W, nbr, n_out, bias=None, out=None, accumulate=False, w_t
         perm, tmask = rowsort(nbr)
         wsb = lib.usc_spconv_sorted_ws_bytes(n_out, cin, cout, K)
         ws = _ws(wsb, feats.device) if wsb > 0 else None
-        with _prof.maybe(lambda: f"usc::gather_gemm_sorted_kernel" + (f" [n={n_out} cin={cin} cout={cout} K={K}]" if _prof.SHAPES else ""),
+        # (named per template instance like every other kernel of the capture — the way rocprofv3 lists them: the merged
+        #  family once overtook the tile-compacted kernel as "dominant" by 0.2 ms between two boxes)
+        with _prof.maybe(lambda: _sorted_symbol(cout) + (f" [n={n_out} cin={cin} cout={cout} K={K}]" if _prof.SHAPES else ""),
                          lambda: _conv_cost(_prof.table_pairs(nbr), feats.shape[0], n_out, K, cin, cout)):
             check(lib.usc_spconv_sorted_gemm(_ptr(feats), feats.shape[0], cin, _ptr(W), K, cout, _ptr(nbr), _ptr(perm),
                                              _ptr(tmask), n_out, _ptr(bias), _ptr(out), int(accumulate),

@@ -17,6 +17,86 @@ from ..models.mask3d import SINGLE_POINT_ERROR
 from ..models.matcher import HungarianMatcher
 
 
+def prepare_steady_state(device, main_factor: float = 1.75, side_bytes: int = 768 << 20, min_main_bytes: int = 3 << 30,
+                         freeze_heap: bool = True) -> dict:
+    """Call ONCE, after the first one or two training steps (every second stream has been picked, the decoder passes are
+    captured, the step's high-water mark is known) and before the run's steady state.
+
+    * Memory.  The step allocates from four stream pools of torch's caching allocator (compute stream, weight-gradient
+      lane, key-preparation stream, prefetcher) and the scenes differ in size, so every new largest scene grew a pool by
+      a `hipMalloc` in the middle of a step: 384 ms steps among 132 ms ones at eight scenes per GPU, 26-37 ms steps
+      among 23.7 ms ones at one (round 5: `profiles/r05_soak.json`, `r05_scenes_per_gpu.txt`), and 22 GB reserved for
+      5.7 GB in use.  Here the cached segments are handed back once (`empty_cache`, a device synchronise) and every pool
+      gets ONE block — `main_factor` x the peak allocation so far on the compute stream, `side_bytes` on each second
+      stream — which is freed at once and stays cached: the allocator carves later requests out of it instead of asking
+      the driver.  MI355X has 288 GB; a training process should never be inside `hipMalloc` after its first steps.
+    * Interpreter heap.  The module tree, the plans and the captured graphs are ~10^5 container objects that live for
+      the whole run; every generation-2 pass of CPython's cycle collector walks them (a multi-millisecond pause on the
+      thread that issues the step).  `gc.freeze()` moves what exists now out of the collector's sight; the per-step
+      garbage (autograd nodes, lists of tensors) is still collected.
+
+    Reference counterpart: none — the reference trains through PyTorch-Lightning's loop on one stream
+    (trainer/trainer.py:99-163) with DataLoader worker PROCESSES (conf/data/indoor.yaml:24-25).
+    -> what was done: {"main_bytes", "side_bytes", "streams", "reserved_before", "reserved_after", "frozen_objects"}."""
+    import gc
+
+    from .. import streams
+    device = torch.device(device)
+    out = {}
+    if device.type == "cuda":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(idx):
+            torch.cuda.synchronize()
+            peak = torch.cuda.max_memory_allocated()
+            out["reserved_before"] = torch.cuda.memory_reserved()
+            torch.cuda.empty_cache()
+            main_bytes = max(int(min_main_bytes), int(main_factor * peak))
+            main = torch.cuda.current_stream()
+            side = [s for (d, _), s in streams._PICKED.items() if d == idx and s.cuda_stream != main.cuda_stream]
+            for st, nbytes in [(main, main_bytes)] + [(s, int(side_bytes)) for s in side]:
+                with torch.cuda.stream(st):
+                    block = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                    del block                    # back to the stream's pool (nothing was launched on it)
+            torch.cuda.synchronize()
+            out.update(main_bytes=main_bytes, side_bytes=int(side_bytes), streams=1 + len(side),
+                       reserved_after=torch.cuda.memory_reserved())
+    if freeze_heap:
+        gc.collect()
+        gc.freeze()
+        out["frozen_objects"] = gc.get_freeze_count()
+    return out
+
+
+class StepsInFlight:
+    """At most `depth` training steps queued on the device: `begin()` in front of a step waits (interpreter lock released)
+    until the step issued `depth` steps ago has finished, `end()` behind the optimizer step marks this one.
+
+    The loop never reads a loss back, so nothing else bounds the host: it issues a 150 k-voxel step in 14-19 ms, the
+    device needs 23.7, and every step the host ran 5-10 ms further ahead.  The caching allocator paid for it: a block
+    that a SECOND stream has read (`record_stream`: the prefetched batch, the feature maps the key-preparation stream
+    samples, what the weight-gradient lane holds) is not reusable before that stream has passed the free, so with the
+    host seconds ahead every pool kept several steps' worth of such blocks — 22-24 GB reserved for 5.7 GB in use, grown by
+    a `hipMalloc` inside a step whenever the lead reached a new maximum (the 37-104 ms steps of the soak runs,
+    `profiles/r05_soak.json`, `r06_soak_ab.txt`).  Two steps in flight keep the device fed — it always has a whole step
+    queued — and bound what the pools must hold.  The reference's loop is bounded by construction: 52 `.cpu().item()`
+    read-backs per step (trainer/trainer.py:149).  depth <= 0: unbounded (the behaviour up to round 5)."""
+
+    def __init__(self, depth: int = 2):
+        import collections
+        self.depth = int(depth)
+        self._marks = collections.deque()
+
+    def begin(self):
+        while self.depth > 0 and len(self._marks) >= self.depth:
+            self._marks.popleft().synchronize()
+
+    def end(self, stream=None):
+        if self.depth > 0:
+            ev = torch.cuda.Event()
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            self._marks.append(ev)
+
+
 class InstanceSegmentation(nn.Module):
     def __init__(self, config):
         super().__init__()
