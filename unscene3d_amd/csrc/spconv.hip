@@ -583,6 +583,13 @@ __global__ __launch_bounds__(64 * kCompactWaves, 4) void gather_gemm_compact_ker
 #endif
 
   // ---- epilogue: coalesced copy of the tile to HBM
+  // (Round 6, measured and not kept: in this loop the compiler waits for `vmcnt(0)` at the join of the bias / accumulate
+  //  branches, i.e. for the previous iteration's store — a bias-free loop of its own without that wait, and the prologue's
+  //  sixteen table loads made unconditional so that all of them are in flight at once, took the write-back from 47.6 k to
+  //  37.1 k and the prologue from 30.1 k to 27.4 k cycles of a 579 k-cycle tile in the phase-counting build, bit-identical
+  //  outputs — and the uninstrumented kernel did not move: 490 / 493 vs 501 / 505 us on 96 -> 96 x 148 564 rows, 23.4 / 24.0 /
+  //  23.4 vs 23.5 / 24.3 / 23.6 ms per step.  The co-resident workgroup's matrix-core work already covers these phases.  The
+  //  same goes for the ordered section as 48 fire-and-forget ds_add_f32 per lane: bit-identical and 2.5x slower, 1 238 us.)
   for (int e = threadIdx.x; e < TM * BN / 4; e += NT) {
     const int lr = e / (BN / 4), c4 = e - lr * (BN / 4);
     const int64_t row = r0 + lr;

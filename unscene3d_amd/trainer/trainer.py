@@ -30,6 +30,11 @@ def prepare_steady_state(device, main_factor: float = 1.75, side_bytes: int = 76
       gets ONE block — `main_factor` x the peak allocation so far on the compute stream, `side_bytes` on each second
       stream — which is freed at once and stays cached: the allocator carves later requests out of it instead of asking
       the driver.  MI355X has 288 GB; a training process should never be inside `hipMalloc` after its first steps.
+      Measured together with `StepsInFlight(2)` over 400 steps on eight scenes of 119 k ... 178 k voxels
+      (`profiles/r06_inflight_ab.txt`): reserved memory flat at 14.5 GB from the call on (23-24 GB and still growing
+      without the bound on the steps in flight), p50 / p99 / max 23.7-24.0 / 26.5 / 27.2-27.6 ms; with factors of
+      1.4 / 512 MB the pools grew once more (11.8 -> 11.9 GB, max 29.8 ms); without this call (bound alone) 11.2 GB
+      reserved and a 91 ms step while the pools found their size.
     * Interpreter heap.  The module tree, the plans and the captured graphs are ~10^5 container objects that live for
       the whole run; every generation-2 pass of CPython's cycle collector walks them (a multi-millisecond pause on the
       thread that issues the step).  `gc.freeze()` moves what exists now out of the collector's sight; the per-step
