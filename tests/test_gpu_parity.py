@@ -1162,11 +1162,23 @@ def test_decoder_graph_capture_equals_eager(device, level_embed, sample_sizes, v
     graphed = InstanceSegmentation(cfg).to(device).train()
     graphed.load_state_dict(eager.state_dict())
     graphed.model.enable_decoder_graphs(batch_size=scenes, device=device)
+    from unscene3d_amd import graphs
     results = []
     for module in (eager, graphed):
         module.model.randperm = _PermSource()
         total, weighted = module.training_step(collate(batch))
+        graphs.STATS.update(grad_buffer_hits=0, grad_out_copies=0)
         total.backward()
+        if module is graphed:
+            # the gradient of a captured pass's output is produced by the decoder norm's backward (ops.layer_norm,
+            # passthrough) straight into the buffer the pass's backward graph reads: no copy in front of any replay
+            # (round-5 advice: this path existed and never fired — the registry compared a 3-D buffer's shape with the
+            # norm's [rows, d] view)
+            # Several scenes per batch: the pass output is a permuted view ([Q, B, d] storage), the norm works on a
+            # contiguous copy of it, and the gradient is copied in front of each replay as before.
+            n = module.model.num_decoders * module.model.num_levels
+            want = {"grad_buffer_hits": n, "grad_out_copies": 0} if scenes == 1 else {"grad_buffer_hits": 0, "grad_out_copies": n}
+            assert graphs.STATS == want, graphs.STATS
         g = torch.cat([p.grad.reshape(-1) for n, p in module.named_parameters()
                        if p.grad is not None and "backbone" not in n])
         results.append((float(total.detach()), g.clone()))

@@ -13,6 +13,8 @@ does not change after capture — use `optimizer.zero_grad(set_to_none=False)` (
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 # "thread_local": other threads of the process (the RCCL watchdog polls events while a multi-GPU job captures) may
@@ -65,13 +67,22 @@ class _Runner:
 # The operator that produces that gradient (the decoder's LayerNorm over the pass output, ops._LayerNorm.backward) asks
 # here and writes straight into the buffer: no copy in front of the backward replay (12 per training step).
 _GRAD_OUT_BUFFERS = {}
+STATS = {"grad_buffer_hits": 0, "grad_out_copies": 0}      # counted per backward replay (tests; tools)
+_GRAD_BUFFER_PASSTHROUGH = os.environ.get("USC3D_GRAD_BUFFER_PASSTHROUGH", "1") == "1"
 
 
 def grad_buffer_for(t):
-    """-> the static output-gradient buffer of the captured pass whose output buffer `t` is, or None."""
-    hit = _GRAD_OUT_BUFFERS.get((t.device.index, t.data_ptr()))
-    if hit is None or hit.shape != t.shape or hit.dtype != t.dtype or not hit.is_contiguous():
+    """-> the static output-gradient buffer of the captured pass whose output buffer `t` is (as stored, same element
+    order as the pass output), or None.  `t` may be any contiguous VIEW of the output (the LayerNorm works on
+    [rows, d]): what has to agree is the element count, the dtype and that both are dense in the same order — a
+    buffer with permuted strides (several scenes per batch) is not handed out."""
+    if not _GRAD_BUFFER_PASSTHROUGH:
         return None
+    hit = _GRAD_OUT_BUFFERS.get((t.device.index, t.data_ptr()))
+    if (hit is None or hit.numel() != t.numel() or hit.dtype != t.dtype or not hit.is_contiguous()
+            or not t.is_contiguous()):
+        return None
+    STATS["grad_buffer_hits"] += 1
     return hit
 
 
@@ -112,6 +123,7 @@ class _GraphedFn(torch.autograd.Function):
         r = ctx.runner
         r.check_param_grads()
         if r.static_grad_out.data_ptr() != g.data_ptr():
+            STATS["grad_out_copies"] += 1
             r.static_grad_out.copy_(g)
         r.bwd_graph.replay()
         r.live = False

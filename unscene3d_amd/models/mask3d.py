@@ -143,6 +143,8 @@ class Mask3D(nn.Module):
         (checked per call; otherwise the eager path runs).  Weights stay shared: the graphs read the live
         parameter tensors and add their gradients straight into `p.grad` (unscene3d_amd/graphs.py), so gradient
         buffers must stay allocated: `optimizer.zero_grad(set_to_none=False)`."""
+        from ..graphs import forget_grad_buffers
+        forget_grad_buffers()          # a re-capture must not leave the old passes' buffers registered (stale pointers)
         passes, samples = [], []
         sizes = self.backbone.PLANES[-5:]
         B, Q, d = batch_size, self.num_queries, self.mask_dim
@@ -416,7 +418,10 @@ class Mask3D(nn.Module):
                          and self.num_queries <= 128)
 
                 # ---- query-independent half (side stream): rows of the level's features -> keys, values
-                if use_side:
+                # (the non-fused gather indexes per-scene slices that a compute-stream kernel may only just have produced —
+                #  after `ready` — and that no stream record covers: it stays on the compute stream; round-5 advice)
+                on_side = use_side and fused
+                if on_side:
                     # geometry tensors come from the prefetch stream's pool and are released as soon as the host has
                     # ISSUED their last reader (autograd drops a node's saved tensors after running it): the allocator
                     # must know that this stream reads them too, or the next scene's prefetch overwrites the indices
@@ -424,21 +429,18 @@ class Mask3D(nn.Module):
                     for t in (plan["gidx"], samples["pos_keys"][pidx], feats_l):
                         if t is not None and t.is_cuda:
                             t.record_stream(side)
-                with (torch.cuda.stream(side) if use_side else contextlib.nullcontext()):
+                with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
                     if fused:
                         batched_aux = ops.sample_keys(
                             feats_l.contiguous(), None, None, plan["gidx"], n_scenes, curr_sample_size, n_valid,
                             unique=plan["all_sampled"], valid_unique=True,       # (the plan's keys: distinct rows, then masked padding)
                             sink=sinks.setdefault((hlevel, bool(plan["all_sampled"])), ops.GradSink()) if _GRAD_SINKS else None)
                     else:
-                        if use_side:
-                            for t in rand_idx:
-                                t.record_stream(side)
                         batched_aux = _stack([ops.gather_rows(decomposed_aux[k].contiguous(), rand_idx[k],
                                                               unique=sizes[k] > curr_sample_size) for k in range(n_scenes)])
                     k_keys, v_keys = self._key_prep(dec, i)(batched_aux, samples["pos_keys"][pidx],
                                                             outs=None if bufs is None else (bufs[2], bufs[3]))
-                    if use_side:
+                    if on_side:
                         kv_done = torch.cuda.Event()
                         kv_done.record(side)
                         if bufs is None:               # fresh tensors of the side stream's pool, read on the compute stream
@@ -469,7 +471,7 @@ class Mask3D(nn.Module):
                 rec = getattr(self, "attn_mask_record", None)
                 if rec is not None:          # parity tests: the thresholded masks are discrete decisions
                     rec.append(batched_attn.detach().clone())
-                if use_side:
+                if on_side:
                     main.wait_event(kv_done)
                 queries = step_fn(queries, query_pos, k_keys, v_keys, batched_attn.contiguous())
 

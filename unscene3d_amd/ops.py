@@ -1021,10 +1021,12 @@ class _LayerNorm(torch.autograd.Function):
         dy2 = dy.contiguous().view(rows, d)
         dadd = None if dpass is None else dpass.contiguous().view(rows, d)
         # x is the output buffer of a captured decoder pass: its gradient goes straight into the buffer the pass's
-        # backward graph reads (graphs.grad_buffer_for), which saves the copy in front of the replay
+        # backward graph reads (graphs.grad_buffer_for), which saves the copy in front of the replay.  Safe whether or
+        # not this norm is x's only consumer: if autograd has to add another consumer's gradient, the sum is a new
+        # tensor and _GraphedFn.backward copies it over what was written here before it replays.
         from .graphs import grad_buffer_for
-        buf = grad_buffer_for(x2) if getattr(ctx, "passthrough", False) else None
-        dx = buf.view(rows, d) if buf is not None and buf.numel() == x2.numel() else torch.empty_like(x2)
+        buf = grad_buffer_for(x2)
+        dx = buf.view(rows, d) if buf is not None else torch.empty_like(x2)
         tg, tb = _grad_target(ctx.w_param), _grad_target(ctx.b_param)
         in_place = tg is not None and tb is not None
         dgamma = tg if in_place else torch.empty_like(weight)
