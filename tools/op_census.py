@@ -51,8 +51,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--voxels", type=int, default=150_000)
     ap.add_argument("--top", type=int, default=120)
+    ap.add_argument("--graphs", action="store_true",
+                    help="the step as bench.py runs it (decoder passes captured): what is listed is then the eager glue "
+                         "BETWEEN the replays — the operators inside a captured pass never reach the dispatcher")
     a = ap.parse_args()
-    args = bench.parse(["--voxels", str(a.voxels), "--no-graphs", "--no-prefetch", "--rotate", "0"])
+    args = bench.parse(["--voxels", str(a.voxels), "--no-prefetch", "--rotate", "0"] + ([] if a.graphs else ["--no-graphs"]))
     dev = torch.device("cuda:0")
     step = bench.make_mask3d_step(args, dev, 0, 1)
     for _ in range(3):
