@@ -115,7 +115,12 @@ class _GraphedFn(torch.autograd.Function):
                 s._usc_holds = (a, a._version)  # (keeps `a` alive: its storage cannot be handed to another tensor)
         runner.fwd_graph.replay()
         ctx.runner = runner
-        runner.live = torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad for a in inputs)
+        # (grad mode is OFF inside Function.forward, so torch.is_grad_enabled() says nothing here — up to round 5 this
+        #  flag was therefore never set and the chained-input guard above could not fire; needs_input_grad is what tells
+        #  whether a backward through this replay can follow.  Round 6 also measured the passes summing query_pos's
+        #  gradient inside their backward graphs instead of autograd's 11 eager adds per step: same bits, 23.33 / 23.38 /
+        #  23.35 vs 23.30 / 23.32 / 23.23 ms per step — an add is a kernel either way; not kept.)
+        runner.live = any(ctx.needs_input_grad[1:])
         return runner.static_out.detach()
 
     @staticmethod
