@@ -1290,6 +1290,30 @@ def test_decoder_graphs_refuse_parameters_moved_after_capture(device):
         fn(x)
 
 
+def test_chained_graph_pass_refuses_a_foreign_input_while_the_previous_output_is_live(device):
+    """capture_passes(chain_input=0): pass 1 reads pass 0's output buffer in place.  Handing pass 1 ANOTHER tensor would
+    make the replay copy it over that buffer — which pass 0's autograd consumers still need for this step's backward:
+    refused.  (The flag behind this guard was computed from torch.is_grad_enabled() inside Function.forward, where grad
+    mode is always off, and never fired before round 6.)  Without gradients in play the same call is an ordinary copy."""
+    from unscene3d_amd.graphs import capture_passes
+
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(32, 32).to(device), torch.nn.Linear(32, 32).to(device)
+    x = torch.randn(8, 32, device=device, requires_grad=True)
+    f0, f1 = capture_passes([a, b], [(x,), (torch.zeros(8, 32, device=device, requires_grad=True),)], chain_input=0)
+    y0 = f0(x)
+    y1 = f1(y0)                                  # the chain as captured: no copy, fine
+    (y0.sum() + y1.sum()).backward()
+    other = torch.randn(8, 32, device=device, requires_grad=True)
+    y0 = f0(x)
+    with pytest.raises(RuntimeError, match="still needed by this step's backward"):
+        f1(other)
+    with torch.no_grad():                        # nothing live: a foreign input is simply copied in
+        y0 = f0(x)
+        y1 = f1(other)
+        assert torch.allclose(y1, b(other), atol=1e-5)
+
+
 def test_scene_prefetcher_hands_over_prepared_batches(device):
     """submit() on the side stream, take() on the compute stream: coordinates, features and the prepared pyramid are
     those of a plain collate + SparseTensor; take() without submit() is an error."""

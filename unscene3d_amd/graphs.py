@@ -116,11 +116,12 @@ class _GraphedFn(torch.autograd.Function):
         runner.fwd_graph.replay()
         ctx.runner = runner
         # (grad mode is OFF inside Function.forward, so torch.is_grad_enabled() says nothing here — up to round 5 this
-        #  flag was therefore never set and the chained-input guard above could not fire; needs_input_grad is what tells
-        #  whether a backward through this replay can follow.  Round 6 also measured the passes summing query_pos's
+        #  flag was therefore never set and the chained-input guard above could not fire; whether a backward through this
+        #  replay can follow is decided where the pass is CALLED (grad mode on and an input that requires a gradient;
+        #  ctx.needs_input_grad ignores no_grad()).  Round 6 also measured the passes summing query_pos's
         #  gradient inside their backward graphs instead of autograd's 11 eager adds per step: same bits, 23.33 / 23.38 /
         #  23.35 vs 23.30 / 23.32 / 23.23 ms per step — an add is a kernel either way; not kept.)
-        runner.live = any(ctx.needs_input_grad[1:])
+        runner.live = bool(getattr(runner, "next_live", False))   # set by GraphedPass.__call__, OUTSIDE the Function
         return runner.static_out.detach()
 
     @staticmethod
@@ -155,6 +156,8 @@ class GraphedPass:
         self.input_buffers = [s.detach() for s in runner.static_in]
 
     def __call__(self, *inputs):
+        self._runner.next_live = torch.is_grad_enabled() and any(isinstance(a, torch.Tensor) and a.requires_grad
+                                                                 for a in inputs)
         return _GraphedFn.apply(self._runner, *inputs)
 
 

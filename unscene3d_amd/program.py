@@ -144,7 +144,9 @@ def _plan(model):
 
 def _module_key(model):
     """Identity of every module the plan references: a conversion that swaps modules after the first forward pass (a
-    batch-norm conversion, a re-built block) must not be served the old plan, which holds the old modules' parameters."""
+    batch-norm conversion, a re-built block) must not be served the old plan, which holds the old modules' parameters.
+    (The cached plan keeps references to the modules it uses, so none of THEIR ids can be handed to a new object while
+    it is cached; ~30 us per call for the few hundred modules of the trunk — round-5 advice, left as it is.)"""
     return tuple(id(m) for m in model.modules())
 
 
