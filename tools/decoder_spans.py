@@ -98,6 +98,15 @@ def timed_call(obj, name, label):
     setattr(obj, name, wrapper)
 
 
+if step.prefetch is not None:              # where does the compute stream spend the time between the step's start and the backbone?
+    _take = step.prefetch.take
+
+    def take_marked(*a, **k):
+        mark("take0")
+        out = _take(*a, **k)
+        mark("take1")
+        return out
+    step.prefetch.take = take_marked
 timed_call(step.module, "training_step", "training_step (forward + criterion)")
 timed_call(torch.Tensor, "backward", "backward")
 timed_call(step.opt, "step", "optimizer")
@@ -118,7 +127,9 @@ for i in range(n):
     mark("t1")
 torch.cuda.synchronize()
 print(f"host time to issue a step: first after the synchronize {host[args.warmup]:.2f} ms, others {sum(host[args.warmup + 1:]) / max(1, n - args.warmup - 1):.2f} ms")
-rows = [("backbone forward", "bb0", "bb1"), ("decoder forward", "bb1", "dec_fwd_done"), ("criterion", "dec_fwd_done", "bwd0"),
+rows = [("step start -> prefetch.take() entered", "t0", "take0"), ("inside prefetch.take() (wait for the batch's event)", "take0", "take1"),
+        ("take() returned -> backbone forward entered", "take1", "bb0"),
+        ("backbone forward", "bb0", "bb1"), ("decoder forward", "bb1", "dec_fwd_done"), ("criterion", "dec_fwd_done", "bwd0"),
         ("criterion + decoder backward", "bwd0", "dec_bwd_done"), ("backbone backward", "dec_bwd_done", "bwd1"),
         ("reduce + optimizer", "bwd1", "t1"), ("step", "t0", "t1"),
         ("weight-gradient lane done AFTER the compute stream's last backward kernel by", "chain_done", "lane_done"),

@@ -28,8 +28,11 @@ if step.prefetch is not None:
             worker["wall"] += time.perf_counter() - w0
             worker["n"] += 1
     step.prefetch._issue = issue
-for _ in range(args.warmup):
+for w in range(args.warmup):
     step(1)
+    if w == 1 and os.environ.get("USC3D_STEADY", "1") == "1":
+        from unscene3d_amd.trainer.trainer import prepare_steady_state
+        prepare_steady_state(dev)
 torch.cuda.synchronize()
 worker.update(cpu=0.0, wall=0.0, n=0)
 c0, w0 = time.thread_time(), time.perf_counter()
