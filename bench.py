@@ -941,7 +941,8 @@ def main():
         q = lambda f: per[min(len(per) - 1, int(round(f * (len(per) - 1))))]
         rot = {"rotated_scene_sets": args.rotate, "rotate_spread": args.rotate_spread, "step_ms_p10": q(0.1), "step_ms_p50": q(0.5), "step_ms_p90": q(0.9),
                "step_ms_min": per[0], "step_ms_max": per[-1],
-               "step_ms_max_at": int(max(range(args.steps), key=lambda k: per_in_order[k]))}
+               "step_ms_max_at": int(max(range(args.steps), key=lambda k: per_in_order[k])),
+               **({"step_ms_all": [round(v, 2) for v in per_in_order]} if os.environ.get("USC3D_BENCH_STEP_LIST") else {})}
     skew = None
     if own_marks is not None and len(own_marks) == args.steps:
         # per-rank step-time skew: how long each rank's OWN work of a step took (step start -> backward queued, device

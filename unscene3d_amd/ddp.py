@@ -36,6 +36,8 @@ def all_reduce_mean_(flat, world_size: int):
 
 # USC3D_LANE_ORDERED_COLLECTIVES=0: the round-5 behaviour (the compute stream waits for the lane before every bucket)
 LANE_ORDERED_COLLECTIVES = os.environ.get("USC3D_LANE_ORDERED_COLLECTIVES", "1") == "1"
+# USC3D_EARLY_BUCKETS=0 (diagnostic): the reducer counts the reports but starts every bucket in finish()
+_EARLY_BUCKETS = os.environ.get("USC3D_EARLY_BUCKETS", "1") == "1"
 
 
 class BucketedGradReducer:
@@ -109,7 +111,7 @@ class BucketedGradReducer:
             if self.launched and self.launched[self.bucket_of[id(param)]]:
                 self._late = True        # the kernels of this write race with the bucket's collective already in flight
             from . import ops
-            if not (self.flat.is_cuda and ops.on_side_stream()):
+            if _EARLY_BUCKETS and not (self.flat.is_cuda and ops.on_side_stream()):
                 # (a report from the decoder's key-preparation stream only counts: a collective started here would be
                 # ordered behind THAT stream alone; the next report on the compute stream, or finish(), starts it)
                 self._advance()
@@ -181,7 +183,15 @@ class BucketedGradReducer:
         self.flat.div_(self.world)
         late_handle.wait()                       # stream-ordered for RCCL; a 4-byte host wait for gloo
         if self._late_flag.is_cuda:
-            host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            # ONE pinned allocation for the reducer's lifetime, used as a ring (a slot is read two steps after it was
+            # written).  Round 6: a fresh `torch.zeros(1).pin_memory()` per step asked the driver for pinned memory
+            # again whenever the caching host allocator's block was not yet released — every third or fourth step under a
+            # one-rank RCCL group — and a pinned-memory (un)map stalls the kernels in flight: 30-36 ms steps among 23.5 ms
+            # ones, +1.7 ms on the mean (`profiles/r06_world1_rccl_ab.txt`).
+            if getattr(self, "_late_ring", None) is None:
+                self._late_ring = torch.zeros(16, dtype=torch.float32).pin_memory()
+            slot = self._step_no % self._late_ring.numel()
+            host = self._late_ring[slot:slot + 1]
             host.copy_(self._late_flag, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
