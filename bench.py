@@ -282,9 +282,18 @@ def make_mask3d_step(args, dev, rank, world):
             state["marks"].append(ev)
         if reducer is not None:
             reducer.finish()           # RCCL over xGMI: what backward has not already started, then wait + average
-        elif w > 1:
-            dist.all_reduce(flat)      # one flat ~158 MB gradient buffer
+        elif w > 1 or getattr(args, "force_dist", False):
+            dist.all_reduce(flat)      # one flat ~158 MB gradient buffer (--force-dist: over the one-rank group too)
             flat.div_(w)
+            nd = int(os.environ.get("USC3D_DUMMY_COLLECTIVES", "0"))      # diagnostic: does the NUMBER of collectives per step matter?
+            if nd:
+                if os.environ.get("USC3D_DUMMY_SYNC"):
+                    for k in range(nd):
+                        dist.all_reduce(flat[k * 1024:(k + 1) * 1024])
+                else:
+                    hs = [dist.all_reduce(flat[k * 1024:(k + 1) * 1024], async_op=True) for k in range(nd)]
+                    for h in hs:
+                        h.wait()
         opt.step()
         state["sched"].step()
         in_flight.end()

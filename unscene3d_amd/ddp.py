@@ -119,25 +119,50 @@ class BucketedGradReducer:
     def _complete(self, b):
         return all(self.counts[i] >= self.expected[i] for i in self.members[b])
 
+    def _collective_stream(self):
+        """The stream a bucket's all-reduce is issued on: the decoder's key-preparation stream when there is one — it has a
+        hardware queue of its own (streams.pick) and is idle while the backbone's backward pass runs — else the lane."""
+        from . import ops, units
+        dev = self.flat.device
+        for st in ops.SIDE_STREAMS:
+            if st.device == dev:
+                return st
+        ent = units._LANE.get(dev.index if dev.index is not None else torch.cuda.current_device())
+        return None if ent is None else ent[0]
+
     def _launch(self, b):
         import torch.distributed as dist
         s, e = self.bounds[b]
         if self.flat.is_cuda:
-            # weight gradients queued on the lane stream (units.py) are not in this stream's order: the collective has to
-            # start behind BOTH.  Round 5 made the compute stream wait for the lane here — every bucket started during
-            # backward then serialised the lane's work into the input-gradient chain (a one-rank process group, bench.py
-            # --force-dist: 26.1-27.5 ms per step against 23.9).  Now the LANE waits for the compute stream (one event) and
-            # the collective is issued in the lane's order: RCCL's stream waits for the lane, the chain waits for nobody.
+            # A bucket's collective has to start behind the compute stream's gradient writes, the lane's (units.py) and the
+            # key-preparation stream's.  Round 5 made the compute stream wait for the lane here (every bucket then
+            # serialised the lane's work into the input-gradient chain: 26.1-27.5 ms per step against 23.9 with a one-rank
+            # group); the first half of round 6 issued `all_reduce(async_op=True)` in the lane's order.  Both used
+            # ProcessGroupNCCL's ASYNC path — its own stream and a Work object per collective — and with eight of those per
+            # step every third to sixth step took 30-36 ms instead of 23.5 (`profiles/r06_world1_rccl_steps.txt`: two async
+            # dummy collectives per step are enough to produce it, twenty synchronous ones are not).  A SYNCHRONOUS
+            # collective runs on the stream it is called on (torch >= 2.8) — no fifth stream next to the rank's four
+            # (DESIGN.md §3.13: more than four active hardware queues are time-sliced), no Work to retire: it is issued on a
+            # second stream that waits for one event of the compute stream and one of the lane, and nobody waits for IT
+            # until finish().
             from . import ops, units
             ops.join_side_streams()          # (the decoder's key-preparation stream writes lin_squeeze / in_proj gradients)
-            lane = units.lane_stream_behind_current(self.flat.device) if LANE_ORDERED_COLLECTIVES else None
-            if lane is not None:
-                with torch.cuda.stream(lane):
-                    self.handles.append(dist.all_reduce(self.flat[s:e], async_op=True))
+            cs = self._collective_stream() if LANE_ORDERED_COLLECTIVES else None
+            if cs is not None:
+                cur = torch.cuda.current_stream()
+                lane_ev = units.lane_event(self.flat.device)          # (releases weight gradients the lane still holds)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                cs.wait_event(ev)
+                if lane_ev is not None:
+                    cs.wait_event(lane_ev)
+                with torch.cuda.stream(cs):
+                    dist.all_reduce(self.flat[s:e])
+                self._on_stream = cs
                 self.launched[b] = True
                 return
             units.join_lane(self.flat.device)
-        self.handles.append(dist.all_reduce(self.flat[s:e], async_op=True))
+        dist.all_reduce(self.flat[s:e])
         self.launched[b] = True
 
     def _advance(self):
@@ -177,11 +202,12 @@ class BucketedGradReducer:
             self._late_flag = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
         self._late_flag.fill_(1.0 if self._late else 0.0)
         self._late = False
-        late_handle = dist.all_reduce(self._late_flag, op=dist.ReduceOp.MAX, async_op=True)
-        for h in self.handles:
-            h.wait()
+        cs = getattr(self, "_on_stream", None)
+        if cs is not None:                       # the buckets were reduced on a second stream: the compute stream joins it here
+            torch.cuda.current_stream().wait_stream(cs)
+            self._on_stream = None
+        dist.all_reduce(self._late_flag, op=dist.ReduceOp.MAX)      # stream-ordered for RCCL; a 4-byte host wait for gloo
         self.flat.div_(self.world)
-        late_handle.wait()                       # stream-ordered for RCCL; a 4-byte host wait for gloo
         if self._late_flag.is_cuda:
             # ONE pinned allocation for the reducer's lifetime, used as a ring (a slot is read two steps after it was
             # written).  Round 6: a fresh `torch.zeros(1).pin_memory()` per step asked the driver for pinned memory
