@@ -236,7 +236,9 @@ def make_mask3d_step(args, dev, rank, world):
         from unscene3d_amd.datasets.prefetch import ScenePrefetcher
         prefetch = ScenePrefetcher(collate, add_raw_coordinates=cfg.data.add_raw_coordinates, device=dev,
                                    precompute=module.model.precompute_geometry,
-                                   threaded=os.environ.get("USC3D_PREFETCH_THREAD", "1") == "1")
+                                   threaded=os.environ.get("USC3D_PREFETCH_THREAD", "1") == "1",
+                                   bounded_lifetime=(int(os.environ.get("USC3D_STEPS_IN_FLIGHT", "2")) > 0
+                                                     and os.environ.get("USC3D_BOUNDED_BATCHES", "1") == "1"))
         # the first batches, outside the timed region like the resident raw arrays.  Two in flight (the reference's
         # DataLoader default, prefetch_factor = 2): with one, every step began by waiting ~8 ms for the worker thread to
         # finish issuing the batch submitted a moment earlier — host time the 24 ms device step no longer hides
@@ -248,8 +250,7 @@ def make_mask3d_step(args, dev, rank, world):
     ahead = []
     if prefetch is not None and getattr(args, "prefetch_ahead", 0) > 0:
         from unscene3d_amd.datasets.prefetch import _record_streams
-        while prefetch.in_flight:
-            prefetch.take()
+        prefetch.drain()
         ahead = [prefetch._issue(sets[k % n_sets]) for k in range(args.prefetch_ahead)]
         torch.cuda.synchronize()
 
@@ -296,7 +297,9 @@ def make_mask3d_step(args, dev, rank, world):
                         h.wait()
         opt.step()
         state["sched"].step()
-        in_flight.end()
+        step_done = in_flight.end()
+        if prefetch is not None and prefetch.bounded:
+            prefetch.retire(step_done)     # the batch of this step may be released once the device is past this point
         if prefetch is not None and not ahead and not getattr(args, "prefetch_ahead", 0):
             # the voxelisation + coordinate maps of the step after the next (depth 2), on the prefetch stream
             prefetch.submit(sets[(state["k"] + max(1, getattr(args, "prefetch_depth", 2)) - 1) % n_sets])
@@ -308,8 +311,7 @@ def make_mask3d_step(args, dev, rank, world):
         re-issue the prefetched batch in the new order."""
         collate.spatial_sort = int(shift) if shift else False
         if prefetch is not None:
-            while prefetch.in_flight:
-                prefetch.take()
+            prefetch.drain()
             for j in range(max(1, getattr(args, "prefetch_depth", 2))):
                 prefetch.submit(sets[(state["k"] + j) % n_sets])
 

@@ -1314,6 +1314,47 @@ def test_chained_graph_pass_refuses_a_foreign_input_while_the_previous_output_is
         assert torch.allclose(y1, b(other), atol=1e-5)
 
 
+def test_scene_prefetcher_with_bounded_lifetime_keeps_a_batch_until_its_step_is_done(device):
+    """bounded_lifetime=True: no record_stream marks; a batch — with EVERY tensor reachable from it when it was issued,
+    also what the step pops out of it early (the decoder's key samples: dropped by Mask3D.forward once used, they were
+    freed while a two-rank run was still reading them and the losses came out NaN) — stays referenced until the event
+    handed to retire() has completed; a caller that never retires is told so."""
+    import weakref
+
+    from unscene3d_amd.datasets.prefetch import ScenePrefetcher
+    from unscene3d_amd.datasets.synthetic import SyntheticFreeMaskDataset
+    from unscene3d_amd.datasets.utils import FreeMaskVoxelizeCollate
+
+    sample = SyntheticFreeMaskDataset(n_scenes=1, target_voxels=6000, seed=5)[0]
+    collate = FreeMaskVoxelizeCollate(ignore_label=255, voxel_size=0.02, mode="train", device=device)
+    pre = ScenePrefetcher(collate, add_raw_coordinates=True, device=device, bounded_lifetime=True)
+    pre.submit([sample])
+    data, target, names = pre.take()
+    held = data._usc_held_tensors
+    assert len(held) > 20 and all(t.is_cuda for t in held)
+    probe = weakref.ref(data.sparse_tensor.F)
+    spin = torch.cuda.Stream(device=device)
+    gate = torch.cuda.Event()
+    with torch.cuda.stream(spin):
+        from unscene3d_amd._lib import check, lib
+        for _ in range(3):
+            check(lib.usc_spin(100000, 1, spin.cuda_stream), "usc_spin")  # ~0.3 s of device time in front of the event
+        gate.record(spin)
+    pre.retire(gate)
+    del data, target, held
+    assert probe() is not None, "the batch was released before its step's event had completed"
+    gate.synchronize()
+    pre.submit([sample])
+    pre.take()                                   # take() drops what has finished
+    assert probe() is None
+    for _ in range(5):
+        pre.submit([sample])
+        pre.take()
+    pre.submit([sample])
+    with pytest.raises(RuntimeError, match="retire"):
+        pre.take()
+
+
 def test_scene_prefetcher_hands_over_prepared_batches(device):
     """submit() on the side stream, take() on the compute stream: coordinates, features and the prepared pyramid are
     those of a plain collate + SparseTensor; take() without submit() is an error."""

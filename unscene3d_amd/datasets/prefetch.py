@@ -24,32 +24,37 @@ import torch
 from .. import MinkowskiEngine as ME
 
 
-def _record_streams(obj, stream, seen):
+def _record_streams(obj, stream, seen, collect=None):
     """record_stream(stream) on every HIP tensor reachable from obj (containers, object attributes, attributes hung
-    on tensors such as the cached row orders of a neighbour table)."""
+    on tensors such as the cached row orders of a neighbour table).  collect (a list): the tensors are appended to it
+    INSTEAD (bounded_lifetime: they are kept referenced until the device has finished their step — also the ones the
+    step itself lets go of early, like the decoder's key samples, which the model pops from the geometry once used)."""
     if obj is None or isinstance(obj, (int, float, str, bool, bytes, slice)) or id(obj) in seen:
         return
     seen.add(id(obj))
     if isinstance(obj, torch.Tensor):
         if obj.is_cuda:
-            obj.record_stream(stream)
+            if collect is not None:
+                collect.append(obj)
+            else:
+                obj.record_stream(stream)
         d = getattr(obj, "__dict__", None)
         if d:
-            _record_streams(d, stream, seen)
+            _record_streams(d, stream, seen, collect)
         return
     if isinstance(obj, dict):
         for v in obj.values():
-            _record_streams(v, stream, seen)
+            _record_streams(v, stream, seen, collect)
         return
     if isinstance(obj, (list, tuple, set, collections.deque)):
         for v in obj:
-            _record_streams(v, stream, seen)
+            _record_streams(v, stream, seen, collect)
         return
     d = getattr(obj, "__dict__", None)
     if d:
-        _record_streams(d, stream, seen)
+        _record_streams(d, stream, seen, collect)
     for name in getattr(type(obj), "__slots__", ()):
-        _record_streams(getattr(obj, name, None), stream, seen)
+        _record_streams(getattr(obj, name, None), stream, seen, collect)
 
 
 class ScenePrefetcher:
@@ -59,7 +64,7 @@ class ScenePrefetcher:
     `data.raw_coordinates` attached, ready for `InstanceSegmentation.training_step`."""
 
     def __init__(self, collate, add_raw_coordinates: bool = True, n_down: int = 4, ksize: int = 3, device="cuda",
-                 precompute=None, threaded: bool = False):
+                 precompute=None, threaded: bool = False, bounded_lifetime: bool = False):
         """precompute: optional `Mask3D.precompute_geometry` (bound method): the parameter-free, geometry-only part
         of the model's forward pass is then issued here as well.
         threaded: issue the batch from a worker thread (the reference's DataLoader workers, conf/data/indoor.yaml:24).
@@ -70,7 +75,15 @@ class ScenePrefetcher:
         use threaded=False (or hand the model its own `randperm` source).
         The ~6 ms of host time a 150 k-voxel batch takes to issue — about a third of it blocked in the count read-backs
         of the voxel unique / coordinate maps, which release the interpreter lock — then overlap with the main thread
-        issuing the step instead of extending it; submit() returns at once, take() joins."""
+        issuing the step instead of extending it; submit() returns at once, take() joins.
+        bounded_lifetime: the caller promises to call `retire(event)` after every step with an event that completes when
+        the DEVICE has finished the step on every stream (the mark of `trainer.StepsInFlight`: recorded on the compute
+        stream behind the end-of-backward joins of the lane and the key-preparation stream).  A batch is then kept
+        referenced — with every tensor reachable from it at issue time, also those the step lets go of early — until its step's event has completed, and no tensor of it is `record_stream`ed: a block freed after
+        that point is not in use anywhere, so it may go straight back to the prefetch stream's pool.  What that saves per
+        step: the walk over the batch's ~1 800 objects on the worker (1 ms), and on the main thread the release of the
+        batch of two steps ago, whose every marked block costs the allocator an event (0.6 ms inside take(), seen on
+        the compute stream as a wait at every step's start on a host-bound box; `profiles/r06_step_sections.txt`)."""
         self.collate, self.add_raw, self.n_down, self.ksize = collate, add_raw_coordinates, n_down, ksize
         self.precompute = precompute
         self.device = torch.device(device)
@@ -80,6 +93,8 @@ class ScenePrefetcher:
         self.consumer = torch.cuda.default_stream(self.device)      # the stream take() is normally called on
         self._pending = collections.deque()        # batches submitted and not yet taken, oldest first
         self._keep = collections.deque(maxlen=2)
+        self.bounded = bool(bounded_lifetime)
+        self._live = collections.deque()           # bounded_lifetime: [batch, event of its step or None] in take() order
         self._jobs = self._worker = None
         if threaded:
             self._jobs = queue.Queue()
@@ -151,7 +166,12 @@ class ScenePrefetcher:
         # the allocator must know that the consumer's stream reads these tensors too; done HERE (on the worker thread when
         # there is one: the walk over ~1 800 objects is 1 ms of the step's host time) for the stream the consumer normally
         # is; take() repeats it only for another stream
-        _record_streams(batch, self.consumer, set())
+        if self.bounded:
+            held = []
+            _record_streams(batch, None, set(), held)
+            batch[0]._usc_held_tensors = held          # travels with the batch; dropped with it (take() / retire())
+        else:
+            _record_streams(batch, self.consumer, set())
         return batch, done, self.consumer.cuda_stream
 
     def take(self):
@@ -166,7 +186,36 @@ class ScenePrefetcher:
         batch, done, recorded = pending
         main = torch.cuda.current_stream(self.device)
         main.wait_event(done)
+        if self.bounded:
+            self._drop_finished()
+            if len(self._live) >= 6:
+                raise RuntimeError("ScenePrefetcher(bounded_lifetime=True): retire(event) has not been called for the "
+                                   "last batches — their memory cannot be released safely")
+            self._live.append([batch, None])
+            return batch
         if main.cuda_stream != recorded:
             _record_streams(batch, main, set())
         self._keep.append(batch)
         return batch
+
+    def drain(self):
+        """Take and drop every batch still in flight (a change of configuration between measurement loops): nothing
+        consumed them, so they may go as soon as the prefetch stream has finished them."""
+        while self._pending:
+            self.take()
+            if self.bounded:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))      # behind take()'s wait for the batch's own event
+                self.retire(ev)
+
+    def retire(self, event):
+        """bounded_lifetime: `event` completes when the device has finished, on every stream, the step that consumed the
+        batch handed out by the last take()."""
+        for ent in self._live:
+            if ent[1] is None:
+                ent[1] = event
+        self._drop_finished()
+
+    def _drop_finished(self):
+        while self._live and self._live[0][1] is not None and self._live[0][1].query():
+            self._live.popleft()

@@ -96,10 +96,15 @@ class StepsInFlight:
             self._marks.popleft().synchronize()
 
     def end(self, stream=None):
+        """-> the step's event (None when unbounded): completes when the device has finished everything queued on the
+        compute stream up to here — call it behind the optimizer step, i.e. behind the end-of-backward joins of the
+        second streams (`ScenePrefetcher.retire` takes it)."""
         if self.depth > 0:
             ev = torch.cuda.Event()
             ev.record(stream if stream is not None else torch.cuda.current_stream())
             self._marks.append(ev)
+            return ev
+        return None
 
 
 class InstanceSegmentation(nn.Module):
