@@ -823,7 +823,10 @@ def main():
             from unscene3d_amd.trainer.trainer import prepare_steady_state
             steady = prepare_steady_state(dev)
     torch.cuda.synchronize()
-    if multi and args.dist_backend == "nccl" and args.mode == "mask3d" and os.environ.get("USC3D_STREAM_RECHECK", "1") == "1":
+    if multi and args.dist_backend == "nccl" and args.mode == "mask3d" and os.environ.get("USC3D_STREAM_RECHECK", "0") == "1":
+        # (Off by default since the step issues no ASYNCHRONOUS collective any more — the reducer's buckets and the
+        #  criterion's num_masks are synchronous all-reduces on the rank's own streams, ddp.py — so RCCL's internal stream
+        #  is not in play; the probe itself puts an asynchronous all-reduce in flight.  USC3D_STREAM_RECHECK=1:)
         # RCCL's stream exists now (first collective done): do the lane and the key stream still run beside the compute
         # stream with an all-reduce in flight?  A stream that does not is switched off (config.streams says so).
         from unscene3d_amd import streams
