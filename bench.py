@@ -374,7 +374,8 @@ def _stream_report():
 def _allreduce_note(step, world):
     red = getattr(step, "reducer", None)
     if world == 1 and red is None:
-        return None
+        import torch.distributed as dist
+        return "one flat buffer after backward (one-rank group)" if dist.is_available() and dist.is_initialized() else None
     if red is None:
         return "one flat buffer after backward"
     return (f"{len(red.bounds)} buckets of the flat buffer, {red.started_during_backward} started during backward "
