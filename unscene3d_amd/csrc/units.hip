@@ -438,7 +438,14 @@ static int conv_backward_impl(const usc_kmap* m, int32_t kind, const float* x, i
         hipEventRecord(lane->fork, as_stream(s)) == hipSuccess && hipStreamWaitEvent(lane->st, lane->fork, 0) == hipSuccess) {
       usc_stream_t ls = (usc_stream_t)lane->st;
       lane->dirty = true;
-      if (!m->nbr)
+      // the stem (3 -> 32 channels) keeps its table-form kernel on the lane too: it is the LAST weight gradient of the
+      // backward pass — the lane's tail, which the step waits for — and the pair-list kernel needs 110 us for it, the table
+      // form 57 (round 6: the lane branch used to send everything through usc_spconv_wgrad)
+      static const bool stem_table = !getenv("USC3D_STEM_KERNEL") || atoi(getenv("USC3D_STEM_KERNEL")) != 0;
+      const int64_t bt = usc_spconv_wgrad_table_ws_bytes(K, cin, cout);
+      if (stem_table && kind == USC_CONV_SAME && m->nbr && cin <= 4 && cout == 32 && K <= 32 && bt <= lane->ws_bytes)
+        rc = usc_spconv_wgrad_table(x, cin, dy, cout, m->nbr, K, sh.n_out, dW, 1, lane->ws, bt, ls);
+      else if (!m->nbr)
         rc = usc_spconv_wgrad(x, cin, dy, cout, 1, nullptr, nullptr, nullptr, sh.n_in, dW, 1, lane->ws, b, ls);
       else if (kind == USC_CONV_UP)
         rc = usc_spconv_wgrad(x, cin, dy, cout, K, m->pair_out, m->pair_in, m->koff, rows, dW, 1, lane->ws, b, ls);
