@@ -169,12 +169,14 @@ def test_prefetched_batches_give_the_same_training_trajectory():
 
 def test_one_rank_rccl_reducer_runs_the_real_exchange_and_changes_no_bit():
     """bench.py --force-dist: a ONE-rank RCCL process group on the one device this box has — the bucketed reducer (buckets
-    started during backward, issued in the weight-gradient lane's order), the criterion's num_masks all-reduce and RCCL's
-    own stream next to the step's four, exactly as on N ranks minus the wire (reference: DDP's bucket all-reduce,
-    main_instance_segmentation.py:86-92; models/criterion.py:258-260).  Averaging over one rank is the identity: the
-    loss after the steps has the bits of the plain run; the line says what was measured about the streams."""
-    def run(*extra):
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    started during backward as synchronous collectives on a second stream behind events of the compute stream and the
+    lane) and the criterion's num_masks all-reduce, exactly as on N ranks minus the wire (reference: DDP's bucket
+    all-reduce, main_instance_segmentation.py:86-92; models/criterion.py:258-260).  Averaging over one rank is the
+    identity: the loss after the steps has the bits of the plain run.  The stream probe under an ASYNCHRONOUS all-reduce
+    (streams.recheck_under_collective) is on request only — the step issues no asynchronous collective — and the line
+    says what it measured when asked."""
+    def run(*extra, **more_env):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), **more_env)
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--voxels", "40000",
                "--no-cpu-baseline", "--rotate", "0", "--no-zorder", *extra]
         out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -184,6 +186,8 @@ def test_one_rank_rccl_reducer_runs_the_real_exchange_and_changes_no_bit():
     assert forced["n_gpus"] == 1 and forced["config"]["loss"] == plain["config"]["loss"], (forced["config"]["loss"], plain["config"]["loss"])
     note = forced["config"]["grad_allreduce"]
     assert note and "buckets" in note and plain["config"]["grad_allreduce"] is None, note
-    roles = {r["role"] for r in forced["config"]["streams"]}
-    assert "wgrad-lane under an all-reduce" in roles, roles
+    assert "wgrad-lane under an all-reduce" not in {r["role"] for r in forced["config"]["streams"]}
     assert forced["config"]["rccl_ranks_seen"] == 1
+    probed = run("--force-dist", USC3D_STREAM_RECHECK="1")
+    assert "wgrad-lane under an all-reduce" in {r["role"] for r in probed["config"]["streams"]}
+    assert probed["config"]["loss"] == plain["config"]["loss"]

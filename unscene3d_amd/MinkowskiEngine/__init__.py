@@ -86,6 +86,7 @@ class CoordinateManager:
         self._cube = {}       # (ts, ksize) -> dict(nbr, rulebook)
         self._batch_rows = {}  # ts -> list of (start, end) per batch, or index lists
         self._sorted_input = None
+        self.single_scene = False   # set by whoever KNOWS the batch holds one scene (datasets.prefetch: len(samples) == 1)
         self._kmaps = {}      # ("cube", ts, ksize) / ("down", ts) / ("id", ts) -> units.KMapRef (native issue path)
 
     # -- maps
@@ -187,6 +188,9 @@ class CoordinateManager:
         """Row ranges of every scene in the map at tensor stride ts.  Rows are grouped by batch in every
         map this manager builds (first-occurrence order of batch-sorted input), so one bincount and one
         host read per level suffice; unsorted input falls back to index lists."""
+        if ts not in self._batch_rows and self.single_scene:
+            # one scene: every row of every map belongs to it — no bincount, no read-back (five of each per batch)
+            self._batch_rows[ts] = [slice(0, int(self._maps[ts].n))] if int(self._maps[ts].n) > 0 else []
         if ts not in self._batch_rows:
             b = self._maps[ts].coords[:, 0]
             if b.numel() == 0:

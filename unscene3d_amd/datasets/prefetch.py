@@ -154,6 +154,7 @@ class ScenePrefetcher:
                 raw = feats[:, -3:].contiguous()
                 feats = feats[:, :-3].contiguous()
             x = ME.SparseTensor(coordinates=data.coordinates, features=feats, device=self.device)
+            x.coordinate_manager.single_scene = len(samples) == 1
             x.coordinate_manager.prepare(x.tensor_stride[0], n_down=self.n_down, ksize=self.ksize)
             if self.precompute is not None and raw is not None and len(target) > 0:
                 ns = [t.get("num_segments") for t in target]
