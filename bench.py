@@ -231,6 +231,16 @@ def make_mask3d_step(args, dev, rank, world):
         from unscene3d_amd.ddp import BucketedGradReducer
         reducer = BucketedGradReducer(params, flat, world).install()     # ~24 MB buckets, started during backward
 
+    # optimizer in the backward pass (one rank, FlatAdamW): the trunk's parameters are stepped stage by stage, as their
+    # gradients become final, on the stream that is idle during the backbone's backward pass (optim.FlatAdamW.enable_early)
+    early_opt = None
+    if (world == 1 and not getattr(args, "force_dist", False) and not args.torch_adamw
+            and os.environ.get("USC3D_EARLY_OPTIMIZER", "1") == "1"):
+        from unscene3d_amd.models import mask3d as _m3d
+        if getattr(_m3d, "_KV_SIDE_STREAM", False):
+            early_opt = module.model._side_stream(dev)
+            opt.enable_early(early_opt)
+
     prefetch = None
     if not args.no_prefetch:
         from unscene3d_amd.datasets.prefetch import ScenePrefetcher
@@ -316,7 +326,12 @@ def make_mask3d_step(args, dev, rank, world):
                 prefetch.submit(sets[(state["k"] + j) % n_sets])
 
     step.set_spatial_sort = set_spatial_sort
-    step.close = (lambda: prefetch.close()) if prefetch is not None else (lambda: None)
+    def close():
+        if early_opt is not None:
+            opt.disable_early()            # (a module-level hook: the next step object of this process must not feed this optimizer)
+        if prefetch is not None:
+            prefetch.close()
+    step.close = close
     step.prefetch = prefetch
     step.scenes_per_rank = B
     step.skew_info = skew_info
@@ -1015,6 +1030,8 @@ def main():
                        "streams": _stream_report(),
                        "steady_state": steady,
                        "cpu_affinity": numa_cpus,
+                       "optimizer": ("FlatAdamW, the trunk's ranges stepped inside the backward pass (enable_early)"
+                                     if getattr(getattr(step, "opt", None), "_early_stream", None) is not None else "one launch after backward"),
                        **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,
             "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),

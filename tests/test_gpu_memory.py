@@ -72,3 +72,35 @@ def test_steady_state_preparation_keeps_the_step_bit_identical_and_out_of_the_dr
     assert info["streams"] >= 2 and info["frozen_objects"] > 1000
     assert info["reserved_after"] >= info["main_bytes"] + (info["streams"] - 1) * info["side_bytes"]
     assert r5 == r3, f"reserved memory grew from {r3} to {r5} bytes after the pools had been pre-sized"
+
+
+def test_optimizer_ranges_inside_the_backward_pass_keep_the_trajectory_bits(device, monkeypatch):
+    """optim.FlatAdamW.enable_early: the trunk's parameters are stepped stage by stage on the key-preparation stream while
+    the backward pass is still being issued; the same kernel on the same values — losses and final weights of four steps
+    equal those of the one-launch optimizer to the bit, and most of the parameters really did go early."""
+    import bench
+
+    monkeypatch.setenv("USC3D_PREFETCH_THREAD", "0")
+
+    def run(early):
+        monkeypatch.setenv("USC3D_EARLY_OPTIMIZER", "1" if early else "0")
+        args = bench.parse(["--no-cpu-baseline", "--voxels", "20000", "--rotate", "0"])
+        step = bench.make_mask3d_step(args, device, 0, 1)
+        try:
+            early_elems, orig = [], step.opt._launch
+
+            def counted(lo, hi, step_no):
+                if torch.cuda.current_stream().cuda_stream != torch.cuda.default_stream().cuda_stream:
+                    early_elems.append(hi - lo)
+                return orig(lo, hi, step_no)
+            step.opt._launch = counted
+            losses = [step(1)[0] for _ in range(4)]
+            torch.cuda.synchronize()
+            return torch.stack(losses).cpu(), step.opt.flat_param.clone().cpu(), sum(early_elems) / 4, step.opt.flat_param.numel()
+        finally:
+            step.close()
+
+    la, wa, n_early, n_all = run(True)
+    lb, wb, n_none, _ = run(False)
+    assert n_none == 0 and n_early > 0.8 * n_all, (n_early, n_all)
+    assert torch.equal(la, lb) and torch.equal(wa, wb)

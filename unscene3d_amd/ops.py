@@ -384,6 +384,17 @@ def _join_after_backward():
     torch.autograd.Variable._execution_engine.queue_callback(done)
 
 
+PARAMS_FINAL_HOOK = None  # callable(list of params), set by optim.FlatAdamW.enable_early: "every kernel that adds into the
+                          # gradients of THESE parameters this step has been queued (compute stream and lane) — nothing
+                          # else will" — only callers that know it by construction report (program.backward: a trunk
+                          # unit's parameters are written once per backward pass)
+
+
+def _params_final(params):
+    if PARAMS_FINAL_HOOK is not None and params:
+        PARAMS_FINAL_HOOK(params)
+
+
 def _grad_written(*params):
     _join_after_backward()
     if GRAD_WRITTEN_HOOK is not None:

@@ -428,12 +428,14 @@ class _Trunk(torch.autograd.Function):
                     unreported.extend(plist)
                 elif plist or unreported:
                     ops._grad_written(*unreported, *plist)   # finished stages are reported while the earlier ones are still issued
+                    ops._params_final(unreported + plist)    # ... and are final: each unit's parameters are written once
                     unreported = []
                 begin = end
             if holding:
                 check(lib.usc_wgrad_lane_hold(0, 0, 0, stream), "usc_wgrad_lane_hold")
                 if unreported:
                     ops._grad_written(*unreported)
+                    ops._params_final(unreported)
         except BaseException:
             if holding:
                 lib.usc_wgrad_lane_hold(-1, 0, 0, None)

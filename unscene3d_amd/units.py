@@ -141,14 +141,15 @@ def lane_stream_behind_current(device=None):
     return ent[0]
 
 
-def lane_event(device=None):
-    """An event behind every weight gradient queued on the lane so far (held ones are released first), or None without a
-    lane: what a gradient bucket's collective on another stream has to wait for (ddp.BucketedGradReducer._launch)."""
+def lane_event(device=None, release=True):
+    """An event behind every weight gradient queued on the lane so far (held ones are released first unless release=False),
+    or None without a lane: what a gradient bucket's collective on another stream has to wait for
+    (ddp.BucketedGradReducer._launch), or the early optimizer step of parameters whose gradients are final."""
     key = torch.cuda.current_device() if device is None or device.index is None else device.index
     ent = _LANE.get(key)
     if ent is None:
         return None
-    if lib.usc_wgrad_lane_holding():
+    if release and lib.usc_wgrad_lane_holding():
         check(lib.usc_wgrad_lane_hold(0, 0, 0, ops._stream()), "usc_wgrad_lane_hold")
     ev = torch.cuda.Event()
     ev.record(ent[0])
