@@ -415,13 +415,32 @@ def _pin_to_device_numa(dev):
             if part:
                 lo, _, hi = part.partition("-")
                 cpus.update(range(int(lo), int(hi or lo) + 1))
-        cpus &= os.sched_getaffinity(0)
-        if len(cpus) >= 8 and cpus != os.sched_getaffinity(0):
-            os.sched_setaffinity(0, cpus)
+        before = os.sched_getaffinity(0)
+        cpus &= before
+        if len(cpus) >= 8 and cpus != before:
+            _set_affinity_all_threads(cpus)
+            _pin_to_device_numa.before = before        # (the CPU baseline runs on the host's cores as it always did)
             return text
     except (OSError, ValueError, AttributeError):
         pass
     return None
+
+
+def _set_affinity_all_threads(cpus):
+    """sched_setaffinity works per THREAD: apply the mask to every thread the process has (the runtime's, the OpenMP pool's)."""
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            os.sched_setaffinity(int(tid), cpus)
+        except OSError:
+            pass
+
+
+def _unpinned(fn, *a):
+    """fn(*a) with the process's original CPU affinity (the oracle's legs use up to half of the host's threads)."""
+    before = getattr(_pin_to_device_numa, "before", None)
+    if before is not None:
+        _set_affinity_all_threads(before)
+    return fn(*a)
 
 
 def _device_id(dev):
@@ -1034,7 +1053,7 @@ def main():
                                      if getattr(getattr(step, "opt", None), "_early_stream", None) is not None else "one launch after backward"),
                        **({} if ranks_seen is None else ranks_seen)},
             "roofline": roof,
-            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.cpu_sample_voxels, args.mode),
+            "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else _unpinned(cpu_baseline, args.cpu_sample_voxels, args.mode),
         }
         print(json.dumps(line))
     if hasattr(step, "close"):
