@@ -579,9 +579,14 @@ def cpu_baseline_mask3d(sample_voxels, runs=10, warmup=3, leg_budget_s=25.0, ful
             if time.perf_counter() - leg_t0 > leg_budget_s / 2:      # slow leg (oversubscribed host): one warm-up pass
                 break
         ts = []
+        # at least three timed passes — unless the leg is pathological: a pass that alone overruns twice the leg's budget
+        # ends the leg (round 6: with the process bound to one NUMA node the 128-thread leg took 571 s PER PASS and the
+        # default line 40 minutes; the binding is lifted for this function now, and no leg can do that again)
         while len(ts) < runs and (len(ts) < 3 or time.perf_counter() - leg_t0 < leg_budget_s):
             dt, nv = one_pass()
             ts.append(dt)
+            if time.perf_counter() - leg_t0 > 2 * leg_budget_s and len(ts) >= 1 and dt > leg_budget_s / 2:
+                break
         ts.sort()
         q = lambda f: ts[min(len(ts) - 1, int(round(f * (len(ts) - 1))))]
         legs[name] = {"threads": nthr, "timed_passes": len(ts), "median_s": q(0.5), "p10_s": q(0.1), "p90_s": q(0.9),
